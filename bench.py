@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s of velvet-noise decorrelation on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "cfg2"): synthetic 48 kHz stereo float32,
+10 s per signal, 30 taps over 30 ms (seed 1, the reference generator's
+defaults).  One cfg2 signal is only 3.84 MB, which lives in the 256 MiB
+Infinity Cache, so a *step* is one pass of the hot path over a resident pool of
+``--pool`` DISTINCT cfg2 signals in one batched launch (default 128 signals:
+491 MB read + 491 MB written per step, past the cache - SURVEY.md §8d).
+"1 sample" = one float32 output channel-sample.
+
+One process per GPU (torch.distributed / RCCL when launched by torchrun).  The
+path shards by independent streams: each rank owns its own pool, the only
+communication is one RCCL broadcast of the serialized tap table before the
+timed region, and no collective sits on the data path ("scaling": "weak").
+
+The JSON line also carries
+  roofline      algorithmic HBM bytes (8 B per output sample) / kernel time
+                measured with HIP events on the launch stream, vs 8 TB/s;
+  cpu_baseline  the NumPy restatement of the reference's convolve_velvet_noise
+                (oracle/vnd_oracle.py, single thread - NumPy slicing does not
+                multithread) timed on this host on a bounded number of cfg2
+                signals; rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+import numpy as np
+
+REPO = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+SAMPLE_RATE = 48000
+SECONDS = 10
+CHANNELS = 2
+TAPS = 30
+FIR_SECONDS = 0.03
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+ALGO_BYTES_PER_SAMPLE = 8      # 4 B read + 4 B written per output channel-sample
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--pool', type=int, default=128, help='distinct cfg2 signals per rank and step')
+    ap.add_argument('--mode', choices=['exact', 'fma'], default=os.environ.get('VND_BENCH_MODE', 'exact'))
+    ap.add_argument('--cpu-seconds', type=float, default=10.0, help='budget of the CPU baseline leg')
+    ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--variant', type=int, default=-1, help='kernel variant override (tuning)')
+    return ap.parse_args()
+
+
+def cpu_baseline(budget_s: float) -> dict:
+    """Reference CPU path (NumPy restatement, bit-identical to the reference) on
+    whole cfg2 signals until ~budget_s of CPU time is spent."""
+    from oracle import vnd_oracle as O
+    fir = O.generate_velvet_noise(duration_seconds=FIR_SECONDS, num_impulses=TAPS, num_outs=CHANNELS,
+                                  sample_rate_hz=SAMPLE_RATE, seed=1)
+    x = np.random.default_rng(0).uniform(-1, 1, (SAMPLE_RATE * SECONDS, CHANNELS)).astype(np.float32)
+    O.convolve_velvet_noise(x, fir)                      # warm-up
+    reps, spent, best = 0, 0.0, float('inf')
+    while spent < budget_s and reps < 1000:
+        t = time.perf_counter()
+        O.convolve_velvet_noise(x, fir)
+        dt = time.perf_counter() - t
+        spent += dt
+        best = min(best, dt)
+        reps += 1
+    mean = spent / reps
+    return {'value': round(x.size / mean / 1e6, 3), 'unit': 'Msamples/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{reps} x one cfg2 signal ({x.shape[0]}x{x.shape[1]} f32, {TAPS} taps), '
+                      f'NumPy restatement of convolve_velvet_noise, mean {mean * 1e3:.1f} ms, '
+                      f'min {best * 1e3:.1f} ms, host cores available {os.cpu_count()}',
+            'best_value': round(x.size / best / 1e6, 3)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch multi-GPU runs with: python -m torch.distributed.run '
+                             '--nproc-per-node N bench.py --gpus N ...')
+    os.environ['VND_DEVICE'] = str(local_rank)
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=device)      # nccl == RCCL on ROCm
+
+    import vndecorrelate_amd.decorrelation as vnd
+    from vndecorrelate_amd import _native
+    from vndecorrelate_amd.taps import function_path_arrays
+
+    ctx = _native.default_context()
+    ctx.set_variant(args.variant)
+    mode = vnd.MODE_EXACT if args.mode == 'exact' else vnd.MODE_FMA
+
+    # ---- shared impulse table: built on rank 0, broadcast over RCCL/xGMI ------
+    if rank == 0:
+        fir = vnd.generate_velvet_noise(duration_seconds=FIR_SECONDS, num_impulses=TAPS,
+                                        num_outs=CHANNELS, sample_rate_hz=SAMPLE_RATE, seed=1)
+        arrays = function_path_arrays(fir)
+        image = _native.TapTable.create(ctx, arrays.tap_offsets, arrays.tap_index,
+                                        arrays.tap_weight).to_bytes()
+    else:
+        image = b''
+    if world > 1:
+        size = torch.tensor([len(image)], dtype=torch.int64, device=device)
+        dist.broadcast(size, src=0)
+        buf = torch.empty(int(size.item()), dtype=torch.uint8, device=device)
+        if rank == 0:
+            buf.copy_(torch.frombuffer(bytearray(image), dtype=torch.uint8))
+        dist.broadcast(buf, src=0)
+        image = bytes(buf.cpu().numpy().tobytes())
+    table = _native.TapTable.from_bytes(ctx, image)
+
+    # ---- resident synthetic pool: (pool, N, C) float32 in HBM --------------------
+    n = SAMPLE_RATE * SECONDS
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + rank)
+    x = torch.empty((args.pool, n, CHANNELS), dtype=torch.float32, device=device)
+    x.uniform_(-1.0, 1.0, generator=gen)
+    y = torch.empty_like(x)
+    stream = torch.cuda.current_stream().cuda_stream
+    samples_per_step = args.pool * n * CHANNELS
+
+    def step():
+        table.convolve_device(x.data_ptr(), y.data_ptr(), args.pool, n, CHANNELS, mode, stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()                     # same stream the kernels are launched on
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # spot-check the timed output against the oracle on one stream (rank 0)
+    if rank == 0:
+        from oracle import c_oracle
+        xs = x[args.pool - 1].cpu().numpy()
+        want = c_oracle.convolve(xs, arrays.tap_offsets, arrays.tap_index, arrays.tap_weight, threads=8)
+        got = y[args.pool - 1].cpu().numpy()
+        if mode == vnd.MODE_EXACT:
+            assert np.array_equal(got, want), 'bench output differs from the oracle'
+        else:
+            assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want))
+
+    if rank == 0:
+        value = world * samples_per_step * args.steps / elapsed / 1e6
+        achieved = ALGO_BYTES_PER_SAMPLE * samples_per_step / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        prof = REPO / 'profiles' / 'hbm_traffic.json'
+        if prof.exists():
+            traffic = json.loads(prof.read_text()).get('bytes_per_launch')
+        line = {
+            'metric': 'Msamples/sec decorrelated (stereo, 30 taps) + achieved HBM GB/s vs roofline',
+            'value': round(value, 1), 'unit': 'Msamples/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'cfg2: 48 kHz stereo float32, 10 s, 30 taps / 30 ms velvet FIR (seed 1); '
+                                   f'{args.pool} distinct signals resident per GPU, one batched launch per step',
+                       'pool_signals_per_gpu': args.pool, 'frames': n, 'channels': CHANNELS,
+                       'arithmetic': args.mode, 'launch': table.describe(args.pool, n, CHANNELS, mode),
+                       'sharding': 'independent streams per rank; RCCL broadcast of the tap table only'},
+            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'kernel_ms': round(kernel_ms, 4),
+                         'algorithmic_bytes_per_launch': ALGO_BYTES_PER_SAMPLE * samples_per_step},
+        }
+        if world == 1 and not args.no_cpu:
+            line['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,123 @@
+/* vnd_amd.h - C ABI of the MI355X (gfx950) velvet-noise decorrelator.
+ *
+ * The reference (ckonst/VNDecorrelate v1.1.0) is pure Python and has no FFI:
+ * its boundary for this path is the Python call surface.  Each entry point
+ * below names the reference interface it stands behind (file:line relative to
+ * the reference checkout).  The Python host layer (vndecorrelate_amd/) keeps
+ * the reference's names, arguments and exceptions and calls these through
+ * ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain C types only; no C++ exceptions cross the ABI; every call returns a
+ *    vnd_status (0 = ok) and vnd_last_error() gives the text for this thread;
+ *  - signals are frame-interleaved, C-contiguous float32: (n_frames, C), or
+ *    (batch, n_frames, C) for independent streams - the reference's layout
+ *    (decorrelation.py:647), so the host never transposes;
+ *  - "*_dev" functions take DEVICE pointers (hipMalloc / torch) and a
+ *    hipStream_t passed as void*; they enqueue and return (no sync).  "*_host"
+ *    functions take host pointers, copy H2D/D2H around the same kernels and
+ *    return after the result is in `y` - the reference's synchronous semantics;
+ *  - the caller owns every buffer it passes; handles own device memory;
+ *  - a handle is used by one thread at a time; distinct handles are independent.
+ */
+#ifndef VND_AMD_H
+#define VND_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VND_ABI_VERSION 1
+
+typedef enum vnd_status {
+    VND_OK = 0,
+    VND_ERR_INVALID = 1,      /* bad argument (host layer maps to ValueError)      */
+    VND_ERR_NO_DEVICE = 2,    /* no gfx950 device / HIP runtime failed to start   */
+    VND_ERR_HIP = 3,          /* a HIP call failed; see vnd_last_error()          */
+    VND_ERR_UNSUPPORTED = 4,  /* shape outside what the kernels cover             */
+    VND_ERR_NOMEM = 5
+} vnd_status;
+
+/* Arithmetic of the tap sum (argument `mode` of the convolve calls). */
+typedef enum vnd_mode {
+    VND_MODE_EXACT = 0,  /* acc = f32(acc + f32(x*w)), taps in table order: bit-identical
+                            to the reference's NumPy paths (decorrelation.py:656-658, :405-414) */
+    VND_MODE_FMA = 1     /* acc = fma(x, w, acc): one rounding per tap, <= 1e-6 of peak    */
+} vnd_mode;
+
+typedef struct vnd_ctx vnd_ctx;     /* one per (process, device)                      */
+typedef struct vnd_taps vnd_taps;   /* device-resident tap table, immutable            */
+
+/* ---- library / device ---------------------------------------------------- */
+int vnd_abi_version(void);
+const char *vnd_last_error(void);
+vnd_status vnd_device_count(int32_t *count);
+vnd_status vnd_ctx_create(int32_t device, vnd_ctx **ctx);
+vnd_status vnd_ctx_destroy(vnd_ctx *ctx);
+/* name (<= len-1 chars), compute units, bytes of HBM, LDS bytes per workgroup */
+vnd_status vnd_ctx_info(const vnd_ctx *ctx, char *name, int32_t len, int32_t *compute_units,
+                        int64_t *hbm_bytes, int32_t *lds_bytes);
+
+/* ---- tap tables ------------------------------------------------------------
+ * CSR over output channels: taps of channel c are [tap_offsets[c], tap_offsets[c+1])
+ * of tap_index / tap_weight, consumed IN TABLE ORDER.
+ *
+ * Function-path table (replaces the np.where scan of decorrelation.py:651-654):
+ *   seg_offsets = seg_end = seg_gain = NULL; indices ascending.
+ * Class-path table (replaces _ParallelVelvetNoise, decorrelation.py:240-323,
+ * consumed by VelvetNoise.convolve :402-414): per channel a CSR of segments,
+ * seg_end[s] = exclusive end (absolute position in tap_index) of segment s,
+ * seg_gain[s] = segment_envelope[s]; weights are -1 (negatives first) / +1;
+ * apply_gain = 0 reproduces the skipped multiply of the identity envelope (:411).
+ * chan_flags[c] & 1 marks an unfiltered channel that is copied through (:399-400);
+ * may be NULL.  All indices must be >= 0.  Arrays are HOST pointers, copied.   */
+vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t num_channels,
+                           const int32_t *tap_offsets, const int32_t *tap_index,
+                           const float *tap_weight,
+                           const int32_t *seg_offsets, const int32_t *seg_end,
+                           const float *seg_gain, const uint8_t *chan_flags,
+                           int32_t apply_gain, vnd_taps **taps);
+vnd_status vnd_taps_destroy(vnd_taps *taps);
+vnd_status vnd_taps_info(const vnd_taps *taps, int32_t *num_channels, int32_t *total_taps,
+                         int32_t *max_index);
+/* Packed image of a table for transport between ranks (RCCL broadcast of the
+ * shared impulse tables): serialise on rank 0, broadcast bytes, rebuild.      */
+vnd_status vnd_taps_serialize(const vnd_taps *taps, void *buf, int64_t capacity, int64_t *bytes);
+vnd_status vnd_taps_deserialize(vnd_ctx *ctx, const void *buf, int64_t bytes, vnd_taps **taps);
+
+/* ---- the hot path ------------------------------------------------------------
+ * y[b,n,c] = sum_k w[c,k] * x[b, n + i[c,k], c]   (terms with n+i >= n_frames drop)
+ * Replaces convolve_velvet_noise (decorrelation.py:630-660) and
+ * VelvetNoise.convolve (decorrelation.py:393-415).  x and y must not overlap.
+ * n_channels must equal the table's num_channels.  batch >= 0, n_frames >= 0.  */
+vnd_status vnd_convolve_f32_dev(vnd_ctx *ctx, const vnd_taps *taps, const float *x_dev,
+                                float *y_dev, int64_t batch, int64_t n_frames,
+                                int32_t n_channels, int32_t mode, void *hip_stream);
+vnd_status vnd_convolve_f32_host(vnd_ctx *ctx, const vnd_taps *taps, const float *x,
+                                 float *y, int64_t batch, int64_t n_frames,
+                                 int32_t n_channels, int32_t mode);
+
+/* ---- measurement helpers (used by bench.py; not on the data path) ---------- */
+/* Launches the convolve `iters` times back to back on `hip_stream`, cycling
+ * through `n_buffers` (x,y) pairs laid out at x_dev + i*stride_elems, and
+ * returns the average kernel milliseconds between two hipEvents recorded on
+ * that same stream.                                                          */
+vnd_status vnd_time_convolve_f32_dev(vnd_ctx *ctx, const vnd_taps *taps, const float *x_dev,
+                                     float *y_dev, int64_t batch, int64_t n_frames,
+                                     int32_t n_channels, int32_t mode, int32_t n_buffers,
+                                     int64_t stride_elems, int32_t iters, void *hip_stream,
+                                     float *avg_ms);
+/* Kernel variant override for tuning runs: -1 = automatic choice. */
+vnd_status vnd_set_variant(vnd_ctx *ctx, int32_t variant);
+/* Describes the launch the library would make (for DESIGN.md / bench output). */
+vnd_status vnd_describe_launch(vnd_ctx *ctx, const vnd_taps *taps, int64_t batch,
+                               int64_t n_frames, int32_t n_channels, int32_t mode,
+                               char *text, int32_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VND_AMD_H */

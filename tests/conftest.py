@@ -1,0 +1,108 @@
+import json
+import pathlib
+import sys
+
+import numpy as np
+import pytest
+
+REPO = pathlib.Path(__file__).resolve().parents[1]
+if str(REPO) not in sys.path:
+    sys.path.insert(0, str(REPO))
+
+GOLDEN_DIR = REPO / 'tests' / 'golden'
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+class Golden:
+    """Fixtures captured from the reference by oracle/gen_golden.py."""
+
+    def __init__(self):
+        self.manifest = json.loads((GOLDEN_DIR / 'manifest.json').read_text())
+        self.arrays = np.load(GOLDEN_DIR / 'golden.npz')
+        self.slice = self.manifest['slice']
+
+    def fir(self, gname):
+        """Dense float32 FIR rebuilt from the stored reference tap table."""
+        meta = self.manifest['generators'][gname]
+        fir = np.zeros(tuple(meta['fir_shape']), np.float32)
+        offs = self.arrays[f'gen_{gname}_offsets']
+        idx, w = self.arrays[f'gen_{gname}_idx'], self.arrays[f'gen_{gname}_w']
+        for c in range(fir.shape[1]):
+            fir[idx[offs[c]:offs[c + 1]], c] = w[offs[c]:offs[c + 1]]
+        return fir
+
+    def class_taps(self, cname, num_outs):
+        """Nested (neg, pos) lists per channel/segment from the stored rows."""
+        rows = self.arrays[f'taps_{cname}']
+        nseg = len(self.manifest['class_taps'][cname]['envelope'])
+        chans = sorted(set(rows[:, 0].tolist()))
+        out = []
+        for c in range(num_outs):
+            if c not in chans:
+                out.append(None)
+                continue
+            segs = [([], []) for _ in range(nseg)]
+            for ch, s, sign, i in rows[rows[:, 0] == c]:
+                segs[s][sign].append(int(i))
+            out.append(segs)
+        return out
+
+    def expect(self, name, y, *, exact=True, rtol_peak=None):
+        """Compare y with the stored reference output of case `name`."""
+        import hashlib
+        meta = None
+        for group in ('fn', 'cls_convolve', 'cls_decorrelate'):
+            if name in self.manifest[group]:
+                meta = self.manifest[group][name]['out']
+        assert meta is not None, name
+        assert list(y.shape) == meta['shape'], (y.shape, meta['shape'])
+        assert str(y.dtype) == meta['dtype']
+        peak = max(meta['max_abs'], 1e-30)
+        if exact:
+            got = hashlib.sha256(np.ascontiguousarray(y).tobytes()).hexdigest()
+            if got != meta['sha256']:
+                ref_parts = self.parts(name, y)
+                worst = max((float(np.max(np.abs(a.astype(np.float64) - b))) if a.size else 0.0)
+                            for a, b in ref_parts)
+                raise AssertionError(f'{name}: sha256 differs from the reference output '
+                                     f'(max |diff| on stored slices {worst:.3e}, peak {peak:.3e})')
+        else:
+            for a, b in self.parts(name, y):
+                if a.size:
+                    err = float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))) / peak
+                    assert err <= rtol_peak, f'{name}: {err:.3e} of peak > {rtol_peak:.1e}'
+
+    def parts(self, name, y):
+        if f'{name}_full' in self.arrays:
+            return [(y, self.arrays[f'{name}_full'])]
+        return [(y[:self.slice], self.arrays[f'{name}_head']),
+                (y[-self.slice:], self.arrays[f'{name}_tail'])]
+
+
+@pytest.fixture(scope='session')
+def golden():
+    return Golden()
+
+
+def make_input(spec) -> np.ndarray:
+    """Same seeded recipe as oracle/gen_golden.py:make_input."""
+    rng = np.random.default_rng(spec['seed'])
+    shape = tuple(spec['shape'])
+    kind = spec.get('dist', 'uniform_pm1')
+    if kind == 'uniform_pm1':
+        x = rng.uniform(-1, 1, shape)
+    elif kind == 'uniform_01':
+        x = rng.uniform(0, 1, shape)
+    elif kind == 'int16':
+        return rng.integers(-32768, 32767, shape, dtype=np.int16)
+    elif kind == 'zeros':
+        x = np.zeros(shape)
+    elif kind == 'impulse':
+        x = np.zeros(shape)
+        x[spec['at']] = 1.0
+    else:
+        raise ValueError(kind)
+    return x.astype(spec.get('dtype', 'float32'))

@@ -1,0 +1,278 @@
+"""GPU tier (-m gpu): the HIP path, called through the C ABI, against the oracle
+and against the fixtures captured from the reference.
+
+Bars: VND_MODE_EXACT is BIT-EXACT for float32 input (sha256 of the whole output
+equals the reference's); VND_MODE_FMA and non-float32 inputs (rounded to float32
+at the boundary) stay within 1e-6 of the output peak - the north-star tolerance.
+"""
+import json
+import pathlib
+
+import numpy as np
+import pytest
+
+from conftest import make_input
+from oracle import c_oracle
+from oracle import vnd_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_PEAK = 1e-6
+MANIFEST = json.loads((pathlib.Path(__file__).parent / 'golden' / 'manifest.json').read_text())
+
+
+@pytest.fixture(scope='module')
+def vnd():
+    import vndecorrelate_amd.decorrelation as d
+    from vndecorrelate_amd import _native
+    ctx = _native.default_context()      # raises without the .so or without a GPU
+    assert 'gfx950' in ctx.info()['name']
+    yield d
+    ctx.set_variant(-1)
+    d.set_default_mode(d.MODE_EXACT)
+
+
+def _kw(d):
+    return {k: (tuple(v) if isinstance(v, list) else v) for k, v in d.items()}
+
+
+def _fir_for(golden, name, meta):
+    if name == 'fn_f64_fir':
+        cm = golden.manifest['class_taps'][meta['class']]
+        kw = {k: v for k, v in _kw(cm['kwargs']).items() if k not in ('width', 'mode', 'normalizer')}
+        return O.class_fir(O.generate_class_taps(num_outs=2, **kw), cm['envelope'], cm['fir_length_samples'])
+    return golden.fir(meta['generator'])
+
+
+# ---- a1: convolve_velvet_noise ------------------------------------------------
+@pytest.mark.parametrize('name', sorted(MANIFEST['fn']))
+def test_function_path_exact(vnd, golden, name):
+    meta = golden.manifest['fn'][name]
+    x = make_input(meta['input'])
+    fir = _fir_for(golden, name, meta)
+    if name == 'fn_cfg4_b4':
+        y = vnd.convolve_velvet_noise_batched(x, fir, mode=vnd.MODE_EXACT)
+        assert np.array_equal(y[:, :golden.slice], golden.arrays['fn_cfg4_b4_head'])
+        assert np.array_equal(y[:, -golden.slice:], golden.arrays['fn_cfg4_b4_tail'])
+        import hashlib
+        for b, want in enumerate(meta['per_stream_sha256']):
+            assert hashlib.sha256(y[b].tobytes()).hexdigest() == want
+        return
+    y = vnd.convolve_velvet_noise(x, fir, mode=vnd.MODE_EXACT)
+    float32_in = x.dtype == np.float32 and fir.dtype == np.float32
+    golden.expect(name, y, exact=float32_in, rtol_peak=TOL_PEAK)
+    if not float32_in and x.size:
+        # what the ABI computes is exact on the float32-rounded operands
+        offs, idx, w = O.fir_to_taps(fir.astype(np.float32))
+        assert np.array_equal(y, c_oracle.convolve(x.astype(np.float32), offs, idx, w))
+
+
+@pytest.mark.parametrize('name', sorted(n for n in MANIFEST['fn'] if n != 'fn_cfg4_b4'))
+def test_function_path_fma(vnd, golden, name):
+    meta = golden.manifest['fn'][name]
+    x = make_input(meta['input'])
+    y = vnd.convolve_velvet_noise(x, _fir_for(golden, name, meta), mode=vnd.MODE_FMA)
+    golden.expect(name, y, exact=False, rtol_peak=TOL_PEAK)
+
+
+def test_function_path_errors(vnd, golden):
+    fir8 = golden.fir('g96k_k64_c8')
+    with pytest.raises(ValueError):
+        vnd.convolve_velvet_noise(np.zeros((10, 2), np.float32), fir8)
+    with pytest.raises(IndexError):
+        vnd.convolve_velvet_noise(np.zeros(10, np.float32), golden.fir('g44k_mono'))
+    # (n, 1) signal against a 2-column FIR uses column 0, as upstream
+    x = make_input(dict(seed=1, shape=[3000, 1]))
+    fir = golden.fir('g44k_k30')
+    assert np.array_equal(vnd.convolve_velvet_noise(x, fir), O.convolve_velvet_noise(x, fir))
+
+
+# ---- a6: VelvetNoise.convolve ---------------------------------------------------
+@pytest.mark.parametrize('name', sorted(MANIFEST['cls_convolve']))
+def test_class_convolve(vnd, golden, name):
+    meta = golden.manifest['cls_convolve'][name]
+    kw = _kw(golden.manifest['class_taps'][meta['class']]['kwargs'])
+    vn = vnd.VelvetNoise(**kw)
+    x = make_input(meta['input'])
+    y = vn.convolve(x)
+    golden.expect(name, y, exact=x.dtype == np.float32, rtol_peak=TOL_PEAK)
+    vnd.set_default_mode(vnd.MODE_FMA)       # weights are +-1: FMA is exact here too
+    try:
+        golden.expect(name, vn.convolve(x), exact=x.dtype == np.float32, rtol_peak=TOL_PEAK)
+    finally:
+        vnd.set_default_mode(vnd.MODE_EXACT)
+
+
+# ---- a8: VelvetNoise.decorrelate / SignalChain ----------------------------------
+@pytest.mark.parametrize('name', sorted(MANIFEST['cls_decorrelate']))
+def test_class_decorrelate(vnd, golden, name):
+    meta = golden.manifest['cls_decorrelate'][name]
+    kw = _kw(golden.manifest['class_taps'][meta['class']]['kwargs'])
+    y = vnd.VelvetNoise(**kw).decorrelate(make_input(meta['input']))
+    golden.expect(name, y, exact=True)
+
+
+def test_viola_excerpt_and_chain(vnd, golden):
+    a = golden.arrays
+    x = a['viola_excerpt_in']
+    kw = _kw(golden.manifest['class_taps']['v44k_20ms']['kwargs'])
+    vn = vnd.VelvetNoise(**kw)
+    assert np.array_equal(vn.decorrelate(x.copy()), a['viola_excerpt_decorrelate'])
+    assert np.array_equal(vn.convolve(x), a['viola_excerpt_convolve'])
+    assert np.array_equal(vnd.convolve_velvet_noise(x, golden.fir('g44k_20ms')), a['viola_excerpt_fn'])
+    # tests/test_example.py's chain: VN (MS) -> Haas (LR)
+    rate = golden.manifest['audio']['viola_excerpt']['fs']
+    chain = (vnd.SignalChain(sample_rate_hz=rate)
+             .velvet_noise(**{k: v for k, v in kw.items() if k != 'sample_rate_hz'})
+             .haas_effect(delay_time_seconds=0.02, delayed_channel=1, mode='LR'))
+    want = O.haas_delay_lr(a['viola_excerpt_decorrelate'], sample_rate_hz=rate,
+                           delay_time_seconds=0.02, delayed_channel=1)
+    got = chain(x.copy())
+    assert got.dtype == np.float64 and np.array_equal(got, want)
+
+
+def test_reference_equality_tests(vnd):
+    """tests/test_decorrelation.py:71-93 and :172-197 restated on the GPU path."""
+    kw = dict(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=44100,
+              segment_envelope=(0.85, 0.55, 0.35, 0.2), log_distribution_strength=1.0, seed=1)
+    vn = vnd.VelvetNoise(**kw)
+    fir = vnd.generate_velvet_noise(**kw)
+    assert np.allclose(vn.FIR, fir, atol=1e-6)
+    x = np.random.default_rng(123).random((10000, 2))
+    y1 = vnd.convolve_velvet_noise(x, fir)
+    y2 = vn.convolve(x)
+    assert y1.shape == y2.shape and np.allclose(y1, y2, atol=1e-6)
+    chain = (vnd.SignalChain(sample_rate_hz=44100)
+             .velvet_noise(duration_seconds=0.03, num_impulses=30, width=0.5)
+             .haas_effect(delay_time_seconds=0.0197, delayed_channel=1, mode='LR')
+             .haas_effect(delay_time_seconds=0.0096, delayed_channel=1, mode='MS')
+             .white_noise(duration_seconds=0.03, width=0.5)
+             .stateless(vnd.convolve_velvet_noise,
+                        vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=30)))
+    out = chain(np.zeros(1000))
+    assert out.shape[0] > 1000 and out.shape[1] == 2
+    out = vnd.VelvetNoise(sample_rate_hz=44100)(np.zeros(1000))
+    assert out.shape == (1000, 2)
+
+
+# ---- kernel variants: every tiling must give the same bits ------------------------
+def _variant(r_log2=None, dual=None, cg=0, direct=False):
+    v = 0
+    if r_log2 is not None:
+        v |= r_log2 + 1
+    if dual is not None:
+        v |= (1 << 5) | (int(dual) << 4)
+    v |= cg << 8
+    v |= int(direct) << 12
+    return v
+
+
+@pytest.mark.parametrize('channels,gname', [(2, 'g48k_k30'), (1, 'g44k_mono'), (8, 'g96k_k64_c8'),
+                                            (3, 'g48k_c3'), (2, 'g48k_k128_u')])
+def test_variants_agree(vnd, golden, channels, gname):
+    from vndecorrelate_amd import _native
+    ctx = _native.default_context()
+    fir = golden.fir(gname)
+    x = make_input(dict(seed=11, shape=[20011, channels]))
+    offs, idx, w = O.fir_to_taps(fir)
+    want = c_oracle.convolve(x, offs, idx, w)
+    cgs = [c for c in (1, 2, 4) if channels % c == 0]
+    try:
+        for mode in (vnd.MODE_EXACT, vnd.MODE_FMA):
+            for direct in (False, True):
+                for cg in ([0] if direct else cgs):
+                    for r in ([None] if direct else range(5)):
+                        for dual in ([None] if direct else (0, 1)):
+                            ctx.set_variant(_variant(r, dual, cg, direct))
+                            y = vnd.convolve_velvet_noise(x, fir, mode=mode)
+                            tag = f'mode={mode} direct={direct} cg={cg} r={r} dual={dual}'
+                            if mode == vnd.MODE_EXACT:
+                                assert np.array_equal(y, want), tag
+                            else:
+                                err = np.max(np.abs(y.astype(np.float64) - want)) / np.max(np.abs(want))
+                                assert err <= TOL_PEAK, (tag, err)
+    finally:
+        ctx.set_variant(-1)
+
+
+def test_class_variants_agree(vnd, golden):
+    from vndecorrelate_amd import _native
+    ctx = _native.default_context()
+    meta = golden.manifest['cls_convolve']['cls_k128_dups']
+    vn = vnd.VelvetNoise(**_kw(golden.manifest['class_taps'][meta['class']]['kwargs']))
+    x = make_input(meta['input'])
+    try:
+        for v in (_variant(0, 0, 1), _variant(2, 1, 2), _variant(4, 1, 1), _variant(direct=True)):
+            ctx.set_variant(v)
+            golden.expect('cls_k128_dups', vn.convolve(x))
+    finally:
+        ctx.set_variant(-1)
+
+
+def test_long_fir_falls_back(vnd):
+    """A 2 s FIR cannot be staged in LDS: the direct kernel takes over."""
+    fir = vnd.generate_velvet_noise(duration_seconds=2.0, num_impulses=40, sample_rate_hz=48000, seed=4)
+    x = make_input(dict(seed=2, shape=[150000, 2]))
+    y = vnd.convolve_velvet_noise(x, fir)
+    offs, idx, w = O.fir_to_taps(fir)
+    assert np.array_equal(y, c_oracle.convolve(x, offs, idx, w, threads=4))
+
+
+# ---- size-independent properties at BASELINE sizes ----------------------------------
+def test_linearity_and_shift_cfg2(vnd, golden):
+    fir = golden.fir('g48k_k30')
+    rng = np.random.default_rng(5)
+    x1 = rng.uniform(-1, 1, (480000, 2)).astype(np.float32)
+    # exact dyadic scaling commutes with every float32 op of the path
+    y1 = vnd.convolve_velvet_noise(x1, fir)
+    y2 = vnd.convolve_velvet_noise(x1 * np.float32(0.25), fir)
+    assert np.array_equal(y2, y1 * np.float32(0.25))
+    # anti-causal shift: dropping the first s frames of x drops the first s frames of y
+    s = 4097
+    y3 = vnd.convolve_velvet_noise(np.ascontiguousarray(x1[s:]), fir)
+    assert np.array_equal(y3, y1[s:])
+    # a unit impulse at frame m reads back the time-reversed filter: y[m - i] = w_i
+    m = 300000
+    imp = np.zeros((480000, 2), np.float32)
+    imp[m] = 1.0
+    yi = vnd.convolve_velvet_noise(imp, fir)
+    assert np.array_equal(yi[m - fir.shape[0] + 1:m + 1][::-1], fir)
+    assert not yi[:m - fir.shape[0] + 1].any() and not yi[m + 1:].any()
+
+
+def test_batched_equals_loop(vnd, golden):
+    fir = golden.fir('g48k_k30')
+    x = make_input(dict(seed=3, shape=[37, 48000, 2]))
+    yb = vnd.convolve_velvet_noise_batched(x, fir)
+    offs, idx, w = O.fir_to_taps(fir)
+    assert np.array_equal(yb, c_oracle.convolve(x, offs, idx, w, threads=8))
+    # ragged tail: a stream length that is not a multiple of anything
+    x = make_input(dict(seed=4, shape=[5, 10007, 2]))
+    assert np.array_equal(vnd.convolve_velvet_noise_batched(x, fir),
+                          c_oracle.convolve(x, offs, idx, w, threads=4))
+
+
+# ---- device-pointer entry + table transport -------------------------------------------
+def test_device_pointer_api_and_table_roundtrip(vnd, golden):
+    import torch
+    from vndecorrelate_amd import _native
+    from vndecorrelate_amd.taps import function_path_arrays
+    ctx = _native.default_context()
+    fir = golden.fir('g48k_k30')
+    arrays = function_path_arrays(fir)
+    table = _native.TapTable.create(ctx, arrays.tap_offsets, arrays.tap_index, arrays.tap_weight)
+    image = table.to_bytes()
+    clone = _native.TapTable.from_bytes(ctx, image)
+    assert clone.to_bytes() == image and clone.total_taps == 60 and clone.num_channels == 2
+    x = make_input(dict(seed=8, shape=[6, 30000, 2]))
+    xd = torch.from_numpy(x).to('cuda:0')
+    yd = torch.empty_like(xd)
+    stream = torch.cuda.current_stream().cuda_stream
+    clone.convolve_device(xd.data_ptr(), yd.data_ptr(), 6, 30000, 2, vnd.MODE_EXACT, stream)
+    torch.cuda.synchronize()
+    offs, idx, w = O.fir_to_taps(fir)
+    assert np.array_equal(yd.cpu().numpy(), c_oracle.convolve(x, offs, idx, w, threads=4))
+    with pytest.raises(ValueError):
+        clone.convolve_device(xd.data_ptr(), yd.data_ptr(), 6, 30000, 3, vnd.MODE_EXACT, stream)
+    with pytest.raises(ValueError):      # overlapping buffers
+        clone.convolve_device(xd.data_ptr(), xd.data_ptr(), 6, 30000, 2, vnd.MODE_EXACT, stream)

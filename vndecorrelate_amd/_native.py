@@ -1,0 +1,276 @@
+"""ctypes binding of ``libvnd_amd.so`` (C ABI in ``include/vnd_amd.h``).
+
+This is the only way the package computes anything: there is no NumPy or CPU
+fallback.  If the shared library is missing, or no gfx950 device is visible,
+the first call that needs the GPU raises ``RuntimeError`` - loudly, by design.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import pathlib
+import threading
+from typing import Optional
+
+import numpy as np
+
+ABI_VERSION = 1
+MODE_EXACT = 0   # acc = f32(acc + f32(x*w)) : bit-identical to the reference's NumPy paths
+MODE_FMA = 1     # acc = fma(x, w, acc)
+
+_PKG = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _PKG / 'libvnd_amd.so'
+
+_c_i32p = ctypes.POINTER(ctypes.c_int32)
+_c_f32p = ctypes.POINTER(ctypes.c_float)
+_c_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+# name -> (restype, argtypes); also the list tests/test_abi.py checks against the header
+SIGNATURES = {
+    'vnd_abi_version': (ctypes.c_int, []),
+    'vnd_last_error': (ctypes.c_char_p, []),
+    'vnd_device_count': (ctypes.c_int, [_c_i32p]),
+    'vnd_ctx_create': (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]),
+    'vnd_ctx_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+    'vnd_ctx_info': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int32, _c_i32p,
+                                    ctypes.POINTER(ctypes.c_int64), _c_i32p]),
+    'vnd_taps_create': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, _c_i32p, _c_i32p, _c_f32p,
+                                       _c_i32p, _c_i32p, _c_f32p, _c_u8p, ctypes.c_int32,
+                                       ctypes.POINTER(ctypes.c_void_p)]),
+    'vnd_taps_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+    'vnd_taps_info': (ctypes.c_int, [ctypes.c_void_p, _c_i32p, _c_i32p, _c_i32p]),
+    'vnd_taps_serialize': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                          ctypes.POINTER(ctypes.c_int64)]),
+    'vnd_taps_deserialize': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                            ctypes.POINTER(ctypes.c_void_p)]),
+    'vnd_convolve_f32_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                            ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    'vnd_convolve_f32_host': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_f32p, _c_f32p,
+                                             ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+                                             ctypes.c_int32]),
+    'vnd_time_convolve_f32_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                 ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                                 ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                 ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,
+                                                 _c_f32p]),
+    'vnd_set_variant': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
+    'vnd_describe_launch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                           ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                           ctypes.c_char_p, ctypes.c_int32]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+class NativeError(RuntimeError):
+    """The HIP extension is missing or a device call failed."""
+
+
+def load_library():
+    """dlopen the in-tree extension and declare every prototype of the header."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not LIB_PATH.exists():
+            raise NativeError(
+                f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; '
+                f'g.build()"` (hipcc --offload-arch=gfx950).  vndecorrelate_amd has no CPU fallback.')
+        lib = ctypes.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        got = lib.vnd_abi_version()
+        if got != ABI_VERSION:
+            raise NativeError(f'{LIB_PATH} has ABI {got}, expected {ABI_VERSION}: rebuild it')
+        _lib = lib
+        return lib
+
+
+def _check(rc: int, what: str):
+    if rc == 0:
+        return
+    msg = load_library().vnd_last_error().decode(errors='replace')
+    if rc == 1:
+        raise ValueError(f'{what}: {msg}')
+    raise NativeError(f'{what} failed (status {rc}): {msg}')
+
+
+def _ptr(a: Optional[np.ndarray], ctype):
+    return None if a is None else a.ctypes.data_as(ctypes.POINTER(ctype))
+
+
+class Context:
+    """One per (process, device): owns the stream and staging buffers of the
+    synchronous host-pointer calls."""
+
+    def __init__(self, device: int = 0):
+        lib = load_library()
+        h = ctypes.c_void_p()
+        _check(lib.vnd_ctx_create(int(device), ctypes.byref(h)), 'vnd_ctx_create')
+        self._lib = lib
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.vnd_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise NativeError('context is closed')
+        return self._h
+
+    def info(self) -> dict:
+        name = ctypes.create_string_buffer(256)
+        cus, lds = ctypes.c_int32(), ctypes.c_int32()
+        hbm = ctypes.c_int64()
+        _check(self._lib.vnd_ctx_info(self.handle, name, 256, ctypes.byref(cus), ctypes.byref(hbm),
+                                      ctypes.byref(lds)), 'vnd_ctx_info')
+        return {'name': name.value.decode(), 'compute_units': cus.value, 'hbm_bytes': hbm.value,
+                'lds_bytes': lds.value}
+
+    def set_variant(self, variant: int):
+        _check(self._lib.vnd_set_variant(self.handle, int(variant)), 'vnd_set_variant')
+
+
+class TapTable:
+    """Device-resident, immutable tap table (``vnd_taps``)."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        self._h = handle
+        c, t, m = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        _check(self._lib.vnd_taps_info(handle, ctypes.byref(c), ctypes.byref(t), ctypes.byref(m)),
+               'vnd_taps_info')
+        self.num_channels, self.total_taps, self.max_index = c.value, t.value, m.value
+
+    @classmethod
+    def create(cls, ctx: Context, tap_offsets, tap_index, tap_weight, *, seg_offsets=None,
+               seg_end=None, seg_gain=None, chan_flags=None, apply_gain=False) -> 'TapTable':
+        tap_offsets = np.ascontiguousarray(tap_offsets, np.int32)
+        tap_index = np.ascontiguousarray(tap_index, np.int32)
+        tap_weight = np.ascontiguousarray(tap_weight, np.float32)
+        channels = len(tap_offsets) - 1
+        if seg_offsets is not None:
+            seg_offsets = np.ascontiguousarray(seg_offsets, np.int32)
+            seg_end = np.ascontiguousarray(seg_end, np.int32)
+            seg_gain = np.ascontiguousarray(seg_gain, np.float32)
+        if chan_flags is not None:
+            chan_flags = np.ascontiguousarray(chan_flags, np.uint8)
+        h = ctypes.c_void_p()
+        _check(ctx._lib.vnd_taps_create(
+            ctx.handle, channels, _ptr(tap_offsets, ctypes.c_int32), _ptr(tap_index, ctypes.c_int32),
+            _ptr(tap_weight, ctypes.c_float), _ptr(seg_offsets, ctypes.c_int32),
+            _ptr(seg_end, ctypes.c_int32), _ptr(seg_gain, ctypes.c_float),
+            _ptr(chan_flags, ctypes.c_uint8), int(bool(apply_gain)), ctypes.byref(h)),
+            'vnd_taps_create')
+        return cls(ctx, h)
+
+    @classmethod
+    def from_bytes(cls, ctx: Context, image: bytes) -> 'TapTable':
+        buf = ctypes.create_string_buffer(image, len(image))
+        h = ctypes.c_void_p()
+        _check(ctx._lib.vnd_taps_deserialize(ctx.handle, buf, len(image), ctypes.byref(h)),
+               'vnd_taps_deserialize')
+        return cls(ctx, h)
+
+    def to_bytes(self) -> bytes:
+        need = ctypes.c_int64()
+        _check(self._lib.vnd_taps_serialize(self.handle, None, 0, ctypes.byref(need)),
+               'vnd_taps_serialize')
+        buf = ctypes.create_string_buffer(need.value)
+        _check(self._lib.vnd_taps_serialize(self.handle, buf, need.value, ctypes.byref(need)),
+               'vnd_taps_serialize')
+        return buf.raw[:need.value]
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise NativeError('tap table is closed')
+        return self._h
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.vnd_taps_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- the hot path ---------------------------------------------------------
+    def convolve_host(self, x: np.ndarray, mode: int = MODE_EXACT) -> np.ndarray:
+        """x: C-contiguous float32 ``(n, C)`` or ``(batch, n, C)``; returns a new array."""
+        if x.dtype != np.float32 or not x.flags.c_contiguous:
+            raise ValueError('convolve_host wants a C-contiguous float32 array')
+        if x.ndim == 2:
+            batch, (n, c) = 1, x.shape
+        elif x.ndim == 3:
+            batch, n, c = x.shape
+        else:
+            raise ValueError(f'expected (n, C) or (batch, n, C), got {x.shape}')
+        y = np.empty_like(x)
+        _check(self._lib.vnd_convolve_f32_host(self.ctx.handle, self.handle,
+                                               _ptr(x, ctypes.c_float), _ptr(y, ctypes.c_float),
+                                               batch, n, c, int(mode)), 'vnd_convolve_f32_host')
+        return y
+
+    def convolve_device(self, x_ptr: int, y_ptr: int, batch: int, n: int, channels: int,
+                        mode: int = MODE_EXACT, stream: int = 0):
+        """Enqueue on ``stream`` (a hipStream_t as int); pointers are device addresses."""
+        _check(self._lib.vnd_convolve_f32_dev(self.ctx.handle, self.handle,
+                                              ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr),
+                                              batch, n, channels, int(mode),
+                                              ctypes.c_void_p(stream)), 'vnd_convolve_f32_dev')
+
+    def time_device(self, x_ptr: int, y_ptr: int, batch: int, n: int, channels: int, *, mode: int,
+                    n_buffers: int, stride_elems: int, iters: int, stream: int = 0) -> float:
+        """Average milliseconds per launch between two hipEvents on ``stream``."""
+        ms = ctypes.c_float()
+        _check(self._lib.vnd_time_convolve_f32_dev(
+            self.ctx.handle, self.handle, ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr), batch, n,
+            channels, int(mode), n_buffers, stride_elems, iters, ctypes.c_void_p(stream),
+            ctypes.byref(ms)), 'vnd_time_convolve_f32_dev')
+        return ms.value
+
+    def describe(self, batch: int, n: int, channels: int, mode: int = MODE_EXACT) -> str:
+        buf = ctypes.create_string_buffer(512)
+        _check(self._lib.vnd_describe_launch(self.ctx.handle, self.handle, batch, n, channels,
+                                             int(mode), buf, 512), 'vnd_describe_launch')
+        return buf.value.decode()
+
+
+def device_count() -> int:
+    n = ctypes.c_int32()
+    rc = load_library().vnd_device_count(ctypes.byref(n))
+    return n.value if rc == 0 else 0
+
+
+_default_ctx: dict = {}
+
+
+def default_context() -> Context:
+    """Process-wide context on ``VND_DEVICE`` / ``LOCAL_RANK`` / device 0."""
+    dev = int(os.environ.get('VND_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+    n = device_count()
+    if n > 0:
+        dev %= n
+    ctx = _default_ctx.get(dev)
+    if ctx is None:
+        ctx = _default_ctx[dev] = Context(dev)
+    return ctx

@@ -1,0 +1,542 @@
+// vnd_amd.hip - C ABI (include/vnd_amd.h) over the gfx950 kernels.
+// Host-side only decides launch geometry; all arithmetic lives in vnd_kernels.hpp.
+#include "vnd_kernels.hpp"
+#include "../../include/vnd_amd.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace vnd;
+
+// ------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static vnd_status fail(vnd_status st, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail(VND_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                           \
+    } while (0)
+
+// ------------------------------------------------------------------------------
+// objects
+// ------------------------------------------------------------------------------
+struct vnd_ctx {
+    int device = 0;
+    hipDeviceProp_t prop{};
+    int lds_limit = 65536;        // bytes of LDS one workgroup may use
+    hipStream_t stream = nullptr; // used by the *_host entry points
+    float *scratch_x = nullptr, *scratch_y = nullptr;
+    size_t scratch_elems = 0;
+    int variant = -1;
+};
+
+struct vnd_taps {
+    vnd_ctx *ctx = nullptr;
+    int32_t C = 0, total = 0, total_segs = 0, max_index = 0, apply_gain = 0;
+    bool has_seg = false, has_flags = false;
+    std::vector<int32_t> tap_off, idx, seg_off, seg_end;
+    std::vector<float> w, seg_gain;
+    std::vector<uint8_t> flags;
+    // device image
+    Tap *d_taps = nullptr;
+    int32_t *d_tap_off = nullptr, *d_seg_off = nullptr, *d_seg_end = nullptr;
+    float *d_seg_gain = nullptr;
+    uint8_t *d_flags = nullptr;
+};
+
+// ------------------------------------------------------------------------------
+// launch geometry
+// ------------------------------------------------------------------------------
+struct Plan {
+    bool direct = false;
+    int cg = 1, r_log2 = 0, dual = 0;
+    int W = 0;
+    size_t lds_bytes = 0;
+    uint32_t nblocks = 0;
+    int tiles = 0, groups = 1;
+};
+
+typedef void (*kern_t)(const KArgs);
+
+template <int CG, int R, int MODE, bool DUAL>
+static kern_t kptr() { return conv_lds_kernel<CG, R, MODE, DUAL>; }
+
+template <int CG, int MODE, bool DUAL>
+static kern_t by_r(int r_log2)
+{
+    switch (r_log2) {
+    case 0: return kptr<CG, 1, MODE, DUAL>();
+    case 1: return kptr<CG, 2, MODE, DUAL>();
+    case 2: return kptr<CG, 4, MODE, DUAL>();
+    case 3: return kptr<CG, 8, MODE, DUAL>();
+    default: return kptr<CG, 16, MODE, DUAL>();
+    }
+}
+
+template <int CG>
+static kern_t by_mode(int r_log2, int mode, int dual)
+{
+    if (mode == VND_MODE_EXACT)
+        return dual ? by_r<CG, 0, true>(r_log2) : by_r<CG, 0, false>(r_log2);
+    return dual ? by_r<CG, 1, true>(r_log2) : by_r<CG, 1, false>(r_log2);
+}
+
+static kern_t lds_kernel(int cg, int r_log2, int mode, int dual)
+{
+    switch (cg) {
+    case 1: return by_mode<1>(r_log2, mode, dual);
+    case 2: return by_mode<2>(r_log2, mode, dual);
+    default: return by_mode<4>(r_log2, mode, dual);
+    }
+}
+
+static int halo_of(int max_index) { return (max_index + 2 + 15) & ~15; }
+
+static size_t lds_need(int cg, int r_log2, int dual, int max_index)
+{
+    const size_t T = (size_t)2 * kThreads << r_log2;
+    return (size_t)(dual ? 2 : 1) * cg * (T + halo_of(max_index)) * sizeof(float);
+}
+
+// variant word (vnd_set_variant): bits 0-3 r_log2+1 (0 = auto), bit 4 dual,
+// bit 5 "dual given", bits 8-11 channels per workgroup (0 = auto), bit 12 direct.
+static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64_t n, int C)
+{
+    Plan p;
+    const int v = ctx->variant;
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    const bool force_direct = v >= 0 && ((v >> 12) & 1);
+    int cg = (v >= 0 && ((v >> 8) & 15)) ? ((v >> 8) & 15) : 0;
+    if (cg == 0) cg = (C % 2 == 0) ? 2 : 1;
+    if (C % cg != 0 || (cg != 1 && cg != 2 && cg != 4)) cg = 1;
+    int dual = (v >= 0 && ((v >> 5) & 1)) ? ((v >> 4) & 1) : 0;
+    int r_log2 = (v >= 0 && (v & 15)) ? (v & 15) - 1 : -1;
+
+    const size_t limit = (size_t)ctx->lds_limit;
+    if (r_log2 < 0) {
+        // Largest tile that still gives every CU several workgroups, within an
+        // LDS budget that keeps >= 2 workgroups resident per CU.
+        const size_t budget = limit / 2;
+        r_log2 = 3;
+        while (r_log2 > 0) {
+            const int64_t T = (int64_t)2 * kThreads << r_log2;
+            const int64_t blocks = batch * ((n + T - 1) / T) * (C / cg);
+            if (blocks >= (int64_t)cus * 6 && lds_need(cg, r_log2, dual, t->max_index) <= budget) break;
+            --r_log2;
+        }
+    }
+    if (r_log2 > 4) r_log2 = 4;
+    // shrink until the tile fits one workgroup's LDS at all
+    while (lds_need(cg, r_log2, dual, t->max_index) > limit) {
+        if (dual) dual = 0;
+        else if (cg > 1) cg /= 2;
+        else if (r_log2 > 0) --r_log2;
+        else break;
+    }
+    if (force_direct || lds_need(cg, r_log2, dual, t->max_index) > limit) {
+        p.direct = true;
+        const int64_t total = batch * n * C;
+        int64_t blocks = (total + kThreads - 1) / kThreads;
+        p.nblocks = (uint32_t)std::min<int64_t>(std::max<int64_t>(blocks, 1), (int64_t)cus * 32);
+        return p;
+    }
+    const int64_t T = (int64_t)2 * kThreads << r_log2;
+    p.cg = cg; p.r_log2 = r_log2; p.dual = dual;
+    p.W = (int)T + halo_of(t->max_index);
+    p.lds_bytes = lds_need(cg, r_log2, dual, t->max_index);
+    p.tiles = (int)((n + T - 1) / T);
+    p.groups = C / cg;
+    p.nblocks = (uint32_t)(batch * p.tiles * p.groups);
+    return p;
+}
+
+static vnd_status check_shape(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64_t n,
+                              int32_t C, int32_t mode)
+{
+    if (!ctx || !t) return fail(VND_ERR_INVALID, "null context or tap table");
+    if (batch < 0 || n < 0) return fail(VND_ERR_INVALID, "negative batch or frame count");
+    if (C != t->C)
+        return fail(VND_ERR_INVALID, "signal has %d channels but the tap table has %d", C, t->C);
+    if (mode != VND_MODE_EXACT && mode != VND_MODE_FMA)
+        return fail(VND_ERR_INVALID, "unknown mode %d", mode);
+    if (n > (int64_t)1 << 40 || batch * n * C / std::max<int64_t>(n, 1) > (int64_t)1 << 40)
+        return fail(VND_ERR_UNSUPPORTED, "problem too large");
+    return VND_OK;
+}
+
+static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
+                         int64_t n, int32_t C, int32_t mode, hipStream_t stream)
+{
+    if (batch == 0 || n == 0) return VND_OK;
+    const Plan p = make_plan(ctx, t, batch, n, C);
+    KArgs a{};
+    a.x = x; a.y = y; a.taps = t->d_taps; a.tap_off = t->d_tap_off;
+    a.seg_off = t->has_seg ? t->d_seg_off : nullptr;
+    a.seg_end = t->d_seg_end; a.seg_gain = t->d_seg_gain;
+    a.chan_flags = t->has_flags ? t->d_flags : nullptr;
+    a.n = n; a.C = C; a.apply_gain = t->apply_gain;
+    a.nblocks = p.nblocks;
+    if (p.direct) {
+        a.tiles = (int32_t)batch; a.groups = 1; a.W = 0;
+        kern_t k = mode == VND_MODE_EXACT ? conv_direct_kernel<0> : conv_direct_kernel<1>;
+        hipLaunchKernelGGL(k, dim3(p.nblocks), dim3(kThreads), 0, stream, a);
+    } else {
+        if ((int64_t)batch * p.tiles * p.groups > 0x7fffffffLL)
+            return fail(VND_ERR_UNSUPPORTED, "grid too large; split the batch");
+        a.tiles = p.tiles; a.groups = p.groups; a.W = p.W;
+        kern_t k = lds_kernel(p.cg, p.r_log2, mode, p.dual);
+        if (p.lds_bytes > 65536)
+            HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)p.lds_bytes));
+        hipLaunchKernelGGL(k, dim3(p.nblocks), dim3(kThreads), p.lds_bytes, stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return VND_OK;
+}
+
+static void free_taps_dev(vnd_taps *t)
+{
+    if (t->d_taps) (void)hipFree(t->d_taps);
+    if (t->d_tap_off) (void)hipFree(t->d_tap_off);
+    if (t->d_seg_off) (void)hipFree(t->d_seg_off);
+    if (t->d_seg_end) (void)hipFree(t->d_seg_end);
+    if (t->d_seg_gain) (void)hipFree(t->d_seg_gain);
+    if (t->d_flags) (void)hipFree(t->d_flags);
+}
+
+template <typename T>
+static hipError_t upload(T **dst, const T *src, size_t count)
+{
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc((void **)dst, bytes);
+    if (e != hipSuccess) return e;
+    if (count) e = hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
+// ------------------------------------------------------------------------------
+// ABI
+// ------------------------------------------------------------------------------
+extern "C" {
+
+int vnd_abi_version(void) { return VND_ABI_VERSION; }
+
+const char *vnd_last_error(void) { return g_err.c_str(); }
+
+vnd_status vnd_device_count(int32_t *count)
+{
+    if (!count) return fail(VND_ERR_INVALID, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(VND_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return VND_OK;
+}
+
+vnd_status vnd_ctx_create(int32_t device, vnd_ctx **out)
+{
+    if (!out) return fail(VND_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(VND_ERR_NO_DEVICE, "no HIP device visible: the velvet-noise kernels need an MI355X (gfx950)");
+    if (device < 0 || device >= n) return fail(VND_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    vnd_ctx *c = new (std::nothrow) vnd_ctx;
+    if (!c) return fail(VND_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&c->prop, device) != hipSuccess) {
+        delete c;
+        return fail(VND_ERR_HIP, "cannot open device %d", device);
+    }
+    if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string arch = c->prop.gcnArchName;
+        delete c;
+        return fail(VND_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, arch.c_str());
+    }
+    int optin = 0;
+    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device) == hipSuccess && optin > 0)
+        c->lds_limit = optin;
+    else
+        c->lds_limit = (int)c->prop.sharedMemPerBlock;
+    if (c->lds_limit < 65536) c->lds_limit = 65536;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(VND_ERR_HIP, "hipStreamCreate failed");
+    }
+    *out = c;
+    return VND_OK;
+}
+
+vnd_status vnd_ctx_destroy(vnd_ctx *c)
+{
+    if (!c) return VND_OK;
+    (void)hipSetDevice(c->device);
+    if (c->scratch_x) (void)hipFree(c->scratch_x);
+    if (c->scratch_y) (void)hipFree(c->scratch_y);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return VND_OK;
+}
+
+vnd_status vnd_ctx_info(const vnd_ctx *c, char *name, int32_t len, int32_t *cus, int64_t *hbm, int32_t *lds)
+{
+    if (!c) return fail(VND_ERR_INVALID, "null context");
+    if (name && len > 0) snprintf(name, (size_t)len, "%s (%s)", c->prop.name, c->prop.gcnArchName);
+    if (cus) *cus = c->prop.multiProcessorCount;
+    if (hbm) *hbm = (int64_t)c->prop.totalGlobalMem;
+    if (lds) *lds = c->lds_limit;
+    return VND_OK;
+}
+
+vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, const int32_t *tap_index,
+                           const float *tap_weight, const int32_t *seg_offsets, const int32_t *seg_end,
+                           const float *seg_gain, const uint8_t *chan_flags, int32_t apply_gain,
+                           vnd_taps **out)
+{
+    if (!out) return fail(VND_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    if (!ctx) return fail(VND_ERR_INVALID, "null context");
+    if (C <= 0 || C > 65535) return fail(VND_ERR_INVALID, "num_channels %d out of range", C);
+    if (!tap_offsets) return fail(VND_ERR_INVALID, "null tap_offsets");
+    if (tap_offsets[0] != 0) return fail(VND_ERR_INVALID, "tap_offsets[0] must be 0");
+    for (int c = 0; c < C; ++c)
+        if (tap_offsets[c + 1] < tap_offsets[c]) return fail(VND_ERR_INVALID, "tap_offsets not monotone");
+    const int32_t total = tap_offsets[C];
+    if (total > 0 && (!tap_index || !tap_weight)) return fail(VND_ERR_INVALID, "null tap arrays");
+    int32_t max_index = 0;
+    for (int32_t k = 0; k < total; ++k) {
+        if (tap_index[k] < 0) return fail(VND_ERR_INVALID, "negative tap index at %d", k);
+        max_index = std::max(max_index, tap_index[k]);
+    }
+    const bool has_seg = seg_offsets != nullptr;
+    int32_t total_segs = 0;
+    if (has_seg) {
+        if (!seg_end || !seg_gain) return fail(VND_ERR_INVALID, "segment table incomplete");
+        if (seg_offsets[0] != 0) return fail(VND_ERR_INVALID, "seg_offsets[0] must be 0");
+        for (int c = 0; c < C; ++c) {
+            if (seg_offsets[c + 1] < seg_offsets[c]) return fail(VND_ERR_INVALID, "seg_offsets not monotone");
+            int32_t prev = tap_offsets[c];
+            for (int32_t s = seg_offsets[c]; s < seg_offsets[c + 1]; ++s) {
+                if (seg_end[s] < prev || seg_end[s] > tap_offsets[c + 1])
+                    return fail(VND_ERR_INVALID, "segment %d of channel %d out of order", s, c);
+                prev = seg_end[s];
+            }
+            // taps after the last segment end would be dropped silently: refuse
+            if (prev != tap_offsets[c + 1] && tap_offsets[c + 1] != tap_offsets[c])
+                return fail(VND_ERR_INVALID, "segments of channel %d do not cover its taps", c);
+        }
+        total_segs = seg_offsets[C];
+    }
+    vnd_taps *t = new (std::nothrow) vnd_taps;
+    if (!t) return fail(VND_ERR_NOMEM, "out of host memory");
+    t->ctx = ctx; t->C = C; t->total = total; t->max_index = max_index;
+    t->apply_gain = apply_gain ? 1 : 0; t->has_seg = has_seg; t->total_segs = total_segs;
+    t->tap_off.assign(tap_offsets, tap_offsets + C + 1);
+    if (total) { t->idx.assign(tap_index, tap_index + total); t->w.assign(tap_weight, tap_weight + total); }
+    if (has_seg) {
+        t->seg_off.assign(seg_offsets, seg_offsets + C + 1);
+        t->seg_end.assign(seg_end, seg_end + total_segs);
+        t->seg_gain.assign(seg_gain, seg_gain + total_segs);
+    }
+    if (chan_flags) { t->flags.assign(chan_flags, chan_flags + C); t->has_flags = true; }
+
+    std::vector<Tap> packed((size_t)total);
+    for (int32_t k = 0; k < total; ++k) { packed[k].idx = tap_index[k]; packed[k].w = tap_weight[k]; }
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = upload(&t->d_taps, packed.data(), (size_t)total);
+    if (e == hipSuccess) e = upload(&t->d_tap_off, t->tap_off.data(), t->tap_off.size());
+    if (e == hipSuccess && has_seg) e = upload(&t->d_seg_off, t->seg_off.data(), t->seg_off.size());
+    if (e == hipSuccess && has_seg) e = upload(&t->d_seg_end, t->seg_end.data(), t->seg_end.size());
+    if (e == hipSuccess && has_seg) e = upload(&t->d_seg_gain, t->seg_gain.data(), t->seg_gain.size());
+    if (e == hipSuccess && t->has_flags) e = upload(&t->d_flags, t->flags.data(), t->flags.size());
+    if (e != hipSuccess) {
+        free_taps_dev(t);
+        delete t;
+        return fail(VND_ERR_HIP, "uploading tap table: %s", hipGetErrorString(e));
+    }
+    *out = t;
+    return VND_OK;
+}
+
+vnd_status vnd_taps_destroy(vnd_taps *t)
+{
+    if (!t) return VND_OK;
+    (void)hipSetDevice(t->ctx->device);
+    free_taps_dev(t);
+    delete t;
+    return VND_OK;
+}
+
+vnd_status vnd_taps_info(const vnd_taps *t, int32_t *C, int32_t *total, int32_t *max_index)
+{
+    if (!t) return fail(VND_ERR_INVALID, "null tap table");
+    if (C) *C = t->C;
+    if (total) *total = t->total;
+    if (max_index) *max_index = t->max_index;
+    return VND_OK;
+}
+
+// image: int32 header[8] = {magic, version, C, total, total_segs, has_seg, has_flags, apply_gain}
+// then tap_off[C+1], idx[total], w[total], (seg_off[C+1], seg_end[S], seg_gain[S]), (flags[C] padded to 4)
+static const int32_t kMagic = 0x564e4454;  // "VNDT"
+
+vnd_status vnd_taps_serialize(const vnd_taps *t, void *buf, int64_t capacity, int64_t *bytes)
+{
+    if (!t || !bytes) return fail(VND_ERR_INVALID, "null argument");
+    const int64_t flag_words = t->has_flags ? (t->C + 3) / 4 : 0;
+    const int64_t words = 8 + (t->C + 1) + 2 * (int64_t)t->total +
+                          (t->has_seg ? (t->C + 1) + 2 * (int64_t)t->total_segs : 0) + flag_words;
+    *bytes = words * 4;
+    if (!buf) return VND_OK;                     // size query
+    if (capacity < *bytes) return fail(VND_ERR_INVALID, "buffer too small: need %lld bytes", (long long)*bytes);
+    int32_t *p = (int32_t *)buf;
+    const int32_t hdr[8] = {kMagic, VND_ABI_VERSION, t->C, t->total, t->total_segs,
+                            t->has_seg, t->has_flags, t->apply_gain};
+    memcpy(p, hdr, sizeof hdr); p += 8;
+    memcpy(p, t->tap_off.data(), (t->C + 1) * 4); p += t->C + 1;
+    if (t->total) { memcpy(p, t->idx.data(), t->total * 4); p += t->total;
+                    memcpy(p, t->w.data(), t->total * 4); p += t->total; }
+    if (t->has_seg) {
+        memcpy(p, t->seg_off.data(), (t->C + 1) * 4); p += t->C + 1;
+        if (t->total_segs) { memcpy(p, t->seg_end.data(), t->total_segs * 4); p += t->total_segs;
+                             memcpy(p, t->seg_gain.data(), t->total_segs * 4); p += t->total_segs; }
+    }
+    if (t->has_flags) { memset(p, 0, flag_words * 4); memcpy(p, t->flags.data(), t->C); }
+    return VND_OK;
+}
+
+vnd_status vnd_taps_deserialize(vnd_ctx *ctx, const void *buf, int64_t bytes, vnd_taps **out)
+{
+    if (!out) return fail(VND_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    if (!buf || bytes < 32) return fail(VND_ERR_INVALID, "tap image too short");
+    const int32_t *p = (const int32_t *)buf;
+    if (p[0] != kMagic || p[1] != VND_ABI_VERSION) return fail(VND_ERR_INVALID, "not a tap image of this ABI version");
+    const int32_t C = p[2], total = p[3], segs = p[4], has_seg = p[5], has_flags = p[6], gain = p[7];
+    if (C <= 0 || total < 0 || segs < 0) return fail(VND_ERR_INVALID, "corrupt tap image header");
+    const int64_t flag_words = has_flags ? (C + 3) / 4 : 0;
+    const int64_t words = 8 + (C + 1) + 2 * (int64_t)total + (has_seg ? (C + 1) + 2 * (int64_t)segs : 0) + flag_words;
+    if (bytes < words * 4) return fail(VND_ERR_INVALID, "tap image truncated");
+    const int32_t *tap_off = p + 8;
+    const int32_t *idx = tap_off + C + 1;
+    const float *w = (const float *)(idx + total);
+    const int32_t *q = (const int32_t *)(w + total);
+    const int32_t *seg_off = nullptr, *seg_end = nullptr;
+    const float *seg_gain = nullptr;
+    if (has_seg) { seg_off = q; seg_end = seg_off + C + 1; seg_gain = (const float *)(seg_end + segs); q = (const int32_t *)(seg_gain + segs); }
+    const uint8_t *flags = has_flags ? (const uint8_t *)q : nullptr;
+    if (tap_off[C] != total || (has_seg && seg_off[C] != segs)) return fail(VND_ERR_INVALID, "corrupt tap image");
+    return vnd_taps_create(ctx, C, tap_off, idx, w, seg_off, seg_end, seg_gain, flags, gain, out);
+}
+
+vnd_status vnd_convolve_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
+                                int64_t n, int32_t C, int32_t mode, void *stream)
+{
+    vnd_status st = check_shape(ctx, t, batch, n, C, mode);
+    if (st != VND_OK) return st;
+    if (batch == 0 || n == 0) return VND_OK;
+    if (!x || !y) return fail(VND_ERR_INVALID, "null signal pointer");
+    const int64_t elems = batch * n * C;
+    if ((x < y + elems) && (y < x + elems)) return fail(VND_ERR_INVALID, "x and y overlap");
+    return launch(ctx, t, x, y, batch, n, C, mode, (hipStream_t)stream);
+}
+
+vnd_status vnd_convolve_f32_host(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
+                                 int64_t n, int32_t C, int32_t mode)
+{
+    vnd_status st = check_shape(ctx, t, batch, n, C, mode);
+    if (st != VND_OK) return st;
+    if (batch == 0 || n == 0) return VND_OK;
+    if (!x || !y) return fail(VND_ERR_INVALID, "null signal pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t elems = (size_t)batch * n * C;
+    if (elems > ctx->scratch_elems) {
+        if (ctx->scratch_x) (void)hipFree(ctx->scratch_x);
+        if (ctx->scratch_y) (void)hipFree(ctx->scratch_y);
+        ctx->scratch_x = ctx->scratch_y = nullptr;
+        ctx->scratch_elems = 0;
+        HIP_TRY(hipMalloc((void **)&ctx->scratch_x, elems * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&ctx->scratch_y, elems * sizeof(float)));
+        ctx->scratch_elems = elems;
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->scratch_x, x, elems * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    st = launch(ctx, t, ctx->scratch_x, ctx->scratch_y, batch, n, C, mode, ctx->stream);
+    if (st != VND_OK) return st;
+    HIP_TRY(hipMemcpyAsync(y, ctx->scratch_y, elems * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VND_OK;
+}
+
+vnd_status vnd_time_convolve_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
+                                     int64_t n, int32_t C, int32_t mode, int32_t n_buffers, int64_t stride,
+                                     int32_t iters, void *stream_, float *avg_ms)
+{
+    vnd_status st = check_shape(ctx, t, batch, n, C, mode);
+    if (st != VND_OK) return st;
+    if (!avg_ms || iters <= 0 || n_buffers <= 0) return fail(VND_ERR_INVALID, "bad timing arguments");
+    hipStream_t stream = (hipStream_t)stream_;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, stream));
+    for (int i = 0; i < iters; ++i) {
+        const int64_t off = (int64_t)(i % n_buffers) * stride;
+        st = launch(ctx, t, x + off, y + off, batch, n, C, mode, stream);
+        if (st != VND_OK) break;
+    }
+    HIP_TRY(hipEventRecord(e1, stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (st != VND_OK) return st;
+    *avg_ms = ms / iters;
+    return VND_OK;
+}
+
+vnd_status vnd_set_variant(vnd_ctx *ctx, int32_t variant)
+{
+    if (!ctx) return fail(VND_ERR_INVALID, "null context");
+    ctx->variant = variant;
+    return VND_OK;
+}
+
+vnd_status vnd_describe_launch(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64_t n, int32_t C,
+                               int32_t mode, char *text, int32_t len)
+{
+    vnd_status st = check_shape(ctx, t, batch, n, C, mode);
+    if (st != VND_OK) return st;
+    if (!text || len <= 0) return fail(VND_ERR_INVALID, "null text buffer");
+    const Plan p = make_plan(ctx, t, batch, n, C);
+    if (p.direct)
+        snprintf(text, (size_t)len, "conv_direct mode=%d blocks=%u threads=%d", mode, p.nblocks, kThreads);
+    else
+        snprintf(text, (size_t)len,
+                 "conv_lds cg=%d pairs_per_lane=%d tile=%d halo=%d dual=%d mode=%d lds=%zuB blocks=%u threads=%d",
+                 p.cg, 1 << p.r_log2, (2 * kThreads) << p.r_log2, p.W - ((2 * kThreads) << p.r_log2), p.dual,
+                 mode, p.lds_bytes, p.nblocks, kThreads);
+    return VND_OK;
+}
+
+}  // extern "C"

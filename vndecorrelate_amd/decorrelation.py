@@ -1,0 +1,618 @@
+"""Drop-in host layer for the velvet-noise path of ckonst/VNDecorrelate.
+
+Same public names, keyword arguments, defaults and exceptions as the
+reference's ``vndecorrelate.decorrelation`` (v1.1.0; ``file:line`` citations
+are relative to its checkout), but every tap sum runs on an MI355X through the
+C ABI in ``include/vnd_amd.h``:
+
+===========================  ==================================================
+reference                    here
+===========================  ==================================================
+``convolve_velvet_noise``    :func:`convolve_velvet_noise`  -> ``vnd_convolve_f32_host``
+``generate_velvet_noise``    :func:`generate_velvet_noise`  (host NumPy, O(K))
+``VelvetNoise``              :class:`VelvetNoise` (``convolve`` on the GPU)
+``SignalChain``              :class:`SignalChain`
+``HaasEffect``/``WhiteNoise`` NumPy-only chain stages (out of the GPU scope,
+                             SURVEY.md §2 rows 6-7; kept so chains stay drop-in)
+===========================  ==================================================
+
+There is no CPU implementation of the tap sum in this package: without the
+built extension or without a gfx950 device the calls raise ``RuntimeError``.
+
+Deliberate, documented deviations from the reference (DESIGN.md "Parity"):
+non-float32 inputs and float64 FIR weights are rounded to float32 before the
+GPU call (the reference promotes to float64 per tap, then rounds to float32).
+"""
+from __future__ import annotations
+
+import hashlib
+from abc import ABC, abstractmethod
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from functools import partial
+from typing import Any, Callable, Iterator, List, Optional, Protocol, Sequence
+
+import numpy as np
+from numpy.typing import NDArray
+
+from . import _native
+from .taps import TapArrays, class_path_arrays, function_path_arrays
+from .utils.dsp import (
+    IDENTITY_ENVELOPE,
+    LayoutMode,
+    LR_to_MS,
+    MS_to_LR,
+    apply_log_distribution,
+    apply_stereo_width,
+    check_equal_length,
+    encode_signal_to_side_channel,
+    generate_log_distribution,
+    mono_to_stereo,
+    rms_normalize,
+    to_float32,
+)
+
+DEFAULT_SEGMENT_ENVELOPE = (0.85, 0.55, 0.35, 0.2)
+
+# Arithmetic used by the host API.  EXACT reproduces the reference bit for bit
+# for float32 inputs; FMA is the single-rounding variant (<= 1e-6 of peak).
+MODE_EXACT = _native.MODE_EXACT
+MODE_FMA = _native.MODE_FMA
+_default_mode = MODE_EXACT
+
+
+def set_default_mode(mode: int) -> None:
+    """Choose the arithmetic of subsequent host-API calls (MODE_EXACT / MODE_FMA)."""
+    global _default_mode
+    if mode not in (MODE_EXACT, MODE_FMA):
+        raise ValueError(f'unknown mode {mode}')
+    _default_mode = mode
+
+
+# ----------------------------------------------------------------------------
+# Protocols / abstract bases   (decorrelation.py:31-59)
+# ----------------------------------------------------------------------------
+class SignalProcessor(Protocol):
+    sample_rate_hz: int
+    num_outs: int
+
+    def __call__(self, input_signal: NDArray) -> NDArray: ...
+
+
+class StatelessDecorrelator(Protocol):
+    def __call__(self, input_signal: NDArray, **kwargs) -> NDArray: ...
+
+
+@dataclass(kw_only=True)
+class Decorrelator(ABC):
+    """Base of the stateful stages: ``stage(x)`` is ``stage.decorrelate(x)``."""
+
+    sample_rate_hz: int
+    num_outs: int = 2
+    width: Optional[float] = None
+
+    @abstractmethod
+    def decorrelate(self, input_signal: NDArray) -> NDArray:
+        raise NotImplementedError
+
+    def __call__(self, input_signal: NDArray) -> NDArray:
+        return self.decorrelate(input_signal)
+
+
+# ----------------------------------------------------------------------------
+# tap placement shared by both generators   (decorrelation.py:488-523, :573-611)
+# ----------------------------------------------------------------------------
+def _draw_taps(seed, num_impulses: int, num_filters: int, fir_length: int, sample_rate_hz,
+               duration_seconds: float, strength: float):
+    """Positions ``int32 (K+1, F)`` and signs ``(K, F)`` in {-1, +1}.
+
+    The order of the two uniform draws (signs, then offsets) and their shapes
+    are part of the contract: they fix which PCG64 values land where.
+    """
+    rng = np.random.default_rng(seed)
+    weights = generate_log_distribution(strength, num_impulses)
+    marks = np.cumsum(weights)
+    if strength == 0.0:
+        marks -= 1.0                      # uniform case starts at sample 0
+    marks *= fir_length / marks[-1]
+    sign_draw = rng.uniform(low=0, high=1, size=(num_impulses, num_filters))
+    offset_draw = rng.uniform(low=0, high=1, size=(num_impulses + 1, num_filters))
+    signs = (2 * np.round(sign_draw)) - 1
+    mean_gap = sample_rate_hz / (num_impulses / duration_seconds)
+    positions = np.stack([apply_log_distribution(offset_draw[:, f], weights, marks, mean_gap)
+                          for f in range(num_filters)], axis=1)
+    return positions, signs
+
+
+def _segment_index(k: int, num_impulses: int, num_segments: int) -> int:
+    return int(k / (num_impulses / num_segments))
+
+
+def generate_velvet_noise(*, duration_seconds: float, num_impulses: int, num_outs: int = 2,
+                          sample_rate_hz: int = 44100,
+                          segment_envelope: Sequence[float] = DEFAULT_SEGMENT_ENVELOPE,
+                          log_distribution_strength: float = 1.0,
+                          seed: Optional[int] = None) -> NDArray:
+    """Dense seeded velvet-noise FIR, float32 ``(int(duration*fs), num_outs)``.
+
+    Mirrors ``generate_velvet_noise`` (decorrelation.py:549-627): the length
+    truncates, a later impulse on an occupied sample overwrites the earlier one.
+    Feed the result to :func:`convolve_velvet_noise`.
+    """
+    fir_length = int(duration_seconds * sample_rate_hz)
+    envelope = tuple(segment_envelope) if len(segment_envelope) else IDENTITY_ENVELOPE
+    fir = np.zeros((fir_length, num_outs), dtype=np.float32)
+    positions, signs = _draw_taps(seed, num_impulses, num_outs, fir_length, sample_rate_hz,
+                                  duration_seconds, log_distribution_strength)
+    for c in range(num_outs):
+        for k in range(num_impulses):
+            fir[positions[k, c], c] = signs[k, c] * envelope[_segment_index(k, num_impulses, len(envelope))]
+    return fir
+
+
+# ----------------------------------------------------------------------------
+# device tap-table cache for the stateless path
+# ----------------------------------------------------------------------------
+class _TableCache:
+    """Small LRU of device tables keyed by FIR content, so calling the stateless
+    function repeatedly with one FIR uploads its 8*K*C bytes once."""
+
+    def __init__(self, capacity: int = 16):
+        self.capacity = capacity
+        self._items: 'OrderedDict[tuple, _native.TapTable]' = OrderedDict()
+
+    def get(self, key, build: Callable[[], TapArrays]) -> _native.TapTable:
+        table = self._items.get(key)
+        if table is not None:
+            self._items.move_to_end(key)
+            return table
+        arrays = build()
+        table = _native.TapTable.create(_native.default_context(), arrays.tap_offsets,
+                                        arrays.tap_index, arrays.tap_weight, **arrays.kwargs())
+        self._items[key] = table
+        while len(self._items) > self.capacity:
+            self._items.popitem(last=False)[1].close()
+        return table
+
+    def clear(self):
+        for t in self._items.values():
+            t.close()
+        self._items.clear()
+
+
+_fir_tables = _TableCache()
+
+
+def _fir_key(fir: np.ndarray, channels: int):
+    view = np.ascontiguousarray(fir[:, :channels])
+    return (view.shape, str(view.dtype), hashlib.blake2b(view.tobytes(), digest_size=16).digest(),
+            _native.default_context().device)
+
+
+def convolve_velvet_noise(input_signal: NDArray, velvet_noise_filters: NDArray, *,
+                          mode: Optional[int] = None) -> NDArray:
+    """Stateless sparse convolution ``y[n,c] = sum_k w[c,k] * x[n + i[c,k], c]``.
+
+    Drop-in for ``convolve_velvet_noise`` (decorrelation.py:630-660): same
+    shapes in and out (float32 ``(n, C)`` result), ``ValueError`` when a
+    multi-channel signal and the filters disagree on channel count, and the
+    reference's ``IndexError`` for a 1-D signal.  ``mode`` picks the arithmetic
+    (default: the bit-exact one).  Runs on the GPU; raises ``RuntimeError``
+    without one.
+    """
+    fir = np.asarray(velvet_noise_filters)
+    if fir.ndim == 1:
+        fir = fir[:, None]
+    if input_signal.ndim == 1:
+        # The reference indexes the 1-D signal with two subscripts at its first tap.
+        if np.any(fir[:, 0] != 0.0):
+            raise IndexError('too many indices for array: array is 1-dimensional, but 2 were indexed')
+        return np.zeros(input_signal.shape, dtype=np.float32)
+    num_channels = input_signal.shape[1]
+    if num_channels > 1:
+        check_equal_length(input_signal, fir, dim=1)
+    x = np.ascontiguousarray(input_signal, dtype=np.float32)
+    if x.shape[0] == 0 or num_channels == 0:
+        return np.zeros(x.shape, dtype=np.float32)
+    table = _fir_tables.get(_fir_key(fir, num_channels),
+                            lambda: function_path_arrays(fir, num_channels))
+    return table.convolve_host(x, _default_mode if mode is None else mode)
+
+
+def convolve_velvet_noise_batched(input_signals: NDArray, velvet_noise_filters: NDArray, *,
+                                  mode: Optional[int] = None) -> NDArray:
+    """Many independent streams with one shared filter bank: ``(B, n, C)`` in and
+    out, one kernel launch.  Equals stacking :func:`convolve_velvet_noise` over B."""
+    if input_signals.ndim != 3:
+        raise ValueError(f'expected (batch, n, C), got shape {input_signals.shape}')
+    fir = np.asarray(velvet_noise_filters)
+    if fir.ndim == 1:
+        fir = fir[:, None]
+    num_channels = input_signals.shape[2]
+    if num_channels > 1 and fir.shape[1] != num_channels:
+        raise ValueError('Input length mismatch: Expected signals of equal length, but got lengths '
+                         f'{num_channels} and {fir.shape[1]} for dimension 1.')
+    x = np.ascontiguousarray(input_signals, dtype=np.float32)
+    if x.size == 0:
+        return np.zeros(x.shape, dtype=np.float32)
+    table = _fir_tables.get(_fir_key(fir, num_channels),
+                            lambda: function_path_arrays(fir, num_channels))
+    return table.convolve_host(x, _default_mode if mode is None else mode)
+
+
+# ----------------------------------------------------------------------------
+# Velvet-noise impulse containers   (decorrelation.py:240-323)
+# ----------------------------------------------------------------------------
+@dataclass
+class VelvetNoiseSegment:
+    """Impulse positions of one envelope segment, split by sign."""
+
+    negative_impulse_indexes: List[int] = field(default_factory=list)
+    positive_impulse_indexes: List[int] = field(default_factory=list)
+
+    def __iter__(self) -> Iterator:
+        yield self.negative_impulse_indexes, '__isub__'
+        yield self.positive_impulse_indexes, '__iadd__'
+
+    def __getitem__(self, key: int) -> List[int]:
+        if key == 0:
+            return self.negative_impulse_indexes
+        if key == 1:
+            return self.positive_impulse_indexes
+        raise ValueError('Invalid key')
+
+    def __setitem__(self, key: int, value) -> None:
+        if key == 0:
+            self.negative_impulse_indexes = value
+        elif key == 1:
+            self.positive_impulse_indexes = value
+        else:
+            raise ValueError('Invalid key')
+
+
+@dataclass
+class VelvetNoiseSequence:
+    """The segments of one output channel."""
+
+    segments: List[VelvetNoiseSegment] = field(default_factory=list)
+
+    @classmethod
+    def create(cls, *, num_segments: int) -> 'VelvetNoiseSequence':
+        return cls(segments=[VelvetNoiseSegment() for _ in range(num_segments)])
+
+    def __iter__(self):
+        return iter(self.segments)
+
+    def __len__(self):
+        return len(self.segments)
+
+    def __getitem__(self, key: int) -> VelvetNoiseSegment:
+        return self.segments[key]
+
+    def __setitem__(self, key: int, value) -> None:
+        self.segments[key] = value
+
+
+@dataclass
+class ParallelVelvetNoise:
+    """One sequence per output channel; an unfiltered channel is an empty list."""
+
+    fir_length_samples: int
+    output_channels: list = field(default_factory=list)
+
+    @property
+    def num_outs(self) -> int:
+        return len(self.output_channels)
+
+    @property
+    def num_impluses(self) -> int:      # (sic) - the reference's spelling, counted on channel 0
+        return sum(len(seg.negative_impulse_indexes) + len(seg.positive_impulse_indexes)
+                   for channel in self.output_channels[0:1] for seg in channel)
+
+    num_impulses = num_impluses
+
+    def __iter__(self):
+        return iter(self.output_channels)
+
+    def __getitem__(self, key: int):
+        return self.output_channels[key]
+
+    def __setitem__(self, key: int, value) -> None:
+        self.output_channels[key] = value
+
+
+_VelvetNoiseSegment = VelvetNoiseSegment
+_VelvetNoiseSequence = VelvetNoiseSequence
+_ParallelVelvetNoise = ParallelVelvetNoise
+
+
+# ----------------------------------------------------------------------------
+# VelvetNoise   (decorrelation.py:326-546)
+# ----------------------------------------------------------------------------
+@dataclass(kw_only=True)
+class VelvetNoise(Decorrelator):
+    """Velvet-noise decorrelator with the reference's fields and defaults.
+
+    The impulse table is drawn once at construction and again only when
+    ``num_outs``, ``num_impulses`` or ``fir_length_samples`` change
+    (decorrelation.py:368-379); ``segment_envelope`` is read at convolve time.
+    ``convolve`` uploads the table to the GPU once and reuses it.
+    """
+
+    duration_seconds: float = 0.03
+    num_impulses: int = 30
+    segment_envelope: Sequence[float] = DEFAULT_SEGMENT_ENVELOPE
+    log_distribution_strength: float = 1.0
+    normalizer: Optional[Callable[[NDArray, NDArray], None]] = rms_normalize
+    filtered_channels: Sequence[int] = (0, 1)
+    mode: LayoutMode = LayoutMode.MS
+    seed: Optional[int] = None
+
+    _velvet_noise: Any = field(default=None, repr=False, compare=False)
+    _device: Any = field(default=None, repr=False, compare=False)   # (key, TapTable)
+
+    def __post_init__(self) -> None:
+        if self.num_impulses >= self.fir_length_samples * 0.2:
+            raise ValueError(
+                f'Velvet Noise Filter of length {self.fir_length_samples} with {self.num_impulses} '
+                f'impulses is not sparse. (density={self.density:.2f})\n'
+                '\tnum_impulses must be less than 20% the FIR length in samples.')
+        if not self.segment_envelope:
+            self.segment_envelope = IDENTITY_ENVELOPE
+        self._velvet_noise = self._generate()
+
+    # ---- derived quantities --------------------------------------------------
+    @property
+    def density(self) -> float:
+        """Impulses per second."""
+        return self.num_impulses / self.duration_seconds
+
+    @property
+    def fir_length_samples(self) -> int:
+        return int(round(self.sample_rate_hz * self.duration_seconds))
+
+    @property
+    def unfiltered_channels(self):
+        return filter(lambda c: c not in self.filtered_channels, range(self.num_outs))
+
+    @property
+    def velvet_noise(self) -> ParallelVelvetNoise:
+        vn = self._velvet_noise
+        if (self.num_outs != vn.num_outs or self.num_impulses != vn.num_impluses
+                or self.fir_length_samples != vn.fir_length_samples):
+            self._velvet_noise = self._generate()
+        return self._velvet_noise
+
+    @property
+    def FIR(self) -> NDArray:
+        """Dense float64 ``(fir_length_samples, len(filtered_channels))`` view of
+        the impulse table; a later impulse on an occupied sample wins."""
+        filtered = [seq for seq in self.velvet_noise if len(seq)]
+        fir = np.zeros((self.fir_length_samples, len(self.filtered_channels)))
+        for f, sequence in enumerate(filtered):
+            for s, segment in enumerate(sequence):
+                for i in segment.negative_impulse_indexes:
+                    fir[i, f] = self.segment_envelope[s] * -1
+                for i in segment.positive_impulse_indexes:
+                    fir[i, f] = self.segment_envelope[s] * 1
+        return fir
+
+    # ---- generation ----------------------------------------------------------
+    def _generate(self) -> ParallelVelvetNoise:
+        num_segments = len(self.segment_envelope)
+        table = ParallelVelvetNoise(fir_length_samples=self.fir_length_samples)
+        positions, signs = _draw_taps(self.seed, self.num_impulses, len(self.filtered_channels),
+                                      self.fir_length_samples, self.sample_rate_hz,
+                                      self.duration_seconds, self.log_distribution_strength)
+        for channel in range(self.num_outs):
+            if channel not in self.filtered_channels:
+                table.output_channels.append([])
+                continue
+            # random columns are addressed by OUTPUT channel number, as upstream (:531)
+            column, column_signs = positions[:, channel], signs[:, channel]
+            sequence = VelvetNoiseSequence.create(num_segments=num_segments)
+            for k in range(self.num_impulses):
+                segment = sequence[_segment_index(k, self.num_impulses, num_segments)]
+                segment[int((column_signs[k] + 1) / 2)].append(column[k])
+            table.output_channels.append(sequence)
+        return table
+
+    # ---- the hot path --------------------------------------------------------
+    def _tap_arrays(self) -> TapArrays:
+        apply_gain = self.segment_envelope != IDENTITY_ENVELOPE
+        channels = []
+        for sequence in self.velvet_noise:
+            if not len(sequence):
+                channels.append(None)
+            else:
+                channels.append([(seg.negative_impulse_indexes, seg.positive_impulse_indexes)
+                                 for seg in sequence])
+        return class_path_arrays(channels, self.segment_envelope, apply_gain)
+
+    def _device_table(self) -> _native.TapTable:
+        vn = self.velvet_noise
+        env = self.segment_envelope
+        key = (id(vn), tuple(env) if not isinstance(env, tuple) else env, type(env).__name__,
+               _native.default_context().device)
+        if self._device is None or self._device[0] != key:
+            arrays = self._tap_arrays()
+            if self._device is not None:
+                self._device[1].close()
+            self._device = (key, _native.TapTable.create(
+                _native.default_context(), arrays.tap_offsets, arrays.tap_index,
+                arrays.tap_weight, **arrays.kwargs()))
+        return self._device[1]
+
+    def convolve(self, input_signal: NDArray) -> NDArray:
+        """Velvet-noise filter every ``filtered_channel`` of a ``(n, >= num_outs)``
+        signal on the GPU; other output channels are copied through.  float32
+        ``(n, num_outs)``, bit-identical to ``VelvetNoise.convolve``
+        (decorrelation.py:393-415) for float32 input."""
+        if input_signal.ndim != 2:
+            raise IndexError('too many indices for array: convolve expects a (n, channels) signal')
+        x = np.ascontiguousarray(input_signal[:, :self.num_outs], dtype=np.float32)
+        if x.shape[1] != self.num_outs:
+            raise IndexError(f'index {self.num_outs - 1} is out of bounds for axis 1 '
+                             f'with size {input_signal.shape[1]}')
+        table = self._device_table()
+        if x.shape[0] == 0:
+            return np.zeros((0, self.num_outs), dtype=np.float32)
+        return table.convolve_host(x, _default_mode)
+
+    def decorrelate(self, input_signal: NDArray) -> NDArray:
+        """Full stage (decorrelation.py:417-442): float32 cast, mono->stereo,
+        GPU convolution, then the host epilogue - side-channel encode (MS mode),
+        width, normaliser."""
+        input_signal = to_float32(input_signal)
+        if input_signal.ndim == 1:
+            input_signal = mono_to_stereo(input_signal)
+        output_signal = self.convolve(input_signal)
+        if self.mode == LayoutMode.MS:
+            encode_signal_to_side_channel(input_signal, output_signal)
+        if self.width is not None:
+            apply_stereo_width(output_signal, self.width)
+        if self.normalizer:
+            self.normalizer(input_signal, output_signal)
+        return output_signal
+
+
+# ----------------------------------------------------------------------------
+# NumPy-only chain stages (outside the GPU scope)
+# ----------------------------------------------------------------------------
+@dataclass(kw_only=True)
+class HaasEffect(Decorrelator):
+    """Delay one channel by ``round(delay_time_seconds * fs)`` samples
+    (decorrelation.py:163-230).  Returns float64 ``(n + delay, 2)``."""
+
+    delayed_channel: int = 0
+    delay_time_seconds: float = 0.02
+    mode: LayoutMode = LayoutMode.LR
+
+    def decorrelate(self, input_signal: NDArray) -> NDArray:
+        output_signal = self.haas_delay(to_float32(input_signal))
+        if self.width is not None:
+            apply_stereo_width(output_signal, self.width)
+        return output_signal
+
+    def haas_delay(self, input_signal: NDArray) -> NDArray:
+        delay = round(self.delay_time_seconds * self.sample_rate_hz)
+        n = len(input_signal)
+        mono = input_signal.ndim == 1
+        if mono:
+            input_signal = mono_to_stereo(input_signal)
+        out = np.zeros((n + delay, 2))
+        out[:n, :] = input_signal
+        mid_side = self.mode == LayoutMode.MS
+        if mid_side and not mono:
+            LR_to_MS(out)
+        out[:, self.delayed_channel] = np.roll(out[:, self.delayed_channel], delay, axis=0)
+        if mid_side:
+            MS_to_LR(out)
+            if mono:
+                out *= 0.5          # the duplicated mono channel counted twice
+        return out
+
+
+@dataclass(kw_only=True)
+class WhiteNoise(Decorrelator):
+    """Dense Gaussian FIR per channel via ``np.convolve(mode='same')``
+    (decorrelation.py:670-716) - the comparison baseline of the reference's plots."""
+
+    duration_seconds: float = 0.03
+    seed: Optional[int] = None
+    white_noise_filter: Any = field(default=None, repr=False)
+
+    def __post_init__(self) -> None:
+        rng = np.random.default_rng(self.seed)
+        self.white_noise_filter = rng.normal(loc=0, scale=1,
+                                             size=(self.fir_length_samples, self.num_outs))
+
+    @property
+    def fir_length_samples(self) -> int:
+        return int(round(self.sample_rate_hz * self.duration_seconds))
+
+    @property
+    def FIR(self) -> NDArray:
+        return self.white_noise_filter
+
+    def decorrelate(self, input_signal: NDArray) -> NDArray:
+        input_signal = to_float32(input_signal)
+        if input_signal.ndim == 1:
+            input_signal = mono_to_stereo(input_signal)
+        out = np.zeros((len(input_signal), self.num_outs), dtype=np.float32)
+        for c in range(self.num_outs):
+            out[:, c] = np.convolve(input_signal[:, c], self.white_noise_filter[:, c], mode='same')
+        if self.width is not None:
+            apply_stereo_width(out, self.width)
+        rms_normalize(input_signal, out)
+        return out
+
+
+# ----------------------------------------------------------------------------
+# SignalChain   (decorrelation.py:71-153)
+# ----------------------------------------------------------------------------
+class SignalChain:
+    """Fluent, lazily-instantiated cascade of stages; ``chain(x)`` feeds each
+    stage the previous stage's output."""
+
+    def __init__(self, *, sample_rate_hz: int, num_outs: int = 2, lazy: bool = True,
+                 _hot: bool = False, _decorrelators=None):
+        if _decorrelators is not None:
+            raise TypeError(
+                'Cannot supply decorrelators directly, use ``SignalChain.velvet_noise``,'
+                ' ``SignalChain.haas_effect``, ``SignalChain.white_noise``, or ``SignalChain.stateless``.')
+        self.sample_rate_hz = sample_rate_hz
+        self.num_outs = num_outs
+        self.lazy = lazy
+        self._hot = bool(_hot) or not lazy
+        self._decorrelators: list = []
+
+    def __repr__(self) -> str:
+        return (f'SignalChain(sample_rate_hz={self.sample_rate_hz}, num_outs={self.num_outs}, '
+                f'lazy={self.lazy}, stages={len(self._decorrelators)})')
+
+    # ---- builders ------------------------------------------------------------
+    def velvet_noise(self, **kwargs) -> 'SignalChain':
+        return self._add(VelvetNoise, kwargs)
+
+    def haas_effect(self, **kwargs) -> 'SignalChain':
+        return self._add(HaasEffect, kwargs)
+
+    def white_noise(self, **kwargs) -> 'SignalChain':
+        return self._add(WhiteNoise, kwargs)
+
+    def stateless(self, function: StatelessDecorrelator, *args, **kwargs) -> 'SignalChain':
+        """``function`` is later called as ``function(*args, signal, **kwargs)`` -
+        ``functools.partial`` semantics, positional extras BEFORE the signal,
+        exactly as upstream (decorrelation.py:104-110)."""
+        bound = partial(function, *args, **kwargs)
+        self._decorrelators.append(bound if self._hot else (lambda: bound))
+        return self
+
+    def _add(self, cls, kwargs: dict) -> 'SignalChain':
+        rate = kwargs.pop('sample_rate_hz', None)
+        if rate is not None and rate != self.sample_rate_hz:
+            raise TypeError(f'sample_rate_hz={rate} was supplied to {cls} but differs from the sample '
+                            f'rate of the enclosing ``SignalChain`` ({self.sample_rate_hz})')
+        params = dict(kwargs)
+        params.setdefault('num_outs', self.num_outs)
+
+        def make():
+            return cls(sample_rate_hz=self.sample_rate_hz, **params)
+
+        self._decorrelators.append(make() if self._hot else make)
+        return self
+
+    # ---- execution -----------------------------------------------------------
+    def _init_decorrelators(self) -> None:
+        if self._hot:
+            return
+        self._decorrelators = [factory() for factory in self._decorrelators]
+        self._hot = True
+
+    def __call__(self, input_signal: NDArray) -> NDArray:
+        self._init_decorrelators()
+        signal = input_signal
+        for stage in self._decorrelators:
+            signal = stage(signal)
+        return signal
