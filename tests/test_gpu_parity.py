@@ -276,3 +276,37 @@ def test_device_pointer_api_and_table_roundtrip(vnd, golden):
         clone.convolve_device(xd.data_ptr(), yd.data_ptr(), 6, 30000, 3, vnd.MODE_EXACT, stream)
     with pytest.raises(ValueError):      # overlapping buffers
         clone.convolve_device(xd.data_ptr(), xd.data_ptr(), 6, 30000, 2, vnd.MODE_EXACT, stream)
+
+
+@pytest.mark.parametrize('channels,gname', [(2, 'g48k_k30'), (1, 'g44k_mono'), (8, 'g96k_k64_c8'), (3, 'g48k_c3')])
+def test_misaligned_device_pointers(vnd, golden, channels, gname):
+    """Signals that start 4, 8 or 12 bytes off a 16-byte boundary take the narrower
+    buffer-access shapes (kFrame / kDword); every shape must give the same bits."""
+    import torch
+    from vndecorrelate_amd import _native
+    from vndecorrelate_amd.taps import function_path_arrays
+    ctx = _native.default_context()
+    fir = golden.fir(gname)
+    arrays = function_path_arrays(fir)
+    table = _native.TapTable.create(ctx, arrays.tap_offsets, arrays.tap_index, arrays.tap_weight)
+    offs, idx, w = O.fir_to_taps(fir)
+    n, batch = 9001, 3
+    x = make_input(dict(seed=21, shape=[batch, n, channels]))
+    want = c_oracle.convolve(x, offs, idx, w, threads=4)
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        for cg in [c for c in (1, 2, 4) if channels % c == 0]:
+            ctx.set_variant(cg << 8)
+            for shift in (0, 1, 2, 3):                     # floats
+                xin = torch.zeros(x.size + 8, dtype=torch.float32, device='cuda:0')
+                yout = torch.full((x.size + 8,), 7.0, dtype=torch.float32, device='cuda:0')
+                xin[shift:shift + x.size] = torch.from_numpy(x.ravel()).cuda()
+                table.convolve_device(xin.data_ptr() + 4 * shift, yout.data_ptr() + 4 * shift,
+                                      batch, n, channels, vnd.MODE_EXACT, stream)
+                torch.cuda.synchronize()
+                got = yout.cpu().numpy()
+                assert np.array_equal(got[shift:shift + x.size].reshape(x.shape), want), (cg, shift)
+                # nothing outside the output range was touched
+                assert np.all(got[:shift] == 7.0) and np.all(got[shift + x.size:] == 7.0), (cg, shift)
+    finally:
+        ctx.set_variant(-1)

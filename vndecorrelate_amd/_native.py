@@ -64,6 +64,31 @@ _lib = None
 _lib_lock = threading.Lock()
 
 
+def _preload_hip_runtime() -> None:
+    """Keep ONE HIP runtime in the process.
+
+    PyTorch-ROCm wheels bundle their own ``libamdhip64.so`` (soname
+    ``libamdhip64.so.7``) and ask for it by the unversioned name, so if this
+    extension pulled in ``/opt/rocm``'s copy first, a later ``import torch`` would
+    map a second runtime and see no GPUs.  When torch is installed but not yet
+    imported, map its runtime first: our NEEDED ``libamdhip64.so.7`` then binds
+    to it by soname, and torch later finds the same file already loaded.
+    """
+    try:
+        with open('/proc/self/maps') as maps:
+            if any('libamdhip64' in line for line in maps):
+                return
+    except OSError:
+        pass
+    import importlib.util
+    spec = importlib.util.find_spec('torch')
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = pathlib.Path(list(spec.submodule_search_locations)[0]) / 'lib' / 'libamdhip64.so'
+    if cand.exists():
+        ctypes.CDLL(str(cand), mode=ctypes.RTLD_GLOBAL)
+
+
 class NativeError(RuntimeError):
     """The HIP extension is missing or a device call failed."""
 
@@ -78,6 +103,7 @@ def load_library():
             raise NativeError(
                 f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; '
                 f'g.build()"` (hipcc --offload-arch=gfx950).  vndecorrelate_amd has no CPU fallback.')
+        _preload_hip_runtime()
         lib = ctypes.CDLL(str(LIB_PATH))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

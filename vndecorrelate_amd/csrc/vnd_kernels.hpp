@@ -87,6 +87,186 @@ __device__ __forceinline__ float tap_op(float acc, float v, float w)
     }
 }
 
+
+// ---- staging: HBM -> registers -> per-channel LDS planes ------------------------
+// All global traffic goes through raw buffer descriptors whose num_records is
+// the number of bytes left in the stream from the tile start.  The hardware
+// range check is per dword for dword/x2/x4 accesses: loads past the end of the
+// stream return 0 - exactly the reference's "term drops out when n + i >= N"
+// (decorrelation.py:656-658, adding 0.0f is exact) - and stores past the end are
+// discarded, so neither the halo of a stream's last tiles nor a ragged final
+// pair needs a branch, and no access can leave the stream's allocation.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// Raw-buffer intrinsics bound by name.  (The clang builtin
+// __builtin_amdgcn_raw_buffer_load_b64 of ROCm 7.2 lowers to a 32-bit load and
+// splats it, so the 64-bit forms are declared here directly.)
+__device__ float buf_load1(v4i rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ v2f buf_load2(v4i rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ v4f buf_load4(v4i rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ void buf_store1(float d, v4i rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
+__device__ void buf_store2(v2f d, v4i rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
+__device__ void buf_store4(v4f d, v4i rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+
+// Descriptor of a raw (stride 0) buffer: base, num_records in BYTES, gfx9 dword format.
+// Built from kernel arguments and blockIdx only, so it lives in SGPRs.
+__device__ __forceinline__ v4i make_rsrc(const void *base, int64_t bytes)
+{
+    const int64_t cap = 0x7fffffff;            // one tile's window is far smaller
+    const uint64_t addr = (uint64_t)base;
+    v4i r;
+    r.x = (int)(uint32_t)addr;
+    r.y = (int)((uint32_t)(addr >> 32) & 0xffffu);
+    r.z = (int)(bytes < 0 ? 0 : (bytes > cap ? cap : bytes));
+    r.w = 0x00020000;
+    return r;
+}
+
+// A lane moves PAIRS of frames.  Access shape is picked per workgroup from the
+// alignment of its first sample (all three are the same arithmetic downstream):
+//   kPair   one access of 2*CG dwords   (block owns all channels, base 8*CG-aligned)
+//   kFrame  one access of CG dwords per frame            (base 4*CG-aligned)
+//   kDword  dword accesses, any alignment, any channel stride
+// Byte offsets are written as  index * constant  so that hipcc can prove the
+// natural alignment and keeps the wide buffer_load/store_dwordx2/x4 forms.
+// kStageDepth independent loads are issued before the first LDS write, so every
+// wave keeps several KiB in flight; with one load per lane and iteration the
+// kernel is bound by HBM latency, not bandwidth.
+enum { kPair = 0, kFrame = 1, kDword = 2 };
+constexpr int kStageDepth = 4;
+
+// strideG = C / CG  (frame stride in units of CG floats);  q = pair index in the window
+template <int CG, int SHAPE>
+__device__ __forceinline__ void load_pair(v4i rsrc, int q, int strideG, int C, float (&v)[2 * CG])
+{
+    if constexpr (SHAPE == kPair) {
+        const int off = q * (8 * CG);
+        if constexpr (CG == 1) {
+            const v2f t = buf_load2(rsrc, off, 0, 0);
+            v[0] = t.x; v[1] = t.y;
+        } else if constexpr (CG == 2) {
+            const v4f t = buf_load4(rsrc, off, 0, 0);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+            const v4f p = buf_load4(rsrc, off, 0, 0), t = buf_load4(rsrc, off + 16, 0, 0);
+            v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w;
+            v[4] = t.x; v[5] = t.y; v[6] = t.z; v[7] = t.w;
+        }
+    } else if constexpr (SHAPE == kFrame) {
+        const int off0 = (2 * q) * strideG * (4 * CG);
+        const int off1 = (2 * q + 1) * strideG * (4 * CG);
+        if constexpr (CG == 1) {
+            v[0] = buf_load1(rsrc, off0, 0, 0); v[1] = buf_load1(rsrc, off1, 0, 0);
+        } else if constexpr (CG == 2) {
+            const v2f p = buf_load2(rsrc, off0, 0, 0), t = buf_load2(rsrc, off1, 0, 0);
+            v[0] = p.x; v[1] = p.y; v[2] = t.x; v[3] = t.y;
+        } else {
+            const v4f p = buf_load4(rsrc, off0, 0, 0), t = buf_load4(rsrc, off1, 0, 0);
+            v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w;
+            v[4] = t.x; v[5] = t.y; v[6] = t.z; v[7] = t.w;
+        }
+    } else {
+        const int off0 = (2 * q) * C * 4;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+            v[c] = buf_load1(rsrc, off0 + 4 * c, 0, 0);
+            v[CG + c] = buf_load1(rsrc, off0 + C * 4 + 4 * c, 0, 0);
+        }
+    }
+}
+
+// out pair -> interleaved frames;  v[c] = frame 2q, v[CG + c] = frame 2q+1
+template <int CG, int SHAPE>
+__device__ __forceinline__ void store_pair(v4i rdst, int q, int strideG, int C, const float (&v)[2 * CG])
+{
+    if constexpr (SHAPE == kPair) {
+        const int off = q * (8 * CG);
+        if constexpr (CG == 1) {
+            v2f t; t.x = v[0]; t.y = v[1];
+            buf_store2(t, rdst, off, 0, 0);
+        } else if constexpr (CG == 2) {
+            v4f t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+            buf_store4(t, rdst, off, 0, 0);
+        } else {
+            v4f t, u;
+            t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+            u.x = v[4]; u.y = v[5]; u.z = v[6]; u.w = v[7];
+            buf_store4(t, rdst, off, 0, 0);
+            buf_store4(u, rdst, off + 16, 0, 0);
+        }
+    } else if constexpr (SHAPE == kFrame) {
+        const int off0 = (2 * q) * strideG * (4 * CG);
+        const int off1 = (2 * q + 1) * strideG * (4 * CG);
+        if constexpr (CG == 1) {
+            buf_store1(v[0], rdst, off0, 0, 0);
+            buf_store1(v[1], rdst, off1, 0, 0);
+        } else if constexpr (CG == 2) {
+            v2f t, u; t.x = v[0]; t.y = v[1]; u.x = v[2]; u.y = v[3];
+            buf_store2(t, rdst, off0, 0, 0);
+            buf_store2(u, rdst, off1, 0, 0);
+        } else {
+            v4f t, u;
+            t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+            u.x = v[4]; u.y = v[5]; u.z = v[6]; u.w = v[7];
+            buf_store4(t, rdst, off0, 0, 0);
+            buf_store4(u, rdst, off1, 0, 0);
+        }
+    } else {
+        const int off0 = (2 * q) * C * 4;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+            buf_store1(v[c], rdst, off0 + 4 * c, 0, 0);
+            buf_store1(v[CG + c], rdst, off0 + C * 4 + 4 * c, 0, 0);
+        }
+    }
+}
+
+template <int CG>
+__device__ __forceinline__ int access_shape(const void *base, int C)
+{
+    const uintptr_t p = (uintptr_t)base;
+    if (C == CG && (p & (8 * CG - 1)) == 0) return kPair;
+    if ((p & (4 * CG - 1)) == 0) return kFrame;      // C % CG == 0 by construction
+    return kDword;
+}
+
+template <int CG, bool DUAL>
+__device__ __forceinline__ void write_pair(float *planeA, float *planeB, int W, int f,
+                                           const float (&v)[2 * CG])
+{
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
+        *(float2 *)(planeA + c * W + f) = make_float2(v[c], v[CG + c]);
+        if constexpr (DUAL) {
+            // B[m] = A[m+1]: frame f lands on slot f-1, frame f+1 on slot f
+            if (f > 0) planeB[c * W + f - 1] = v[c];
+            planeB[c * W + f] = v[CG + c];
+        }
+    }
+}
+
+template <int CG, bool DUAL, int SHAPE>
+__device__ __forceinline__ void stage_window(float *planeA, float *planeB, v4i rsrc,
+                                             int C, int W, int tid)
+{
+    const int npairs = W >> 1;
+    const int strideG = C / CG;
+    for (int q0 = tid; q0 < npairs; q0 += kThreads * kStageDepth) {
+        float v[kStageDepth][2 * CG];
+        int q[kStageDepth];
+        // Lanes past the window re-do its last pair (same value to the same slot)
+        // rather than branch: the loads stay one straight-line burst.
+#pragma unroll
+        for (int u = 0; u < kStageDepth; ++u) {
+            q[u] = min(q0 + u * kThreads, npairs - 1);
+            load_pair<CG, SHAPE>(rsrc, q[u], strideG, C, v[u]);   // in range, or zero-filled by the descriptor
+        }
+#pragma unroll
+        for (int u = 0; u < kStageDepth; ++u) write_pair<CG, DUAL>(planeA, planeB, W, 2 * q[u], v[u]);
+    }
+}
+
 // CG   channels handled per workgroup (C % CG == 0)
 // R    frame pairs per lane (tile = 2 * kThreads * R frames)
 // MODE 0 exact (mul, add)  1 fma
@@ -117,36 +297,12 @@ __global__ __launch_bounds__(kThreads) void conv_lds_kernel(const KArgs a)
 
     // ---- stage tile + halo: coalesced HBM read, de-interleave into planes ----
     {
-        const int64_t remain = a.n - t0;                   // frames available from t0
-        const int valid = remain < W ? (int)remain : W;
-        const bool vec_ok = (CG == 1) ||
-            ((((uintptr_t)(xs + c0)) & (CG * 4 - 1)) == 0 && (C % CG) == 0);
-        for (int f = tid; f < W; f += kThreads) {
-            float v[CG];
-#pragma unroll
-            for (int c = 0; c < CG; ++c) v[c] = 0.0f;
-            if (f < valid) {
-                const float *src = xs + (t0 + f) * C + c0;
-                if constexpr (CG == 2) {
-                    if (vec_ok) { float2 t = *(const float2 *)src; v[0] = t.x; v[1] = t.y; }
-                    else { v[0] = src[0]; v[1] = src[1]; }
-                } else if constexpr (CG == 4) {
-                    if (vec_ok) { float4 t = *(const float4 *)src; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-                    else { v[0] = src[0]; v[1] = src[1]; v[2] = src[2]; v[3] = src[3]; }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < CG; ++c) v[c] = src[c];
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < CG; ++c) {
-                planeA[c * W + f] = v[c];
-                if constexpr (DUAL) { if (f > 0) planeB[c * W + f - 1] = v[c]; }
-            }
-        }
-        if constexpr (DUAL) {
-            if (tid < CG) planeB[tid * W + W - 1] = 0.0f;   // never read; keep it defined
-        }
+        const float *src = xs + t0 * C + c0;                 // this block's first sample
+        const v4i rsrc = make_rsrc(src, ((a.n - t0) * C - c0) * 4);
+        const int shape = access_shape<CG>(src, C);          // workgroup-uniform
+        if (shape == kPair)       stage_window<CG, DUAL, kPair>(planeA, planeB, rsrc, C, W, tid);
+        else if (shape == kFrame) stage_window<CG, DUAL, kFrame>(planeA, planeB, rsrc, C, W, tid);
+        else                      stage_window<CG, DUAL, kDword>(planeA, planeB, rsrc, C, W, tid);
     }
     __syncthreads();
 
@@ -234,30 +390,21 @@ __global__ __launch_bounds__(kThreads) void conv_lds_kernel(const KArgs a)
     }
 
     // ---- interleaved store: 2 frames x CG channels per lane and pair ------------
-    const bool st_vec = (C == CG) && ((((uintptr_t)ys) & 15) == 0) && (CG == 2 || CG == 4);
+    // Range-checked buffer stores: frames past the end of the stream are dropped.
+    {
+        float *dst = ys + t0 * C + c0;
+        const v4i rdst = make_rsrc(dst, ((a.n - t0) * C - c0) * 4);
+        const int shape = access_shape<CG>(dst, C);
+        const int strideG = C / CG;
 #pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const int64_t n0 = t0 + lane_base + 2 * kThreads * j;
-        if (n0 >= a.n) continue;
-        float *dst = ys + n0 * C + c0;
-        const bool two = n0 + 1 < a.n;
-        if constexpr (CG == 2) {
-            if (st_vec && two) {
-                *(float4 *)dst = make_float4(out[0][j].x, out[1][j].x, out[0][j].y, out[1][j].y);
-                continue;
-            }
-        }
-        if constexpr (CG == 4) {
-            if (st_vec) {
-                *(float4 *)dst = make_float4(out[0][j].x, out[1][j].x, out[2][j].x, out[3][j].x);
-                if (two) *(float4 *)(dst + C) = make_float4(out[0][j].y, out[1][j].y, out[2][j].y, out[3][j].y);
-                continue;
-            }
-        }
+        for (int j = 0; j < R; ++j) {
+            float v[2 * CG];
 #pragma unroll
-        for (int c = 0; c < CG; ++c) {
-            dst[c] = out[c][j].x;
-            if (two) dst[C + c] = out[c][j].y;
+            for (int c = 0; c < CG; ++c) { v[c] = out[c][j].x; v[CG + c] = out[c][j].y; }
+            const int q = tid + kThreads * j;
+            if (shape == kPair)       store_pair<CG, kPair>(rdst, q, strideG, C, v);
+            else if (shape == kFrame) store_pair<CG, kFrame>(rdst, q, strideG, C, v);
+            else                      store_pair<CG, kDword>(rdst, q, strideG, C, v);
         }
     }
 }
