@@ -53,7 +53,7 @@ def parse():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--pool', type=int, default=128, help='distinct cfg2 signals per rank and step')
-    ap.add_argument('--mode', choices=['exact', 'fma'], default=os.environ.get('VND_BENCH_MODE', 'exact'))
+    ap.add_argument('--mode', choices=['exact', 'fma', 'fast'], default=os.environ.get('VND_BENCH_MODE', 'fast'))
     ap.add_argument('--cpu-seconds', type=float, default=10.0, help='budget of the CPU baseline leg')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--variant', type=int, default=-1, help='kernel variant override (tuning)')
@@ -108,7 +108,7 @@ def main():
 
     ctx = _native.default_context()
     ctx.set_variant(args.variant)
-    mode = vnd.MODE_EXACT if args.mode == 'exact' else vnd.MODE_FMA
+    mode = {'exact': vnd.MODE_EXACT, 'fma': vnd.MODE_FMA, 'fast': vnd.MODE_FAST}[args.mode]
 
     # ---- shared impulse table: built on rank 0, broadcast over RCCL/xGMI ------
     if rank == 0:

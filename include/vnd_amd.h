@@ -45,7 +45,9 @@ typedef enum vnd_status {
 typedef enum vnd_mode {
     VND_MODE_EXACT = 0,  /* acc = f32(acc + f32(x*w)), taps in table order: bit-identical
                             to the reference's NumPy paths (decorrelation.py:656-658, :405-414) */
-    VND_MODE_FMA = 1     /* acc = fma(x, w, acc): one rounding per tap, <= 1e-6 of peak    */
+    VND_MODE_FMA = 1,    /* acc = fma(x, w, acc) in table order: one rounding per tap       */
+    VND_MODE_FAST = 2    /* fma, free summation order, segment gains folded into the weights:
+                            the throughput mode; <= 1e-6 of the output peak from the reference */
 } vnd_mode;
 
 typedef struct vnd_ctx vnd_ctx;     /* one per (process, device)                      */

@@ -67,11 +67,13 @@ def test_function_path_exact(vnd, golden, name):
         assert np.array_equal(y, c_oracle.convolve(x.astype(np.float32), offs, idx, w))
 
 
+@pytest.mark.parametrize('mode', ['fma', 'fast'])
 @pytest.mark.parametrize('name', sorted(n for n in MANIFEST['fn'] if n != 'fn_cfg4_b4'))
-def test_function_path_fma(vnd, golden, name):
+def test_function_path_tolerance_modes(vnd, golden, name, mode):
     meta = golden.manifest['fn'][name]
     x = make_input(meta['input'])
-    y = vnd.convolve_velvet_noise(x, _fir_for(golden, name, meta), mode=vnd.MODE_FMA)
+    m = vnd.MODE_FMA if mode == 'fma' else vnd.MODE_FAST
+    y = vnd.convolve_velvet_noise(x, _fir_for(golden, name, meta), mode=m)
     golden.expect(name, y, exact=False, rtol_peak=TOL_PEAK)
 
 
@@ -99,6 +101,8 @@ def test_class_convolve(vnd, golden, name):
     vnd.set_default_mode(vnd.MODE_FMA)       # weights are +-1: FMA is exact here too
     try:
         golden.expect(name, vn.convolve(x), exact=x.dtype == np.float32, rtol_peak=TOL_PEAK)
+        vnd.set_default_mode(vnd.MODE_FAST)  # gains folded, free order: tolerance parity
+        golden.expect(name, vn.convolve(x), exact=False, rtol_peak=TOL_PEAK)
     finally:
         vnd.set_default_mode(vnd.MODE_EXACT)
 
@@ -178,11 +182,11 @@ def test_variants_agree(vnd, golden, channels, gname):
     want = c_oracle.convolve(x, offs, idx, w)
     cgs = [c for c in (1, 2, 4) if channels % c == 0]
     try:
-        for mode in (vnd.MODE_EXACT, vnd.MODE_FMA):
+        for mode in (vnd.MODE_EXACT, vnd.MODE_FMA, vnd.MODE_FAST):
             for direct in (False, True):
                 for cg in ([0] if direct else cgs):
                     for r in ([None] if direct else range(5)):
-                        for dual in ([None] if direct else (0, 1)):
+                        for dual in ([None] if direct or mode == vnd.MODE_FAST else (0, 1)):
                             ctx.set_variant(_variant(r, dual, cg, direct))
                             y = vnd.convolve_velvet_noise(x, fir, mode=mode)
                             tag = f'mode={mode} direct={direct} cg={cg} r={r} dual={dual}'

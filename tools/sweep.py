@@ -37,6 +37,8 @@ def main():
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--cgs', default='')
     ap.add_argument('--rs', default='1,2,3,4')
+    ap.add_argument('--modes', default='0,1,2')
+    ap.add_argument('--direct', action='store_true')
     args = ap.parse_args()
     import torch
     import vndecorrelate_amd.decorrelation as vnd
@@ -55,12 +57,15 @@ def main():
     nbytes = 8 * x.numel()
     cgs = [int(c) for c in args.cgs.split(',')] if args.cgs else ([2] if ch % 2 == 0 else [1])
     cases = []
-    for mode in (0, 1):
+    for mode in [int(m) for m in args.modes.split(',')]:
         for cg in cgs:
             for r in [int(v) for v in args.rs.split(',')]:
-                for dual in (0, 1):
+                for dual in ((0,) if mode == 2 else (0, 1)):
+                    if mode == 2 and r > 3:
+                        continue
                     cases.append((mode, cg, r, dual, False))
-        cases.append((mode, 0, None, None, True))
+        if args.direct:
+            cases.append((mode, 0, None, None, True))
     results = {c: [] for c in cases}
     for rnd in range(args.rounds + 1):
         for c in cases:
@@ -79,7 +84,7 @@ def main():
         desc = table.describe(pool, n, ch, mode)
         med, mn = float(np.median(results[c])), float(np.min(results[c]))
         gbs = nbytes / med / 1e6
-        print(f'{"exact" if mode == 0 else "fma  "} {cg:2d} {(1 << r) if r is not None else 0:5d} '
+        print(f'{("exact", "fma  ", "fast ")[mode]} {cg:2d} {(1 << r) if r is not None else 0:5d} '
               f'{dual if dual is not None else "-":>4} {int(direct):6d} {med:8.4f} {mn:8.4f} '
               f'{gbs:10.1f} {gbs / 8000:10.4f}   {desc}')
     ctx.set_variant(-1)

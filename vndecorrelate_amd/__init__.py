@@ -9,6 +9,7 @@ __version__ = '0.1.0'
 
 from .decorrelation import (  # noqa: F401
     MODE_EXACT,
+    MODE_FAST,
     MODE_FMA,
     HaasEffect,
     SignalChain,

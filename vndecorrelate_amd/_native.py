@@ -16,7 +16,8 @@ import numpy as np
 
 ABI_VERSION = 1
 MODE_EXACT = 0   # acc = f32(acc + f32(x*w)) : bit-identical to the reference's NumPy paths
-MODE_FMA = 1     # acc = fma(x, w, acc)
+MODE_FMA = 1     # acc = fma(x, w, acc), table order
+MODE_FAST = 2    # fma, free summation order, gains folded into weights: the throughput mode
 
 _PKG = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _PKG / 'libvnd_amd.so'

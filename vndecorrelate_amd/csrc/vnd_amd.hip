@@ -58,7 +58,7 @@ struct vnd_taps {
     std::vector<float> w, seg_gain;
     std::vector<uint8_t> flags;
     // device image
-    Tap *d_taps = nullptr;
+    Tap *d_taps = nullptr, *d_taps_flat = nullptr;
     int32_t *d_tap_off = nullptr, *d_seg_off = nullptr, *d_seg_end = nullptr;
     float *d_seg_gain = nullptr;
     uint8_t *d_flags = nullptr;
@@ -110,6 +110,26 @@ static kern_t lds_kernel(int cg, int r_log2, int mode, int dual)
     }
 }
 
+template <int CG>
+static kern_t fast_by_r(int r_log2)
+{
+    switch (r_log2) {
+    case 0: return conv_fast_kernel<CG, 1>;
+    case 1: return conv_fast_kernel<CG, 2>;
+    case 2: return conv_fast_kernel<CG, 4>;
+    default: return conv_fast_kernel<CG, 8>;
+    }
+}
+
+static kern_t fast_kernel(int cg, int r_log2)
+{
+    switch (cg) {
+    case 1: return fast_by_r<1>(r_log2);
+    case 2: return fast_by_r<2>(r_log2);
+    default: return fast_by_r<4>(r_log2);
+    }
+}
+
 static int halo_of(int max_index) { return (max_index + 2 + 15) & ~15; }
 
 static size_t lds_need(int cg, int r_log2, int dual, int max_index)
@@ -120,7 +140,7 @@ static size_t lds_need(int cg, int r_log2, int dual, int max_index)
 
 // variant word (vnd_set_variant): bits 0-3 r_log2+1 (0 = auto), bit 4 dual,
 // bit 5 "dual given", bits 8-11 channels per workgroup (0 = auto), bit 12 direct.
-static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64_t n, int C)
+static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64_t n, int C, int mode)
 {
     Plan p;
     const int v = ctx->variant;
@@ -130,6 +150,7 @@ static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int6
     if (cg == 0) cg = (C % 2 == 0) ? 2 : 1;
     if (C % cg != 0 || (cg != 1 && cg != 2 && cg != 4)) cg = 1;
     int dual = (v >= 0 && ((v >> 5) & 1)) ? ((v >> 4) & 1) : 0;
+    if (mode == VND_MODE_FAST) dual = 0;
     int r_log2 = (v >= 0 && (v & 15)) ? (v & 15) - 1 : -1;
 
     const size_t limit = (size_t)ctx->lds_limit;
@@ -146,6 +167,7 @@ static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int6
         }
     }
     if (r_log2 > 4) r_log2 = 4;
+    if (mode == VND_MODE_FAST && r_log2 > 3) r_log2 = 3;
     // shrink until the tile fits one workgroup's LDS at all
     while (lds_need(cg, r_log2, dual, t->max_index) > limit) {
         if (dual) dual = 0;
@@ -177,7 +199,7 @@ static vnd_status check_shape(const vnd_ctx *ctx, const vnd_taps *t, int64_t bat
     if (batch < 0 || n < 0) return fail(VND_ERR_INVALID, "negative batch or frame count");
     if (C != t->C)
         return fail(VND_ERR_INVALID, "signal has %d channels but the tap table has %d", C, t->C);
-    if (mode != VND_MODE_EXACT && mode != VND_MODE_FMA)
+    if (mode != VND_MODE_EXACT && mode != VND_MODE_FMA && mode != VND_MODE_FAST)
         return fail(VND_ERR_INVALID, "unknown mode %d", mode);
     if (n > (int64_t)1 << 40 || batch * n * C / std::max<int64_t>(n, 1) > (int64_t)1 << 40)
         return fail(VND_ERR_UNSUPPORTED, "problem too large");
@@ -188,9 +210,9 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
                          int64_t n, int32_t C, int32_t mode, hipStream_t stream)
 {
     if (batch == 0 || n == 0) return VND_OK;
-    const Plan p = make_plan(ctx, t, batch, n, C);
+    const Plan p = make_plan(ctx, t, batch, n, C, mode);
     KArgs a{};
-    a.x = x; a.y = y; a.taps = t->d_taps; a.tap_off = t->d_tap_off;
+    a.x = x; a.y = y; a.taps = t->d_taps; a.taps_flat = t->d_taps_flat; a.tap_off = t->d_tap_off;
     a.seg_off = t->has_seg ? t->d_seg_off : nullptr;
     a.seg_end = t->d_seg_end; a.seg_gain = t->d_seg_gain;
     a.chan_flags = t->has_flags ? t->d_flags : nullptr;
@@ -199,12 +221,13 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
     if (p.direct) {
         a.tiles = (int32_t)batch; a.groups = 1; a.W = 0;
         kern_t k = mode == VND_MODE_EXACT ? conv_direct_kernel<0> : conv_direct_kernel<1>;
+        if (mode == VND_MODE_FAST) a.taps = t->d_taps;      // direct kernel keeps the table's association
         hipLaunchKernelGGL(k, dim3(p.nblocks), dim3(kThreads), 0, stream, a);
     } else {
         if ((int64_t)batch * p.tiles * p.groups > 0x7fffffffLL)
             return fail(VND_ERR_UNSUPPORTED, "grid too large; split the batch");
         a.tiles = p.tiles; a.groups = p.groups; a.W = p.W;
-        kern_t k = lds_kernel(p.cg, p.r_log2, mode, p.dual);
+        kern_t k = mode == VND_MODE_FAST ? fast_kernel(p.cg, p.r_log2) : lds_kernel(p.cg, p.r_log2, mode, p.dual);
         if (p.lds_bytes > 65536)
             HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)p.lds_bytes));
@@ -217,6 +240,7 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
 static void free_taps_dev(vnd_taps *t)
 {
     if (t->d_taps) (void)hipFree(t->d_taps);
+    if (t->d_taps_flat) (void)hipFree(t->d_taps_flat);
     if (t->d_tap_off) (void)hipFree(t->d_tap_off);
     if (t->d_seg_off) (void)hipFree(t->d_seg_off);
     if (t->d_seg_end) (void)hipFree(t->d_seg_end);
@@ -364,6 +388,14 @@ vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, 
     for (int32_t k = 0; k < total; ++k) { packed[k].idx = tap_index[k]; packed[k].w = tap_weight[k]; }
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = upload(&t->d_taps, packed.data(), (size_t)total);
+    if (has_seg && t->apply_gain) {            // fast mode: gain folded into each weight
+        for (int c = 0; c < C; ++c) {
+            int32_t k = tap_offsets[c];
+            for (int32_t sgi = seg_offsets[c]; sgi < seg_offsets[c + 1]; ++sgi)
+                for (; k < seg_end[sgi]; ++k) packed[k].w = tap_weight[k] * seg_gain[sgi];
+        }
+    }
+    if (e == hipSuccess) e = upload(&t->d_taps_flat, packed.data(), (size_t)total);
     if (e == hipSuccess) e = upload(&t->d_tap_off, t->tap_off.data(), t->tap_off.size());
     if (e == hipSuccess && has_seg) e = upload(&t->d_seg_off, t->seg_off.data(), t->seg_off.size());
     if (e == hipSuccess && has_seg) e = upload(&t->d_seg_end, t->seg_end.data(), t->seg_end.size());
@@ -528,13 +560,13 @@ vnd_status vnd_describe_launch(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, i
     vnd_status st = check_shape(ctx, t, batch, n, C, mode);
     if (st != VND_OK) return st;
     if (!text || len <= 0) return fail(VND_ERR_INVALID, "null text buffer");
-    const Plan p = make_plan(ctx, t, batch, n, C);
+    const Plan p = make_plan(ctx, t, batch, n, C, mode);
     if (p.direct)
         snprintf(text, (size_t)len, "conv_direct mode=%d blocks=%u threads=%d", mode, p.nblocks, kThreads);
     else
         snprintf(text, (size_t)len,
-                 "conv_lds cg=%d pairs_per_lane=%d tile=%d halo=%d dual=%d mode=%d lds=%zuB blocks=%u threads=%d",
-                 p.cg, 1 << p.r_log2, (2 * kThreads) << p.r_log2, p.W - ((2 * kThreads) << p.r_log2), p.dual,
+                 "%s cg=%d pairs_per_lane=%d tile=%d halo=%d dual=%d mode=%d lds=%zuB blocks=%u threads=%d",
+                 mode == VND_MODE_FAST ? "conv_fast" : "conv_lds", p.cg, 1 << p.r_log2, (2 * kThreads) << p.r_log2, p.W - ((2 * kThreads) << p.r_log2), p.dual,
                  mode, p.lds_bytes, p.nblocks, kThreads);
     return VND_OK;
 }

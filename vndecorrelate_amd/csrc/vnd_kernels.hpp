@@ -25,6 +25,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 
 namespace vnd {
 
@@ -50,6 +51,7 @@ struct KArgs {
     const float *__restrict__ x;
     float *__restrict__ y;
     const Tap *__restrict__ taps;
+    const Tap *__restrict__ taps_flat;      // same taps, segment gain folded into the weight
     const int32_t *__restrict__ tap_off;    // [C+1]
     const int32_t *__restrict__ seg_off;    // [C+1] or nullptr (function-path table)
     const int32_t *__restrict__ seg_end;    // exclusive ends, absolute tap positions
@@ -402,6 +404,217 @@ __global__ __launch_bounds__(kThreads) void conv_lds_kernel(const KArgs a)
 #pragma unroll
             for (int c = 0; c < CG; ++c) { v[c] = out[c][j].x; v[CG + c] = out[c][j].y; }
             const int q = tid + kThreads * j;
+            if (shape == kPair)       store_pair<CG, kPair>(rdst, q, strideG, C, v);
+            else if (shape == kFrame) store_pair<CG, kFrame>(rdst, q, strideG, C, v);
+            else                      store_pair<CG, kDword>(rdst, q, strideG, C, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Fast mode (VND_MODE_FAST): same tap sum, free summation order, one FMA per tap.
+//
+// The LDS read is the scarce resource (K reads per output), so every tap must be
+// ONE aligned ds_read_b64 per output pair.  A lane's pair (2q, 2q+1) is aligned
+// for even offsets only; for an odd offset i the pair (2q-1, 2q) is the aligned
+// one (it reads x[2q + (i-1)], x[2q + i]).  So each lane keeps TWO accumulator
+// sets: accE for outputs (2q, 2q+1) fed by the even taps, accO for outputs
+// (2q-1, 2q) fed by the odd taps - both read at offset (i & ~1) - and the two are
+// merged once per tile:  y[2q] = accE.x + accO.y ,  y[2q+1] = accE.y + accO(q+1).x,
+// the neighbour's value going through LDS after the tap loops.  The odd part of
+// the tile's very last output has no lane; one wave reduces it from the tap
+// chunk it already holds in registers.
+//
+// Even and odd taps are walked as two bit masks (s_ff1 on a ballot), each loop
+// software-pipelined: the reads of tap k+1 are in flight while tap k is consumed.
+// The LDS reads of the tap loops are inline asm so that (a) each stays a plain
+// ds_read_b64 with an immediate offset and (b) the waits are counted by hand:
+// hipcc's own bookkeeping drains the queue at the loop header (WAW on recycled
+// registers), which halves the depth of the pipeline.  Protocol (guide 5.7 form
+// ii): "=v" loads, then ONE wait statement that names every destination "+v"
+// before its first consumer; LDS returns in order, so lgkmcnt(N) with the N
+// newest reads belonging to the other buffer means "this buffer has landed".
+__device__ __forceinline__ unsigned lds_addr(const float *p)
+{
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)p;
+}
+
+template <int J>
+__device__ __forceinline__ v2f ds_read_pair(unsigned addr)
+{
+    v2f r;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(J * 2 * kThreads * 4));
+    return r;
+}
+
+template <int R, int... Js>
+__device__ __forceinline__ void issue_reads_seq(v2f (&buf)[R], unsigned addr, std::integer_sequence<int, Js...>)
+{
+    ((buf[Js] = ds_read_pair<Js>(addr)), ...);
+}
+
+template <int R>
+__device__ __forceinline__ void issue_reads(v2f (&buf)[R], unsigned addr)
+{
+    issue_reads_seq<R>(buf, addr, std::make_integer_sequence<int, R>{});
+}
+
+template <int N, int R>
+__device__ __forceinline__ void wait_reads(v2f (&buf)[R])
+{
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(buf[0]) : "n"(N));
+#pragma unroll
+    for (int j = 1; j < R; ++j) asm volatile("" : "+v"(buf[j]));
+}
+
+template <int R>
+__device__ __forceinline__ void consume(float2 (&acc)[R], const v2f (&buf)[R], float w)
+{
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        acc[j].x = __builtin_fmaf(buf[j].x, w, acc[j].x);
+        acc[j].y = __builtin_fmaf(buf[j].y, w, acc[j].y);
+    }
+}
+
+// Walk the taps whose bits are set in `mask` (lane l of tv_idx/tv_w holds tap l).
+// Four taps per trip in straight-line code: reads of the next tap are always in
+// flight while a tap is consumed, and no half-landed register crosses a loop edge
+// (a loop-carried buffer would make hipcc copy registers whose LDS data has not
+// arrived).  The last (count mod 4) taps go one by one.
+template <int R>
+__device__ __forceinline__ void run_tap_list(unsigned long long mask, unsigned base, int tv_idx,
+                                             float tv_w, float2 (&acc)[R])
+{
+    static_assert(R <= 15, "lgkmcnt(R) must fit the 4-bit counter field");
+    int left = __builtin_popcountll(mask);
+    auto next = [&](v2f (&buf)[R], float &w) {
+        const int k = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const int idx = __builtin_amdgcn_readlane(tv_idx, k);
+        w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tv_w), k));
+        issue_reads<R>(buf, base + 4u * (unsigned)(idx & ~1));
+    };
+    for (; left >= 4; left -= 4) {
+        v2f b0[R], b1[R], b2[R], b3[R];
+        float w0, w1, w2, w3;
+        next(b0, w0);
+        next(b1, w1);
+        wait_reads<R, R>(b0);      // b1's R reads are the only ones allowed outstanding
+        consume<R>(acc, b0, w0);
+        next(b2, w2);
+        wait_reads<R, R>(b1);
+        consume<R>(acc, b1, w1);
+        next(b3, w3);
+        wait_reads<R, R>(b2);
+        consume<R>(acc, b2, w2);
+        wait_reads<0, R>(b3);
+        consume<R>(acc, b3, w3);
+    }
+    for (; left > 0; --left) {
+        v2f b0[R];
+        float w0;
+        next(b0, w0);
+        wait_reads<0, R>(b0);
+        consume<R>(acc, b0, w0);
+    }
+}
+
+template <int CG, int R>
+__global__ __launch_bounds__(kThreads) void conv_fast_kernel(const KArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int T = 2 * kThreads * R;
+    const int tid = threadIdx.x;
+    const int W = a.W;
+
+    uint32_t lid = xcd_remap(blockIdx.x, a.nblocks);
+    const int g = lid % (uint32_t)a.groups;
+    lid /= (uint32_t)a.groups;
+    const int tile = lid % (uint32_t)a.tiles;
+    const int64_t b = lid / (uint32_t)a.tiles;
+
+    const int C = a.C;
+    const int c0 = g * CG;
+    const int64_t t0 = (int64_t)tile * T;
+    const float *__restrict__ xs = a.x + b * a.n * C;
+    float *__restrict__ ys = a.y + b * a.n * C;
+    float *plane = lds;                                      // [CG][W]
+
+    {
+        const float *src = xs + t0 * C + c0;
+        const v4i rsrc = make_rsrc(src, ((a.n - t0) * C - c0) * 4);
+        const int shape = access_shape<CG>(src, C);
+        if (shape == kPair)       stage_window<CG, false, kPair>(plane, plane, rsrc, C, W, tid);
+        else if (shape == kFrame) stage_window<CG, false, kFrame>(plane, plane, rsrc, C, W, tid);
+        else                      stage_window<CG, false, kDword>(plane, plane, rsrc, C, W, tid);
+    }
+    __syncthreads();
+
+    float2 accE[CG][R], accO[CG][R];
+    float edge[CG];                       // odd-tap part of the tile's last output (frame T-1)
+    const int lane = tid & 63;
+    const int lane_base = 2 * tid;
+
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
+        const int ch = c0 + c;
+        const float *pc = plane + c * W;
+        const float *pa = pc + lane_base;
+        edge[c] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < R; ++j) { accE[c][j] = make_float2(0.0f, 0.0f); accO[c][j] = make_float2(0.0f, 0.0f); }
+        if (a.chan_flags != nullptr && (a.chan_flags[ch] & 1)) {       // unfiltered: copy through
+#pragma unroll
+            for (int j = 0; j < R; ++j) accE[c][j] = *(const float2 *)(pa + 2 * kThreads * j);
+            continue;
+        }
+        const int k_last = a.tap_off[ch + 1];
+        for (int chunk = a.tap_off[ch]; chunk < k_last; chunk += 64) {
+            const int kk = chunk + lane;
+            const bool live = kk < k_last;
+            Tap t;
+            t.idx = 0; t.w = 0.0f;
+            if (live) t = a.taps_flat[kk];
+            const bool odd = (t.idx & 1) != 0;
+            const unsigned long long even_mask = __ballot(live && !odd);
+            const unsigned long long odd_mask = __ballot(live && odd);
+            run_tap_list<R>(even_mask, lds_addr(pa), t.idx, t.w, accE[c]);
+            run_tap_list<R>(odd_mask, lds_addr(pa), t.idx, t.w, accO[c]);
+            // frame T-1 pairs with frame T, which no lane owns: reduce its odd taps here
+            float part = (live && odd) ? pc[T - 1 + t.idx] * t.w : 0.0f;
+#pragma unroll
+            for (int sh = 32; sh > 0; sh >>= 1) part += __shfl_xor(part, sh);
+            edge[c] += part;
+        }
+    }
+
+    // ---- merge the two accumulator sets: neighbour's accO.x through LDS -----------
+    __syncthreads();                                   // every wave is done reading the planes
+    float *xo = lds;                                   // [CG][T/2 + 1], reuses the window
+    constexpr int XS = T / 2 + 1;
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) xo[c * XS + tid + kThreads * j] = accO[c][j].x;
+        if (tid == kThreads - 1) xo[c * XS + T / 2] = edge[c];
+    }
+    __syncthreads();
+
+    {
+        float *dst = ys + t0 * C + c0;
+        const v4i rdst = make_rsrc(dst, ((a.n - t0) * C - c0) * 4);
+        const int shape = access_shape<CG>(dst, C);
+        const int strideG = C / CG;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int q = tid + kThreads * j;
+            float v[2 * CG];
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {
+                v[c] = accE[c][j].x + accO[c][j].y;
+                v[CG + c] = accE[c][j].y + xo[c * XS + q + 1];
+            }
             if (shape == kPair)       store_pair<CG, kPair>(rdst, q, strideG, C, v);
             else if (shape == kFrame) store_pair<CG, kFrame>(rdst, q, strideG, C, v);
             else                      store_pair<CG, kDword>(rdst, q, strideG, C, v);

@@ -58,13 +58,14 @@ DEFAULT_SEGMENT_ENVELOPE = (0.85, 0.55, 0.35, 0.2)
 # for float32 inputs; FMA is the single-rounding variant (<= 1e-6 of peak).
 MODE_EXACT = _native.MODE_EXACT
 MODE_FMA = _native.MODE_FMA
+MODE_FAST = _native.MODE_FAST
 _default_mode = MODE_EXACT
 
 
 def set_default_mode(mode: int) -> None:
     """Choose the arithmetic of subsequent host-API calls (MODE_EXACT / MODE_FMA)."""
     global _default_mode
-    if mode not in (MODE_EXACT, MODE_FMA):
+    if mode not in (MODE_EXACT, MODE_FMA, MODE_FAST):
         raise ValueError(f'unknown mode {mode}')
     _default_mode = mode
 
