@@ -58,7 +58,9 @@ struct vnd_taps {
     std::vector<float> w, seg_gain;
     std::vector<uint8_t> flags;
     // device image
-    Tap *d_taps = nullptr, *d_taps_flat = nullptr;
+    Tap *d_taps = nullptr;
+    FastTap *d_taps_fast = nullptr;
+    int32_t *d_fast_off = nullptr, *d_fast_even = nullptr;
     int32_t *d_tap_off = nullptr, *d_seg_off = nullptr, *d_seg_end = nullptr;
     float *d_seg_gain = nullptr;
     uint8_t *d_flags = nullptr;
@@ -212,7 +214,7 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
     if (batch == 0 || n == 0) return VND_OK;
     const Plan p = make_plan(ctx, t, batch, n, C, mode);
     KArgs a{};
-    a.x = x; a.y = y; a.taps = t->d_taps; a.taps_flat = t->d_taps_flat; a.tap_off = t->d_tap_off;
+    a.x = x; a.y = y; a.taps = t->d_taps; a.taps_fast = t->d_taps_fast; a.fast_off = t->d_fast_off; a.fast_even = t->d_fast_even; a.tap_off = t->d_tap_off;
     a.seg_off = t->has_seg ? t->d_seg_off : nullptr;
     a.seg_end = t->d_seg_end; a.seg_gain = t->d_seg_gain;
     a.chan_flags = t->has_flags ? t->d_flags : nullptr;
@@ -240,7 +242,9 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
 static void free_taps_dev(vnd_taps *t)
 {
     if (t->d_taps) (void)hipFree(t->d_taps);
-    if (t->d_taps_flat) (void)hipFree(t->d_taps_flat);
+    if (t->d_taps_fast) (void)hipFree(t->d_taps_fast);
+    if (t->d_fast_off) (void)hipFree(t->d_fast_off);
+    if (t->d_fast_even) (void)hipFree(t->d_fast_even);
     if (t->d_tap_off) (void)hipFree(t->d_tap_off);
     if (t->d_seg_off) (void)hipFree(t->d_seg_off);
     if (t->d_seg_end) (void)hipFree(t->d_seg_end);
@@ -388,14 +392,32 @@ vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, 
     for (int32_t k = 0; k < total; ++k) { packed[k].idx = tap_index[k]; packed[k].w = tap_weight[k]; }
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = upload(&t->d_taps, packed.data(), (size_t)total);
-    if (has_seg && t->apply_gain) {            // fast mode: gain folded into each weight
+    // fast-mode image: per channel the even-offset taps, then the odd-offset ones;
+    // idx <- LDS byte offset (i & ~1) * 4, w <- weight * segment gain; 16 zero records of
+    // padding so that a 16-record scalar fetch never leaves the array
+    std::vector<FastTap> fast;
+    std::vector<int32_t> fast_off(C + 1, 0), fast_even(C, 0);
+    {
+        std::vector<float> eff(tap_weight, tap_weight + total);
+        if (has_seg && t->apply_gain)
+            for (int c = 0; c < C; ++c) {
+                int32_t k = tap_offsets[c];
+                for (int32_t sgi = seg_offsets[c]; sgi < seg_offsets[c + 1]; ++sgi)
+                    for (; k < seg_end[sgi]; ++k) eff[k] = tap_weight[k] * seg_gain[sgi];
+            }
         for (int c = 0; c < C; ++c) {
-            int32_t k = tap_offsets[c];
-            for (int32_t sgi = seg_offsets[c]; sgi < seg_offsets[c + 1]; ++sgi)
-                for (; k < seg_end[sgi]; ++k) packed[k].w = tap_weight[k] * seg_gain[sgi];
+            for (int parity = 0; parity < 2; ++parity) {
+                for (int32_t k = tap_offsets[c]; k < tap_offsets[c + 1]; ++k)
+                    if ((tap_index[k] & 1) == parity) fast.push_back(FastTap{eff[k], (tap_index[k] & ~1) * 4});
+                if (parity == 0) fast_even[c] = (int32_t)fast.size() - fast_off[c];
+            }
+            fast_off[c + 1] = (int32_t)fast.size();
         }
+        fast.resize(fast.size() + 16, FastTap{0.0f, 0});
     }
-    if (e == hipSuccess) e = upload(&t->d_taps_flat, packed.data(), (size_t)total);
+    if (e == hipSuccess) e = upload(&t->d_taps_fast, fast.data(), fast.size());
+    if (e == hipSuccess) e = upload(&t->d_fast_off, fast_off.data(), fast_off.size());
+    if (e == hipSuccess) e = upload(&t->d_fast_even, fast_even.data(), fast_even.size());
     if (e == hipSuccess) e = upload(&t->d_tap_off, t->tap_off.data(), t->tap_off.size());
     if (e == hipSuccess && has_seg) e = upload(&t->d_seg_off, t->seg_off.data(), t->seg_off.size());
     if (e == hipSuccess && has_seg) e = upload(&t->d_seg_end, t->seg_end.data(), t->seg_end.size());

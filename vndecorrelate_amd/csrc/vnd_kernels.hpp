@@ -47,11 +47,22 @@ struct Tap {          // 8-byte record -> one s_load_dwordx2 per tap
     float w;
 };
 
+// Fast-mode record.  The weight comes FIRST: records are fetched into SGPR pairs
+// and hipcc feeds v_pk_fma_f32 the LOW half of an even-aligned pair as the
+// splatted scalar operand; with the weight in the odd register (ROCm 7.2) it
+// still encodes the low half and multiplies by the offset bits instead.
+struct FastTap {
+    float w;          // weight * segment gain
+    int32_t off;      // LDS byte offset (i & ~1) * 4
+};
+
 struct KArgs {
     const float *__restrict__ x;
     float *__restrict__ y;
     const Tap *__restrict__ taps;
-    const Tap *__restrict__ taps_flat;      // same taps, segment gain folded into the weight
+    const FastTap *__restrict__ taps_fast;  // fast mode: per channel [even taps | odd taps], zero-padded
+    const int32_t *__restrict__ fast_off;   // [C+1] start of each channel's list in taps_fast
+    const int32_t *__restrict__ fast_even;  // [C]   number of even-offset taps (the odd ones follow)
     const int32_t *__restrict__ tap_off;    // [C+1]
     const int32_t *__restrict__ seg_off;    // [C+1] or nullptr (function-path table)
     const int32_t *__restrict__ seg_end;    // exclusive ends, absolute tap positions
@@ -110,6 +121,10 @@ __device__ v4f buf_load4(v4i rsrc, int voff, int soff, int aux) __asm("llvm.amdg
 __device__ void buf_store1(float d, v4i rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
 __device__ void buf_store2(v2f d, v4i rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
 __device__ void buf_store4(v4f d, v4i rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+// Scalar (SMEM) fetch of 16 dwords through a descriptor: wave-uniform table data
+// straight into SGPRs, whatever the compiler can or cannot prove about aliasing.
+typedef int v16i __attribute__((ext_vector_type(16)));
+__device__ v16i sbuf_load16(v4i rsrc, int byte_off, int aux) __asm("llvm.amdgcn.s.buffer.load.v16i32");
 
 // Descriptor of a raw (stride 0) buffer: base, num_records in BYTES, gfx9 dword format.
 // Built from kernel arguments and blockIdx only, so it lives in SGPRs.
@@ -425,8 +440,8 @@ __global__ __launch_bounds__(kThreads) void conv_lds_kernel(const KArgs a)
 // the tile's very last output has no lane; one wave reduces it from the tap
 // chunk it already holds in registers.
 //
-// Even and odd taps are walked as two bit masks (s_ff1 on a ballot), each loop
-// software-pipelined: the reads of tap k+1 are in flight while tap k is consumed.
+// The host splits each channel's taps into an even and an odd list
+// (vnd_taps_create); each list is walked by run_tap_array below.
 // The LDS reads of the tap loops are inline asm so that (a) each stays a plain
 // ds_read_b64 with an immediate offset and (b) the waits are counted by hand:
 // hipcc's own bookkeeping drains the queue at the loop header (WAW on recycled
@@ -477,46 +492,89 @@ __device__ __forceinline__ void consume(float2 (&acc)[R], const v2f (&buf)[R], f
     }
 }
 
-// Walk the taps whose bits are set in `mask` (lane l of tv_idx/tv_w holds tap l).
-// Four taps per trip in straight-line code: reads of the next tap are always in
-// flight while a tap is consumed, and no half-landed register crosses a loop edge
-// (a loop-carried buffer would make hipcc copy registers whose LDS data has not
-// arrived).  The last (count mod 4) taps go one by one.
+// One list of taps (all even or all odd offsets) into one accumulator set.
+// The list is wave-uniform, so it is fetched with scalar loads, 16 records at a
+// time, and lives in SGPRs: per tap the vector pipe issues ONE v_add (address =
+// lane base + scalar byte offset) plus the R packed FMAs - profiling showed the
+// kernel bound by instruction issue (VALU ~70 % busy, SALU ~55 %) when each tap
+// also cost two v_readlane and a find-first-bit walk over a ballot mask.
+// Four taps per group in straight-line code: the reads of the next tap are in
+// flight while a tap is consumed, and no half-landed register crosses a branch.
 template <int R>
-__device__ __forceinline__ void run_tap_list(unsigned long long mask, unsigned base, int tv_idx,
-                                             float tv_w, float2 (&acc)[R])
+__device__ __forceinline__ void tap_group4(const FastTap (&t)[16], int g, unsigned lane_addr, float2 (&acc)[R])
+{
+    v2f b0[R], b1[R], b2[R], b3[R];
+    issue_reads<R>(b0, lane_addr + (unsigned)t[4 * g + 0].off);
+    issue_reads<R>(b1, lane_addr + (unsigned)t[4 * g + 1].off);
+    wait_reads<R, R>(b0);          // only b1's R reads may still be outstanding
+    consume<R>(acc, b0, t[4 * g + 0].w);
+    issue_reads<R>(b2, lane_addr + (unsigned)t[4 * g + 2].off);
+    wait_reads<R, R>(b1);
+    consume<R>(acc, b1, t[4 * g + 1].w);
+    issue_reads<R>(b3, lane_addr + (unsigned)t[4 * g + 3].off);
+    wait_reads<R, R>(b2);
+    consume<R>(acc, b2, t[4 * g + 2].w);
+    wait_reads<0, R>(b3);
+    consume<R>(acc, b3, t[4 * g + 3].w);
+}
+
+template <int R>
+__device__ __forceinline__ void tap_single(const FastTap &t, unsigned lane_addr, float2 (&acc)[R])
+{
+    v2f b0[R];
+    issue_reads<R>(b0, lane_addr + (unsigned)t.off);
+    wait_reads<0, R>(b0);
+    consume<R>(acc, b0, t.w);
+}
+
+// 16 records into 16 SGPR pairs with one burst of scalar loads.  Inline asm on
+// purpose: (w, off) of a record then sit in ONE even-aligned pair, which is the
+// only scalar operand shape hipcc (ROCm 7.2) encodes correctly for the splatted
+// weight of v_pk_fma_f32 - fed from sub-registers of a wider s_buffer_load tuple
+// it multiplies every tap by the tuple's first dword.  Loads and their wait live
+// in one statement (guide 5.7 form i), outputs early-clobber.
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void load_taps16(const FastTap *ptr, FastTap (&t)[16])
+{
+    v2i r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;
+    asm volatile(
+        "s_load_dwordx2 %0, %16, 0x0\n\ts_load_dwordx2 %1, %16, 0x8\n\t"
+        "s_load_dwordx2 %2, %16, 0x10\n\ts_load_dwordx2 %3, %16, 0x18\n\t"
+        "s_load_dwordx2 %4, %16, 0x20\n\ts_load_dwordx2 %5, %16, 0x28\n\t"
+        "s_load_dwordx2 %6, %16, 0x30\n\ts_load_dwordx2 %7, %16, 0x38\n\t"
+        "s_load_dwordx2 %8, %16, 0x40\n\ts_load_dwordx2 %9, %16, 0x48\n\t"
+        "s_load_dwordx2 %10, %16, 0x50\n\ts_load_dwordx2 %11, %16, 0x58\n\t"
+        "s_load_dwordx2 %12, %16, 0x60\n\ts_load_dwordx2 %13, %16, 0x68\n\t"
+        "s_load_dwordx2 %14, %16, 0x70\n\ts_load_dwordx2 %15, %16, 0x78\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(r0), "=&s"(r1), "=&s"(r2), "=&s"(r3), "=&s"(r4), "=&s"(r5), "=&s"(r6), "=&s"(r7),
+          "=&s"(r8), "=&s"(r9), "=&s"(r10), "=&s"(r11), "=&s"(r12), "=&s"(r13), "=&s"(r14), "=&s"(r15)
+        : "s"(ptr));
+    const v2i r[16] = {r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { t[i].w = __builtin_bit_cast(float, r[i].x); t[i].off = r[i].y; }
+}
+
+template <int R>
+__device__ __forceinline__ void run_tap_array(const FastTap *__restrict__ tp, int n, unsigned lane_addr,
+                                              float2 (&acc)[R])
 {
     static_assert(R <= 15, "lgkmcnt(R) must fit the 4-bit counter field");
-    int left = __builtin_popcountll(mask);
-    auto next = [&](v2f (&buf)[R], float &w) {
-        const int k = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        const int idx = __builtin_amdgcn_readlane(tv_idx, k);
-        w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tv_w), k));
-        issue_reads<R>(buf, base + 4u * (unsigned)(idx & ~1));
-    };
-    for (; left >= 4; left -= 4) {
-        v2f b0[R], b1[R], b2[R], b3[R];
-        float w0, w1, w2, w3;
-        next(b0, w0);
-        next(b1, w1);
-        wait_reads<R, R>(b0);      // b1's R reads are the only ones allowed outstanding
-        consume<R>(acc, b0, w0);
-        next(b2, w2);
-        wait_reads<R, R>(b1);
-        consume<R>(acc, b1, w1);
-        next(b3, w3);
-        wait_reads<R, R>(b2);
-        consume<R>(acc, b2, w2);
-        wait_reads<0, R>(b3);
-        consume<R>(acc, b3, w3);
-    }
-    for (; left > 0; --left) {
-        v2f b0[R];
-        float w0;
-        next(b0, w0);
-        wait_reads<0, R>(b0);
-        consume<R>(acc, b0, w0);
+    for (int k0 = 0; k0 < n; k0 += 16) {
+        FastTap t[16];
+        load_taps16(tp + k0, t);                 // the table is zero-padded by 16 records
+        const int m = n - k0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (4 * g + 4 <= m) {
+                tap_group4<R>(t, g, lane_addr, acc);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (4 * g + i < m) tap_single<R>(t[4 * g + i], lane_addr, acc);
+            }
+        }
     }
 }
 
@@ -569,24 +627,23 @@ __global__ __launch_bounds__(kThreads) void conv_fast_kernel(const KArgs a)
             for (int j = 0; j < R; ++j) accE[c][j] = *(const float2 *)(pa + 2 * kThreads * j);
             continue;
         }
-        const int k_last = a.tap_off[ch + 1];
-        for (int chunk = a.tap_off[ch]; chunk < k_last; chunk += 64) {
-            const int kk = chunk + lane;
-            const bool live = kk < k_last;
-            Tap t;
-            t.idx = 0; t.w = 0.0f;
-            if (live) t = a.taps_flat[kk];
-            const bool odd = (t.idx & 1) != 0;
-            const unsigned long long even_mask = __ballot(live && !odd);
-            const unsigned long long odd_mask = __ballot(live && odd);
-            run_tap_list<R>(even_mask, lds_addr(pa), t.idx, t.w, accE[c]);
-            run_tap_list<R>(odd_mask, lds_addr(pa), t.idx, t.w, accO[c]);
-            // frame T-1 pairs with frame T, which no lane owns: reduce its odd taps here
-            float part = (live && odd) ? pc[T - 1 + t.idx] * t.w : 0.0f;
-#pragma unroll
-            for (int sh = 32; sh > 0; sh >>= 1) part += __shfl_xor(part, sh);
-            edge[c] += part;
+        const int first = __builtin_amdgcn_readfirstlane(a.fast_off[ch]);
+        const FastTap *__restrict__ tp = a.taps_fast + first;
+        const int n_all = __builtin_amdgcn_readfirstlane(a.fast_off[ch + 1]) - first;
+        const int n_even = __builtin_amdgcn_readfirstlane(a.fast_even[ch]);
+        const int n_odd = n_all - n_even;
+        run_tap_array<R>(tp, n_even, lds_addr(pa), accE[c]);
+        run_tap_array<R>(tp + n_even, n_odd, lds_addr(pa), accO[c]);
+        // frame T-1 pairs with frame T, which no lane owns: its odd taps, x[T-1+i] = plane[T + (i-1)],
+        // are reduced across the wave (lane l takes odd tap l, l+64, ...)
+        float part = 0.0f;
+        for (int k = lane; k < n_odd; k += 64) {
+            const FastTap t = tp[n_even + k];
+            part = __builtin_fmaf(pc[T + (t.off >> 2)], t.w, part);
         }
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) part += __shfl_xor(part, sh);
+        edge[c] = part;
     }
 
     // ---- merge the two accumulator sets: neighbour's accO.x through LDS -----------
