@@ -1,0 +1,76 @@
+"""CPU tier: the C-ABI shared library builds, loads, and exports exactly what
+include/vnd_amd.h declares.  No compute calls (there is no GPU here)."""
+import ctypes
+import pathlib
+import re
+import subprocess
+
+import pytest
+
+REPO = pathlib.Path(__file__).resolve().parents[1]
+HEADER = REPO / 'include' / 'vnd_amd.h'
+
+
+@pytest.fixture(scope='module')
+def lib():
+    import __graft_entry__ as entry
+    entry.build()
+    from vndecorrelate_amd import _native
+    return _native.load_library()
+
+
+def declared_functions():
+    text = re.sub(r'/\*.*?\*/', '', HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r'\b(vnd_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_is_plain_c():
+    """The boundary must be consumable by cgo/JNI/ctypes: compile it as C."""
+    src = '#include "vnd_amd.h"\nint main(void){return VND_ABI_VERSION == vnd_abi_version() ? 0 : 1;}\n'
+    r = subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-fsyntax-only', '-I', str(REPO / 'include'),
+                        '-x', 'c', '-'], input=src.encode(), capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    assert 'torch' not in HEADER.read_text().lower().replace('(hipmalloc / torch)', '')
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from vndecorrelate_amd import _native
+    names = declared_functions()
+    assert len(names) >= 15
+    for name in names:
+        assert hasattr(lib, name), f'{name} declared in vnd_amd.h but not exported'
+    # and the Python binding covers the whole header, nothing more
+    assert sorted(_native.SIGNATURES) == names
+
+
+def test_abi_version_and_error_channel(lib):
+    assert lib.vnd_abi_version() == 1
+    assert isinstance(lib.vnd_last_error(), bytes)
+    n = ctypes.c_int32(-1)
+    rc = lib.vnd_device_count(ctypes.byref(n))
+    assert rc in (0, 2) and n.value >= 0
+
+
+def test_no_cpu_fallback_without_device(lib):
+    """On a box without a GPU the product path fails loudly (and says why)."""
+    from vndecorrelate_amd import _native
+    if _native.device_count() > 0:
+        pytest.skip('a GPU is present')
+    with pytest.raises(_native.NativeError) as e:
+        _native.Context(0)
+    assert 'gfx950' in str(e.value) or 'HIP device' in str(e.value)
+    import numpy as np
+    import vndecorrelate_amd.decorrelation as vnd
+    fir = vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, seed=1)
+    with pytest.raises(RuntimeError):
+        vnd.convolve_velvet_noise(np.zeros((100, 2), np.float32), fir)
+    with pytest.raises(RuntimeError):
+        vnd.VelvetNoise(sample_rate_hz=44100, seed=1).decorrelate(np.zeros((100, 2), np.float32))
+
+
+def test_product_never_imports_the_oracle():
+    for path in (REPO / 'vndecorrelate_amd').rglob('*.py'):
+        text = path.read_text()
+        assert 'oracle' not in text.replace('the oracle', '').replace('oracle/', ''), path
+    for path in (REPO / 'vndecorrelate_amd' / 'csrc').iterdir():
+        assert 'oracle' not in path.read_text(), path

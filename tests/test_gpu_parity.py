@@ -314,3 +314,19 @@ def test_misaligned_device_pointers(vnd, golden, channels, gname):
                 assert np.all(got[:shift] == 7.0) and np.all(got[shift + x.size:] == 7.0), (cg, shift)
     finally:
         ctx.set_variant(-1)
+
+
+def test_python_and_c_table_images_agree(vnd, golden):
+    """The image that travels between ranks is built in Python on rank 0 and
+    consumed by vnd_taps_deserialize: both sides must produce the same bytes."""
+    from vndecorrelate_amd import _native
+    from vndecorrelate_amd.taps import TapArrays, function_path_arrays
+    ctx = _native.default_context()
+    fn = function_path_arrays(golden.fir('g96k_k64_c8'))
+    t = _native.TapTable.create(ctx, fn.tap_offsets, fn.tap_index, fn.tap_weight)
+    assert t.to_bytes() == fn.to_bytes()
+    cls = vnd.VelvetNoise(sample_rate_hz=44100, seed=1, filtered_channels=(0,), mode='LR')._tap_arrays()
+    t = _native.TapTable.create(ctx, cls.tap_offsets, cls.tap_index, cls.tap_weight, **cls.kwargs())
+    assert t.to_bytes() == cls.to_bytes()
+    back = TapArrays.from_bytes(t.to_bytes())
+    assert np.array_equal(back.seg_end, cls.seg_end) and back.apply_gain == cls.apply_gain

@@ -21,13 +21,13 @@ CONFIGS = {   # fs, fir seconds, taps, kappa, frames, channels, pool
 }
 
 
-def variant(r_log2=None, dual=None, cg=0, direct=False):
+def variant(r_log2=None, dual=None, cg=0, direct=False, nt=0):
     v = 0
     if r_log2 is not None:
         v |= r_log2 + 1
     if dual is not None:
         v |= (1 << 5) | (int(dual) << 4)
-    return v | (cg << 8) | (int(direct) << 12)
+    return v | (cg << 8) | (int(direct) << 12) | ({0: 0, 256: 1, 512: 2, 1024: 3}[nt] << 16)
 
 
 def main():
@@ -39,6 +39,7 @@ def main():
     ap.add_argument('--rs', default='1,2,3,4')
     ap.add_argument('--modes', default='0,1,2')
     ap.add_argument('--direct', action='store_true')
+    ap.add_argument('--nts', default='256')
     args = ap.parse_args()
     import torch
     import vndecorrelate_amd.decorrelation as vnd
@@ -63,14 +64,15 @@ def main():
                 for dual in ((0,) if mode == 2 else (0, 1)):
                     if mode == 2 and r > 3:
                         continue
-                    cases.append((mode, cg, r, dual, False))
+                    for nt in ([int(v) for v in args.nts.split(',')] if mode == 2 else [0]):
+                        cases.append((mode, cg, r, dual, False, nt))
         if args.direct:
-            cases.append((mode, 0, None, None, True))
+            cases.append((mode, 0, None, None, True, 0))
     results = {c: [] for c in cases}
     for rnd in range(args.rounds + 1):
         for c in cases:
-            mode, cg, r, dual, direct = c
-            ctx.set_variant(variant(r, dual, cg, direct))
+            mode, cg, r, dual, direct, nt = c
+            ctx.set_variant(variant(r, dual, cg, direct, nt))
             iters = 2 if direct else args.iters
             ms = table.time_device(x.data_ptr(), y.data_ptr(), pool, n, ch, mode=mode, n_buffers=1,
                                    stride_elems=0, iters=iters, stream=stream)
@@ -79,8 +81,8 @@ def main():
     print(f'# {args.config}: pool={pool} n={n} C={ch} taps={taps} algorithmic bytes/launch={nbytes/1e6:.1f} MB')
     print('mode cg pairs dual direct   med_ms   min_ms   GB/s(med)  frac_of_8TB/s  launch')
     for c in cases:
-        mode, cg, r, dual, direct = c
-        ctx.set_variant(variant(r, dual, cg, direct))
+        mode, cg, r, dual, direct, nt = c
+        ctx.set_variant(variant(r, dual, cg, direct, nt))
         desc = table.describe(pool, n, ch, mode)
         med, mn = float(np.median(results[c])), float(np.min(results[c]))
         gbs = nbytes / med / 1e6

@@ -71,7 +71,7 @@ struct vnd_taps {
 // ------------------------------------------------------------------------------
 struct Plan {
     bool direct = false;
-    int cg = 1, r_log2 = 0, dual = 0;
+    int nt = 256, cg = 1, r_log2 = 0, dual = 0;
     int W = 0;
     size_t lds_bytes = 0;
     uint32_t nblocks = 0;
@@ -80,114 +80,131 @@ struct Plan {
 
 typedef void (*kern_t)(const KArgs);
 
-template <int CG, int R, int MODE, bool DUAL>
-static kern_t kptr() { return conv_lds_kernel<CG, R, MODE, DUAL>; }
+constexpr int kOrderedThreads = 256;
 
 template <int CG, int MODE, bool DUAL>
-static kern_t by_r(int r_log2)
+static kern_t ordered_by_r(int r_log2)
 {
     switch (r_log2) {
-    case 0: return kptr<CG, 1, MODE, DUAL>();
-    case 1: return kptr<CG, 2, MODE, DUAL>();
-    case 2: return kptr<CG, 4, MODE, DUAL>();
-    case 3: return kptr<CG, 8, MODE, DUAL>();
-    default: return kptr<CG, 16, MODE, DUAL>();
+    case 0: return conv_ordered_kernel<kOrderedThreads, CG, 1, MODE, DUAL>;
+    case 1: return conv_ordered_kernel<kOrderedThreads, CG, 2, MODE, DUAL>;
+    case 2: return conv_ordered_kernel<kOrderedThreads, CG, 4, MODE, DUAL>;
+    case 3: return conv_ordered_kernel<kOrderedThreads, CG, 8, MODE, DUAL>;
+    default: return conv_ordered_kernel<kOrderedThreads, CG, 16, MODE, DUAL>;
     }
 }
 
 template <int CG>
-static kern_t by_mode(int r_log2, int mode, int dual)
+static kern_t ordered_by_mode(int r_log2, int mode, int dual)
 {
     if (mode == VND_MODE_EXACT)
-        return dual ? by_r<CG, 0, true>(r_log2) : by_r<CG, 0, false>(r_log2);
-    return dual ? by_r<CG, 1, true>(r_log2) : by_r<CG, 1, false>(r_log2);
+        return dual ? ordered_by_r<CG, 0, true>(r_log2) : ordered_by_r<CG, 0, false>(r_log2);
+    return dual ? ordered_by_r<CG, 1, true>(r_log2) : ordered_by_r<CG, 1, false>(r_log2);
 }
 
-static kern_t lds_kernel(int cg, int r_log2, int mode, int dual)
+static kern_t ordered_kernel(int cg, int r_log2, int mode, int dual)
 {
     switch (cg) {
-    case 1: return by_mode<1>(r_log2, mode, dual);
-    case 2: return by_mode<2>(r_log2, mode, dual);
-    default: return by_mode<4>(r_log2, mode, dual);
+    case 1: return ordered_by_mode<1>(r_log2, mode, dual);
+    case 2: return ordered_by_mode<2>(r_log2, mode, dual);
+    default: return ordered_by_mode<4>(r_log2, mode, dual);
     }
 }
 
-template <int CG>
+template <int NT, int CG>
 static kern_t fast_by_r(int r_log2)
 {
     switch (r_log2) {
-    case 0: return conv_fast_kernel<CG, 1>;
-    case 1: return conv_fast_kernel<CG, 2>;
-    case 2: return conv_fast_kernel<CG, 4>;
-    default: return conv_fast_kernel<CG, 8>;
+    case 0: return conv_fast_kernel<NT, CG, 1>;
+    case 1: return conv_fast_kernel<NT, CG, 2>;
+    case 2: return conv_fast_kernel<NT, CG, 4>;
+    default: return conv_fast_kernel<NT, CG, 8>;
     }
 }
 
-static kern_t fast_kernel(int cg, int r_log2)
+template <int NT>
+static kern_t fast_by_cg(int cg, int r_log2)
 {
     switch (cg) {
-    case 1: return fast_by_r<1>(r_log2);
-    case 2: return fast_by_r<2>(r_log2);
-    default: return fast_by_r<4>(r_log2);
+    case 1: return fast_by_r<NT, 1>(r_log2);
+    case 2: return fast_by_r<NT, 2>(r_log2);
+    default: return fast_by_r<NT, 4>(r_log2);
+    }
+}
+
+static kern_t fast_kernel(int nt, int cg, int r_log2)
+{
+    switch (nt) {
+    case 256: return fast_by_cg<256>(cg, r_log2);
+    case 512: return fast_by_cg<512>(cg, r_log2);
+    default: return fast_by_cg<1024>(cg, r_log2);
     }
 }
 
 static int halo_of(int max_index) { return (max_index + 2 + 15) & ~15; }
 
-static size_t lds_need(int cg, int r_log2, int dual, int max_index)
+static size_t lds_need(int nt, int cg, int r_log2, int dual, int max_index)
 {
-    const size_t T = (size_t)2 * kThreads << r_log2;
+    const size_t T = (size_t)2 * nt << r_log2;
     return (size_t)(dual ? 2 : 1) * cg * (T + halo_of(max_index)) * sizeof(float);
 }
 
 // variant word (vnd_set_variant): bits 0-3 r_log2+1 (0 = auto), bit 4 dual,
-// bit 5 "dual given", bits 8-11 channels per workgroup (0 = auto), bit 12 direct.
+// bit 5 "dual given", bits 8-11 channels per workgroup (0 = auto), bit 12 direct,
+// bits 16-17 threads per workgroup of the fast kernel (0 auto, 1: 256, 2: 512, 3: 1024).
 static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64_t n, int C, int mode)
 {
     Plan p;
     const int v = ctx->variant;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    const bool fast = mode == VND_MODE_FAST;
     const bool force_direct = v >= 0 && ((v >> 12) & 1);
     int cg = (v >= 0 && ((v >> 8) & 15)) ? ((v >> 8) & 15) : 0;
     if (cg == 0) cg = (C % 2 == 0) ? 2 : 1;
     if (C % cg != 0 || (cg != 1 && cg != 2 && cg != 4)) cg = 1;
     int dual = (v >= 0 && ((v >> 5) & 1)) ? ((v >> 4) & 1) : 0;
-    if (mode == VND_MODE_FAST) dual = 0;
+    if (fast) dual = 0;
     int r_log2 = (v >= 0 && (v & 15)) ? (v & 15) - 1 : -1;
+    int nt = kOrderedThreads;
+    if (fast) {
+        const int sel = v >= 0 ? ((v >> 16) & 3) : 0;
+        nt = sel == 1 ? 256 : sel == 2 ? 512 : sel == 3 ? 1024 : 256;
+    }
+    const int r_max = fast ? 3 : 4;
 
     const size_t limit = (size_t)ctx->lds_limit;
     if (r_log2 < 0) {
         // Largest tile that still gives every CU several workgroups, within an
-        // LDS budget that keeps >= 2 workgroups resident per CU.
-        const size_t budget = limit / 2;
-        r_log2 = 3;
+        // LDS budget that keeps several workgroups resident per CU.
+        const size_t budget = limit / 4;
+        r_log2 = 2;
         while (r_log2 > 0) {
-            const int64_t T = (int64_t)2 * kThreads << r_log2;
+            const int64_t T = (int64_t)2 * nt << r_log2;
             const int64_t blocks = batch * ((n + T - 1) / T) * (C / cg);
-            if (blocks >= (int64_t)cus * 6 && lds_need(cg, r_log2, dual, t->max_index) <= budget) break;
+            if (blocks >= (int64_t)cus * 6 && lds_need(nt, cg, r_log2, dual, t->max_index) <= budget) break;
             --r_log2;
         }
     }
-    if (r_log2 > 4) r_log2 = 4;
-    if (mode == VND_MODE_FAST && r_log2 > 3) r_log2 = 3;
+    if (r_log2 > r_max) r_log2 = r_max;
     // shrink until the tile fits one workgroup's LDS at all
-    while (lds_need(cg, r_log2, dual, t->max_index) > limit) {
+    while (lds_need(nt, cg, r_log2, dual, t->max_index) > limit) {
         if (dual) dual = 0;
         else if (cg > 1) cg /= 2;
         else if (r_log2 > 0) --r_log2;
+        else if (nt > 256 && fast) nt /= 2;
         else break;
     }
-    if (force_direct || lds_need(cg, r_log2, dual, t->max_index) > limit) {
+    if (force_direct || lds_need(nt, cg, r_log2, dual, t->max_index) > limit) {
         p.direct = true;
         const int64_t total = batch * n * C;
-        int64_t blocks = (total + kThreads - 1) / kThreads;
+        int64_t blocks = (total + kDirectThreads - 1) / kDirectThreads;
         p.nblocks = (uint32_t)std::min<int64_t>(std::max<int64_t>(blocks, 1), (int64_t)cus * 32);
         return p;
     }
-    const int64_t T = (int64_t)2 * kThreads << r_log2;
-    p.cg = cg; p.r_log2 = r_log2; p.dual = dual;
+    const int64_t T = (int64_t)2 * nt << r_log2;
+    p.nt = nt; p.cg = cg; p.r_log2 = r_log2; p.dual = dual;
     p.W = (int)T + halo_of(t->max_index);
-    p.lds_bytes = lds_need(cg, r_log2, dual, t->max_index);
+    p.lds_bytes = lds_need(nt, cg, r_log2, dual, t->max_index);
     p.tiles = (int)((n + T - 1) / T);
     p.groups = C / cg;
     p.nblocks = (uint32_t)(batch * p.tiles * p.groups);
@@ -224,16 +241,16 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
         a.tiles = (int32_t)batch; a.groups = 1; a.W = 0;
         kern_t k = mode == VND_MODE_EXACT ? conv_direct_kernel<0> : conv_direct_kernel<1>;
         if (mode == VND_MODE_FAST) a.taps = t->d_taps;      // direct kernel keeps the table's association
-        hipLaunchKernelGGL(k, dim3(p.nblocks), dim3(kThreads), 0, stream, a);
+        hipLaunchKernelGGL(k, dim3(p.nblocks), dim3(kDirectThreads), 0, stream, a);
     } else {
         if ((int64_t)batch * p.tiles * p.groups > 0x7fffffffLL)
             return fail(VND_ERR_UNSUPPORTED, "grid too large; split the batch");
         a.tiles = p.tiles; a.groups = p.groups; a.W = p.W;
-        kern_t k = mode == VND_MODE_FAST ? fast_kernel(p.cg, p.r_log2) : lds_kernel(p.cg, p.r_log2, mode, p.dual);
+        kern_t k = mode == VND_MODE_FAST ? fast_kernel(p.nt, p.cg, p.r_log2) : ordered_kernel(p.cg, p.r_log2, mode, p.dual);
         if (p.lds_bytes > 65536)
             HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)p.lds_bytes));
-        hipLaunchKernelGGL(k, dim3(p.nblocks), dim3(kThreads), p.lds_bytes, stream, a);
+        hipLaunchKernelGGL(k, dim3(p.nblocks), dim3(p.nt), p.lds_bytes, stream, a);
     }
     HIP_TRY(hipGetLastError());
     return VND_OK;
@@ -584,12 +601,12 @@ vnd_status vnd_describe_launch(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, i
     if (!text || len <= 0) return fail(VND_ERR_INVALID, "null text buffer");
     const Plan p = make_plan(ctx, t, batch, n, C, mode);
     if (p.direct)
-        snprintf(text, (size_t)len, "conv_direct mode=%d blocks=%u threads=%d", mode, p.nblocks, kThreads);
+        snprintf(text, (size_t)len, "conv_direct mode=%d blocks=%u threads=%d", mode, p.nblocks, kDirectThreads);
     else
         snprintf(text, (size_t)len,
                  "%s cg=%d pairs_per_lane=%d tile=%d halo=%d dual=%d mode=%d lds=%zuB blocks=%u threads=%d",
-                 mode == VND_MODE_FAST ? "conv_fast" : "conv_lds", p.cg, 1 << p.r_log2, (2 * kThreads) << p.r_log2, p.W - ((2 * kThreads) << p.r_log2), p.dual,
-                 mode, p.lds_bytes, p.nblocks, kThreads);
+                 mode == VND_MODE_FAST ? "conv_fast" : "conv_ordered", p.cg, 1 << p.r_log2, (2 * p.nt) << p.r_log2,
+                 p.W - ((2 * p.nt) << p.r_log2), p.dual, mode, p.lds_bytes, p.nblocks, p.nt);
     return VND_OK;
 }
 

@@ -6,22 +6,23 @@
 // (ckonst/VNDecorrelate src/vndecorrelate/decorrelation.py:649-658 and
 // :402-414) is, on the GPU, a *gather* with a forward halo of max(i) frames.
 // It is HBM-streaming work (8 algorithmic bytes per output sample) whose
-// on-chip cost is the K LDS reads per output, so the design is about LDS
-// bandwidth, not FLOPs - no MFMA anywhere:
+// on-chip cost is K LDS reads per output, so the design is about LDS bandwidth
+// and instruction issue, not FLOPs - no MFMA anywhere:
 //
 //   * one workgroup = one time tile of one stream (x CG channels);
-//   * the tile + halo is read once from HBM with coalesced vector loads and
-//     de-interleaved into per-channel LDS planes, so every later LDS read is a
-//     unit-stride, conflict-free access;
-//   * each lane owns PAIRS of consecutive frames: a tap is one ds_read_b64
-//     (the widest conflict-free form: 256 B/clk/CU) feeding two accumulators.
-//     Odd tap offsets would be 4-byte-misaligned b64 reads, so (DUAL) a second
-//     plane shifted by one frame keeps them aligned, or (!DUAL) two aligned
-//     reads straddle the pair;
-//   * tap (index, weight) records are wave-uniform: a wave parks 64 of them in
-//     two VGPRs and broadcasts one per step with v_readlane - no memory access
-//     of any kind for the table inside the tap loop;
-//   * outputs leave as 16-byte interleaved stores, 1 KiB per wave-instruction.
+//   * the tile + halo is read once from HBM with coalesced, range-checked buffer
+//     loads and de-interleaved into per-channel LDS planes, so every later LDS
+//     read is a unit-stride, conflict-free access;
+//   * each lane owns PAIRS of consecutive frames: a tap is one ds_read_b64 (the
+//     widest conflict-free form, 256 B/clk/CU) feeding one packed FMA;
+//   * tap records are wave-uniform and live in SGPRs;
+//   * outputs leave as 16-byte interleaved buffer stores, 1 KiB per wave-instruction.
+//
+// Two kernels share the staging and store code:
+//   conv_ordered_kernel  taps in table order with the reference's association
+//                        (VND_MODE_EXACT bit-identical, VND_MODE_FMA);
+//   conv_fast_kernel     free summation order, every tap an aligned read
+//                        (VND_MODE_FAST, the throughput mode).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,28 +30,19 @@
 
 namespace vnd {
 
-constexpr int kThreads = 256;   // 4 waves; several workgroups share a CU
-
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 
-// One aligned ds_read_b64.  The access is volatile on purpose: hipcc otherwise
-// fuses neighbouring pairs into ds_read2st64_b64 / ds_read2_b32, which move half
-// the bytes per LDS cycle of plain ds_read_b64 (MI355X LDS table: 128 vs 256 B/clk).
-__device__ __forceinline__ v2f lds_pair(const float *p)
-{
-    typedef __attribute__((address_space(3))) const volatile v2f *lds_v2f_ptr;
-    return *(lds_v2f_ptr)p;
-}
-
-struct Tap {          // 8-byte record -> one s_load_dwordx2 per tap
+struct Tap {          // ordered kernels: table order, reference association
     int32_t idx;
     float w;
 };
 
 // Fast-mode record.  The weight comes FIRST: records are fetched into SGPR pairs
 // and hipcc feeds v_pk_fma_f32 the LOW half of an even-aligned pair as the
-// splatted scalar operand; with the weight in the odd register (ROCm 7.2) it
-// still encodes the low half and multiplies by the offset bits instead.
+// splatted scalar operand.
 struct FastTap {
     float w;          // weight * segment gain
     int32_t off;      // LDS byte offset (i & ~1) * 4
@@ -80,8 +72,9 @@ struct KArgs {
 // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Map
 // them so that one XCD walks CONSECUTIVE logical tiles: a tile's halo is the
 // next tile's head, and channel groups of one tile share cache lines, so both
-// re-reads hit that XCD's L2 instead of going back to the fabric.  Bijective
-// for any grid size.  Placement only changes speed, never results.
+// re-reads hit that XCD's L2 instead of going back to the fabric (measured:
+// FETCH_SIZE equals the algorithmic read bytes).  Bijective for any grid size.
+// Placement only changes speed, never results.
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nwg)
 {
     const uint32_t q = nwg >> 3, r = nwg & 7u, xcd = b & 7u;
@@ -89,42 +82,40 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nwg)
     return start + (b >> 3);
 }
 
-template <int MODE>
-__device__ __forceinline__ float tap_op(float acc, float v, float w)
+struct BlockCoord {
+    int group, tile;
+    int64_t stream;
+};
+
+__device__ __forceinline__ BlockCoord decode_block(const KArgs &a)
 {
-    if constexpr (MODE == 0) {
-        float p = v * w;          // file is built with -ffp-contract=off: two roundings,
-        return acc + p;           // exactly NumPy's  out += x * w
-    } else {
-        return __builtin_fmaf(v, w, acc);
-    }
+    uint32_t lid = xcd_remap(blockIdx.x, a.nblocks);
+    BlockCoord bc;
+    bc.group = lid % (uint32_t)a.groups;
+    lid /= (uint32_t)a.groups;
+    bc.tile = lid % (uint32_t)a.tiles;
+    bc.stream = lid / (uint32_t)a.tiles;
+    return bc;
 }
 
-
-// ---- staging: HBM -> registers -> per-channel LDS planes ------------------------
+// ---- global memory: raw buffer descriptors ---------------------------------------
 // All global traffic goes through raw buffer descriptors whose num_records is
 // the number of bytes left in the stream from the tile start.  The hardware
 // range check is per dword for dword/x2/x4 accesses: loads past the end of the
 // stream return 0 - exactly the reference's "term drops out when n + i >= N"
-// (decorrelation.py:656-658, adding 0.0f is exact) - and stores past the end are
+// (decorrelation.py:656-658; adding 0.0f is exact) - and stores past the end are
 // discarded, so neither the halo of a stream's last tiles nor a ragged final
 // pair needs a branch, and no access can leave the stream's allocation.
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-// Raw-buffer intrinsics bound by name.  (The clang builtin
+//
+// The intrinsics are bound by name: the clang builtin
 // __builtin_amdgcn_raw_buffer_load_b64 of ROCm 7.2 lowers to a 32-bit load and
-// splats it, so the 64-bit forms are declared here directly.)
+// splats it.
 __device__ float buf_load1(v4i rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 __device__ v2f buf_load2(v4i rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
 __device__ v4f buf_load4(v4i rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ void buf_store1(float d, v4i rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
 __device__ void buf_store2(v2f d, v4i rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
 __device__ void buf_store4(v4f d, v4i rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
-// Scalar (SMEM) fetch of 16 dwords through a descriptor: wave-uniform table data
-// straight into SGPRs, whatever the compiler can or cannot prove about aliasing.
-typedef int v16i __attribute__((ext_vector_type(16)));
-__device__ v16i sbuf_load16(v4i rsrc, int byte_off, int aux) __asm("llvm.amdgcn.s.buffer.load.v16i32");
 
 // Descriptor of a raw (stride 0) buffer: base, num_records in BYTES, gfx9 dword format.
 // Built from kernel arguments and blockIdx only, so it lives in SGPRs.
@@ -147,11 +138,16 @@ __device__ __forceinline__ v4i make_rsrc(const void *base, int64_t bytes)
 //   kDword  dword accesses, any alignment, any channel stride
 // Byte offsets are written as  index * constant  so that hipcc can prove the
 // natural alignment and keeps the wide buffer_load/store_dwordx2/x4 forms.
-// kStageDepth independent loads are issued before the first LDS write, so every
-// wave keeps several KiB in flight; with one load per lane and iteration the
-// kernel is bound by HBM latency, not bandwidth.
 enum { kPair = 0, kFrame = 1, kDword = 2 };
-constexpr int kStageDepth = 4;
+
+template <int CG>
+__device__ __forceinline__ int access_shape(const void *base, int C)
+{
+    const uintptr_t p = (uintptr_t)base;
+    if (C == CG && (p & (8 * CG - 1)) == 0) return kPair;
+    if ((p & (4 * CG - 1)) == 0) return kFrame;      // C % CG == 0 by construction
+    return kDword;
+}
 
 // strideG = C / CG  (frame stride in units of CG floats);  q = pair index in the window
 template <int CG, int SHAPE>
@@ -239,14 +235,11 @@ __device__ __forceinline__ void store_pair(v4i rdst, int q, int strideG, int C, 
     }
 }
 
-template <int CG>
-__device__ __forceinline__ int access_shape(const void *base, int C)
-{
-    const uintptr_t p = (uintptr_t)base;
-    if (C == CG && (p & (8 * CG - 1)) == 0) return kPair;
-    if ((p & (4 * CG - 1)) == 0) return kFrame;      // C % CG == 0 by construction
-    return kDword;
-}
+// ---- staging: HBM -> registers -> per-channel LDS planes ------------------------
+// kStageDepth independent loads are issued before the first LDS write, so every
+// wave keeps several KiB in flight; with one load per lane and iteration the
+// kernel is bound by HBM latency, not bandwidth.
+constexpr int kStageDepth = 4;
 
 template <int CG, bool DUAL>
 __device__ __forceinline__ void write_pair(float *planeA, float *planeB, int W, int f,
@@ -263,20 +256,19 @@ __device__ __forceinline__ void write_pair(float *planeA, float *planeB, int W, 
     }
 }
 
-template <int CG, bool DUAL, int SHAPE>
-__device__ __forceinline__ void stage_window(float *planeA, float *planeB, v4i rsrc,
-                                             int C, int W, int tid)
+template <int NT, int CG, bool DUAL, int SHAPE>
+__device__ __forceinline__ void stage_window_shape(float *planeA, float *planeB, v4i rsrc, int C, int W, int tid)
 {
     const int npairs = W >> 1;
     const int strideG = C / CG;
-    for (int q0 = tid; q0 < npairs; q0 += kThreads * kStageDepth) {
+    for (int q0 = tid; q0 < npairs; q0 += NT * kStageDepth) {
         float v[kStageDepth][2 * CG];
         int q[kStageDepth];
         // Lanes past the window re-do its last pair (same value to the same slot)
         // rather than branch: the loads stay one straight-line burst.
 #pragma unroll
         for (int u = 0; u < kStageDepth; ++u) {
-            q[u] = min(q0 + u * kThreads, npairs - 1);
+            q[u] = min(q0 + u * NT, npairs - 1);
             load_pair<CG, SHAPE>(rsrc, q[u], strideG, C, v[u]);   // in range, or zero-filled by the descriptor
         }
 #pragma unroll
@@ -284,49 +276,84 @@ __device__ __forceinline__ void stage_window(float *planeA, float *planeB, v4i r
     }
 }
 
-// CG   channels handled per workgroup (C % CG == 0)
-// R    frame pairs per lane (tile = 2 * kThreads * R frames)
-// MODE 0 exact (mul, add)  1 fma
-// DUAL second LDS plane shifted by one frame for odd tap offsets
-template <int CG, int R, int MODE, bool DUAL>
-__global__ __launch_bounds__(kThreads) void conv_lds_kernel(const KArgs a)
+// src = this block's first sample; bytes_left = bytes from there to the end of the stream
+template <int NT, int CG, bool DUAL>
+__device__ __forceinline__ void stage_window(float *planeA, float *planeB, const float *src,
+                                             int64_t bytes_left, int C, int W, int tid)
+{
+    const v4i rsrc = make_rsrc(src, bytes_left);
+    const int shape = access_shape<CG>(src, C);          // workgroup-uniform
+    if (shape == kPair)       stage_window_shape<NT, CG, DUAL, kPair>(planeA, planeB, rsrc, C, W, tid);
+    else if (shape == kFrame) stage_window_shape<NT, CG, DUAL, kFrame>(planeA, planeB, rsrc, C, W, tid);
+    else                      stage_window_shape<NT, CG, DUAL, kDword>(planeA, planeB, rsrc, C, W, tid);
+}
+
+// One (frame pair, CG channels) result per lane and j: v[c] = frame 2q, v[CG+c] = frame 2q+1.
+// Range-checked buffer stores: frames past the end of the stream are dropped.
+template <int CG>
+__device__ __forceinline__ void store_result(v4i rdst, int shape, int q, int strideG, int C,
+                                             const float (&v)[2 * CG])
+{
+    if (shape == kPair)       store_pair<CG, kPair>(rdst, q, strideG, C, v);
+    else if (shape == kFrame) store_pair<CG, kFrame>(rdst, q, strideG, C, v);
+    else                      store_pair<CG, kDword>(rdst, q, strideG, C, v);
+}
+
+// ---- LDS reads ---------------------------------------------------------------------
+// One aligned ds_read_b64, compiler-tracked.  Volatile on purpose: hipcc otherwise
+// fuses neighbouring pairs into ds_read2st64_b64 / ds_read2_b32, which move half
+// the bytes per LDS cycle of plain ds_read_b64 (MI355X LDS table: 128 vs 256 B/clk).
+__device__ __forceinline__ v2f lds_pair(const float *p)
+{
+    typedef __attribute__((address_space(3))) const volatile v2f *lds_v2f_ptr;
+    return *(lds_v2f_ptr)p;
+}
+
+__device__ __forceinline__ unsigned lds_addr(const float *p)
+{
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)p;
+}
+
+// =====================================================================================
+// Ordered kernel: taps in table order, the reference's association.
+//   MODE 0  acc = f32(acc + f32(x*w))   bit-identical to NumPy's  out += x * w
+//   MODE 1  acc = fma(x, w, acc)
+// Odd tap offsets are 4-byte-misaligned for a b64 pair: DUAL keeps a second plane
+// shifted by one frame, !DUAL straddles the pair with two aligned reads.
+// Tap records: a wave parks 64 of them in two VGPRs (lane l <-> tap l) and
+// broadcasts one per step with v_readlane.
+// =====================================================================================
+template <int MODE>
+__device__ __forceinline__ float tap_op(float acc, float v, float w)
+{
+    if constexpr (MODE == 0) {
+        float p = v * w;          // file is built with -ffp-contract=off: two roundings
+        return acc + p;
+    } else {
+        return __builtin_fmaf(v, w, acc);
+    }
+}
+
+template <int NT, int CG, int R, int MODE, bool DUAL>
+__global__ __launch_bounds__(NT) void conv_ordered_kernel(const KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int T = 2 * kThreads * R;
+    constexpr int T = 2 * NT * R;
     const int tid = threadIdx.x;
     const int W = a.W;
-
-    uint32_t lid = xcd_remap(blockIdx.x, a.nblocks);
-    const int g = lid % (uint32_t)a.groups;
-    lid /= (uint32_t)a.groups;
-    const int tile = lid % (uint32_t)a.tiles;
-    const int64_t b = lid / (uint32_t)a.tiles;
-
+    const BlockCoord bc = decode_block(a);
     const int C = a.C;
-    const int c0 = g * CG;
-    const int64_t t0 = (int64_t)tile * T;
-    const float *__restrict__ xs = a.x + b * a.n * C;
-    float *__restrict__ ys = a.y + b * a.n * C;
+    const int c0 = bc.group * CG;
+    const int64_t t0 = (int64_t)bc.tile * T;
+    const float *__restrict__ xs = a.x + bc.stream * a.n * C;
+    float *__restrict__ ys = a.y + bc.stream * a.n * C;
+    const int64_t bytes_left = ((a.n - t0) * C - c0) * 4;
 
     float *planeA = lds;                       // [CG][W]   dword m = x[t0 + m]
     float *planeB = lds + (DUAL ? CG * W : 0); // [CG][W]   dword m = x[t0 + m + 1]
-    // (plane c of B sits CG*W floats after plane c of A: one base serves both)
-
-    // ---- stage tile + halo: coalesced HBM read, de-interleave into planes ----
-    {
-        const float *src = xs + t0 * C + c0;                 // this block's first sample
-        const v4i rsrc = make_rsrc(src, ((a.n - t0) * C - c0) * 4);
-        const int shape = access_shape<CG>(src, C);          // workgroup-uniform
-        if (shape == kPair)       stage_window<CG, DUAL, kPair>(planeA, planeB, rsrc, C, W, tid);
-        else if (shape == kFrame) stage_window<CG, DUAL, kFrame>(planeA, planeB, rsrc, C, W, tid);
-        else                      stage_window<CG, DUAL, kDword>(planeA, planeB, rsrc, C, W, tid);
-    }
+    stage_window<NT, CG, DUAL>(planeA, planeB, xs + t0 * C + c0, bytes_left, C, W, tid);
     __syncthreads();
 
-    // ---- tap sum: every lane owns R pairs of consecutive frames ----------------
-    // Tap records are wave-uniform.  Each wave keeps a chunk of 64 of them in two
-    // VGPRs (lane l <-> tap l) and broadcasts one per iteration with v_readlane:
-    // no scalar-memory round trip sits inside the tap loop.
     float2 out[CG][R];
     const int lane = tid & 63;
     const int lane_base = 2 * tid;
@@ -336,10 +363,9 @@ __global__ __launch_bounds__(kThreads) void conv_lds_kernel(const KArgs a)
     for (int c = 0; c < CG; ++c) {
         const int ch = c0 + c;
         const float *pa = planeA + c * W + lane_base;
-        const bool pass = a.chan_flags != nullptr && (a.chan_flags[ch] & 1);
-        if (pass) {
+        if (a.chan_flags != nullptr && (a.chan_flags[ch] & 1)) {      // unfiltered: copy through
 #pragma unroll
-            for (int j = 0; j < R; ++j) out[c][j] = *(const float2 *)(pa + 2 * kThreads * j);
+            for (int j = 0; j < R; ++j) out[c][j] = *(const float2 *)(pa + 2 * NT * j);
             continue;
         }
 #pragma unroll
@@ -357,7 +383,7 @@ __global__ __launch_bounds__(kThreads) void conv_lds_kernel(const KArgs a)
             Tap t;
             t.idx = 0; t.w = 0.0f;
             if (kk < k_last) t = a.taps[kk];
-            // DUAL: odd offsets read the shifted plane at an even position
+            // DUAL: odd offsets read the shifted plane (CG*W floats further) at an even slot
             tv_off = (DUAL && (t.idx & 1)) ? CG * W + t.idx - 1 : t.idx;
             tv_w = t.w;
         };
@@ -376,7 +402,7 @@ __global__ __launch_bounds__(kThreads) void conv_lds_kernel(const KArgs a)
                     const float *p = pa + off;
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
-                        const v2f v = lds_pair(p + 2 * kThreads * j);
+                        const v2f v = lds_pair(p + 2 * NT * j);
                         sb[j].x = tap_op<MODE>(sb[j].x, v.x, w);
                         sb[j].y = tap_op<MODE>(sb[j].y, v.y, w);
                     }
@@ -384,14 +410,14 @@ __global__ __launch_bounds__(kThreads) void conv_lds_kernel(const KArgs a)
                     const float *p = pa + (off - 1);     // two aligned pairs straddle ours
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
-                        const v2f lo = lds_pair(p + 2 * kThreads * j);
-                        const v2f hi = lds_pair(p + 2 * kThreads * j + 2);
+                        const v2f lo = lds_pair(p + 2 * NT * j);
+                        const v2f hi = lds_pair(p + 2 * NT * j + 2);
                         sb[j].x = tap_op<MODE>(sb[j].x, lo.y, w);
                         sb[j].y = tap_op<MODE>(sb[j].y, hi.x, w);
                     }
                 }
             }
-            if (has_seg) {
+            if (has_seg) {          // class path: seg *= envelope (unless identity); out += seg
                 if (a.apply_gain) {
                     const float gain = a.seg_gain[s_begin + s];
 #pragma unroll
@@ -406,28 +432,21 @@ __global__ __launch_bounds__(kThreads) void conv_lds_kernel(const KArgs a)
         }
     }
 
-    // ---- interleaved store: 2 frames x CG channels per lane and pair ------------
-    // Range-checked buffer stores: frames past the end of the stream are dropped.
-    {
-        float *dst = ys + t0 * C + c0;
-        const v4i rdst = make_rsrc(dst, ((a.n - t0) * C - c0) * 4);
-        const int shape = access_shape<CG>(dst, C);
-        const int strideG = C / CG;
+    float *dst = ys + t0 * C + c0;
+    const v4i rdst = make_rsrc(dst, bytes_left);
+    const int shape = access_shape<CG>(dst, C);
+    const int strideG = C / CG;
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-            float v[2 * CG];
+    for (int j = 0; j < R; ++j) {
+        float v[2 * CG];
 #pragma unroll
-            for (int c = 0; c < CG; ++c) { v[c] = out[c][j].x; v[CG + c] = out[c][j].y; }
-            const int q = tid + kThreads * j;
-            if (shape == kPair)       store_pair<CG, kPair>(rdst, q, strideG, C, v);
-            else if (shape == kFrame) store_pair<CG, kFrame>(rdst, q, strideG, C, v);
-            else                      store_pair<CG, kDword>(rdst, q, strideG, C, v);
-        }
+        for (int c = 0; c < CG; ++c) { v[c] = out[c][j].x; v[CG + c] = out[c][j].y; }
+        store_result<CG>(rdst, shape, tid + NT * j, strideG, C, v);
     }
 }
 
-// ---------------------------------------------------------------------------------
-// Fast mode (VND_MODE_FAST): same tap sum, free summation order, one FMA per tap.
+// =====================================================================================
+// Fast kernel (VND_MODE_FAST): same tap sum, free summation order, one FMA per tap.
 //
 // The LDS read is the scarce resource (K reads per output), so every tap must be
 // ONE aligned ds_read_b64 per output pair.  A lane's pair (2q, 2q+1) is aligned
@@ -437,46 +456,45 @@ __global__ __launch_bounds__(kThreads) void conv_lds_kernel(const KArgs a)
 // (2q-1, 2q) fed by the odd taps - both read at offset (i & ~1) - and the two are
 // merged once per tile:  y[2q] = accE.x + accO.y ,  y[2q+1] = accE.y + accO(q+1).x,
 // the neighbour's value going through LDS after the tap loops.  The odd part of
-// the tile's very last output has no lane; one wave reduces it from the tap
-// chunk it already holds in registers.
+// the tile's very last output has no lane; one wave reduces it from the tap list.
 //
 // The host splits each channel's taps into an even and an odd list
-// (vnd_taps_create); each list is walked by run_tap_array below.
+// (vnd_taps_create) with the segment gain folded into the weight.
+//
 // The LDS reads of the tap loops are inline asm so that (a) each stays a plain
 // ds_read_b64 with an immediate offset and (b) the waits are counted by hand:
-// hipcc's own bookkeeping drains the queue at the loop header (WAW on recycled
-// registers), which halves the depth of the pipeline.  Protocol (guide 5.7 form
-// ii): "=v" loads, then ONE wait statement that names every destination "+v"
-// before its first consumer; LDS returns in order, so lgkmcnt(N) with the N
-// newest reads belonging to the other buffer means "this buffer has landed".
-__device__ __forceinline__ unsigned lds_addr(const float *p)
-{
-    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)p;
-}
-
-template <int J>
+// hipcc's own bookkeeping drains the queue at loop headers (WAW on recycled
+// registers).  Protocol (guide 5.7 form ii): "=v" loads, then ONE wait statement
+// that names every destination "+v" before its first consumer; LDS returns in
+// order, so lgkmcnt(N) with the N newest reads belonging to the next buffer
+// means "this buffer has landed".  Buffers never cross a branch or loop edge: a
+// loop-carried buffer makes hipcc copy registers whose LDS data has not arrived.
+// =====================================================================================
+template <int NT, int J>
 __device__ __forceinline__ v2f ds_read_pair(unsigned addr)
 {
+    static_assert(J * 2 * NT * 4 <= 65535, "ds offset field is 16 bits");
     v2f r;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(J * 2 * kThreads * 4));
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(J * 2 * NT * 4));
     return r;
 }
 
-template <int R, int... Js>
+template <int NT, int R, int... Js>
 __device__ __forceinline__ void issue_reads_seq(v2f (&buf)[R], unsigned addr, std::integer_sequence<int, Js...>)
 {
-    ((buf[Js] = ds_read_pair<Js>(addr)), ...);
+    ((buf[Js] = ds_read_pair<NT, Js>(addr)), ...);
 }
 
-template <int R>
+template <int NT, int R>
 __device__ __forceinline__ void issue_reads(v2f (&buf)[R], unsigned addr)
 {
-    issue_reads_seq<R>(buf, addr, std::make_integer_sequence<int, R>{});
+    issue_reads_seq<NT, R>(buf, addr, std::make_integer_sequence<int, R>{});
 }
 
 template <int N, int R>
 __device__ __forceinline__ void wait_reads(v2f (&buf)[R])
 {
+    static_assert(N <= 15, "lgkmcnt is a 4-bit field");
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(buf[0]) : "n"(N));
 #pragma unroll
     for (int j = 1; j < R; ++j) asm volatile("" : "+v"(buf[j]));
@@ -492,37 +510,32 @@ __device__ __forceinline__ void consume(float2 (&acc)[R], const v2f (&buf)[R], f
     }
 }
 
-// One list of taps (all even or all odd offsets) into one accumulator set.
-// The list is wave-uniform, so it is fetched with scalar loads, 16 records at a
-// time, and lives in SGPRs: per tap the vector pipe issues ONE v_add (address =
-// lane base + scalar byte offset) plus the R packed FMAs - profiling showed the
-// kernel bound by instruction issue (VALU ~70 % busy, SALU ~55 %) when each tap
-// also cost two v_readlane and a find-first-bit walk over a ballot mask.
-// Four taps per group in straight-line code: the reads of the next tap are in
-// flight while a tap is consumed, and no half-landed register crosses a branch.
-template <int R>
+// Four taps in straight-line code: the reads of the next tap are in flight while
+// a tap is consumed.  Per tap the vector pipe issues ONE v_add (address = lane
+// base + scalar byte offset) plus the R packed FMAs.
+template <int NT, int R>
 __device__ __forceinline__ void tap_group4(const FastTap (&t)[16], int g, unsigned lane_addr, float2 (&acc)[R])
 {
     v2f b0[R], b1[R], b2[R], b3[R];
-    issue_reads<R>(b0, lane_addr + (unsigned)t[4 * g + 0].off);
-    issue_reads<R>(b1, lane_addr + (unsigned)t[4 * g + 1].off);
+    issue_reads<NT, R>(b0, lane_addr + (unsigned)t[4 * g + 0].off);
+    issue_reads<NT, R>(b1, lane_addr + (unsigned)t[4 * g + 1].off);
     wait_reads<R, R>(b0);          // only b1's R reads may still be outstanding
     consume<R>(acc, b0, t[4 * g + 0].w);
-    issue_reads<R>(b2, lane_addr + (unsigned)t[4 * g + 2].off);
+    issue_reads<NT, R>(b2, lane_addr + (unsigned)t[4 * g + 2].off);
     wait_reads<R, R>(b1);
     consume<R>(acc, b1, t[4 * g + 1].w);
-    issue_reads<R>(b3, lane_addr + (unsigned)t[4 * g + 3].off);
+    issue_reads<NT, R>(b3, lane_addr + (unsigned)t[4 * g + 3].off);
     wait_reads<R, R>(b2);
     consume<R>(acc, b2, t[4 * g + 2].w);
     wait_reads<0, R>(b3);
     consume<R>(acc, b3, t[4 * g + 3].w);
 }
 
-template <int R>
+template <int NT, int R>
 __device__ __forceinline__ void tap_single(const FastTap &t, unsigned lane_addr, float2 (&acc)[R])
 {
     v2f b0[R];
-    issue_reads<R>(b0, lane_addr + (unsigned)t.off);
+    issue_reads<NT, R>(b0, lane_addr + (unsigned)t.off);
     wait_reads<0, R>(b0);
     consume<R>(acc, b0, t.w);
 }
@@ -532,9 +545,10 @@ __device__ __forceinline__ void tap_single(const FastTap &t, unsigned lane_addr,
 // only scalar operand shape hipcc (ROCm 7.2) encodes correctly for the splatted
 // weight of v_pk_fma_f32 - fed from sub-registers of a wider s_buffer_load tuple
 // it multiplies every tap by the tuple's first dword.  Loads and their wait live
-// in one statement (guide 5.7 form i), outputs early-clobber.
-typedef int v2i __attribute__((ext_vector_type(2)));
-
+// in one statement (guide 5.7 form i), outputs early-clobber.  Profiling an
+// earlier version that broadcast each record with two v_readlane and walked a
+// ballot mask with s_ff1 showed the kernel bound by instruction issue (VALU ~70 %
+// busy, SALU ~55 %).
 __device__ __forceinline__ void load_taps16(const FastTap *ptr, FastTap (&t)[16])
 {
     v2i r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;
@@ -556,11 +570,11 @@ __device__ __forceinline__ void load_taps16(const FastTap *ptr, FastTap (&t)[16]
     for (int i = 0; i < 16; ++i) { t[i].w = __builtin_bit_cast(float, r[i].x); t[i].off = r[i].y; }
 }
 
-template <int R>
+// One list of taps (all even or all odd offsets) into one accumulator set.
+template <int NT, int R>
 __device__ __forceinline__ void run_tap_array(const FastTap *__restrict__ tp, int n, unsigned lane_addr,
                                               float2 (&acc)[R])
 {
-    static_assert(R <= 15, "lgkmcnt(R) must fit the 4-bit counter field");
     for (int k0 = 0; k0 < n; k0 += 16) {
         FastTap t[16];
         load_taps16(tp + k0, t);                 // the table is zero-padded by 16 records
@@ -568,45 +582,33 @@ __device__ __forceinline__ void run_tap_array(const FastTap *__restrict__ tp, in
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (4 * g + 4 <= m) {
-                tap_group4<R>(t, g, lane_addr, acc);
+                tap_group4<NT, R>(t, g, lane_addr, acc);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (4 * g + i < m) tap_single<R>(t[4 * g + i], lane_addr, acc);
+                    if (4 * g + i < m) tap_single<NT, R>(t[4 * g + i], lane_addr, acc);
             }
         }
     }
 }
 
-template <int CG, int R>
-__global__ __launch_bounds__(kThreads) void conv_fast_kernel(const KArgs a)
+template <int NT, int CG, int R>
+__global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int T = 2 * kThreads * R;
+    constexpr int T = 2 * NT * R;
     const int tid = threadIdx.x;
     const int W = a.W;
-
-    uint32_t lid = xcd_remap(blockIdx.x, a.nblocks);
-    const int g = lid % (uint32_t)a.groups;
-    lid /= (uint32_t)a.groups;
-    const int tile = lid % (uint32_t)a.tiles;
-    const int64_t b = lid / (uint32_t)a.tiles;
-
+    const BlockCoord bc = decode_block(a);
     const int C = a.C;
-    const int c0 = g * CG;
-    const int64_t t0 = (int64_t)tile * T;
-    const float *__restrict__ xs = a.x + b * a.n * C;
-    float *__restrict__ ys = a.y + b * a.n * C;
+    const int c0 = bc.group * CG;
+    const int64_t t0 = (int64_t)bc.tile * T;
+    const float *__restrict__ xs = a.x + bc.stream * a.n * C;
+    float *__restrict__ ys = a.y + bc.stream * a.n * C;
+    const int64_t bytes_left = ((a.n - t0) * C - c0) * 4;
     float *plane = lds;                                      // [CG][W]
 
-    {
-        const float *src = xs + t0 * C + c0;
-        const v4i rsrc = make_rsrc(src, ((a.n - t0) * C - c0) * 4);
-        const int shape = access_shape<CG>(src, C);
-        if (shape == kPair)       stage_window<CG, false, kPair>(plane, plane, rsrc, C, W, tid);
-        else if (shape == kFrame) stage_window<CG, false, kFrame>(plane, plane, rsrc, C, W, tid);
-        else                      stage_window<CG, false, kDword>(plane, plane, rsrc, C, W, tid);
-    }
+    stage_window<NT, CG, false>(plane, plane, xs + t0 * C + c0, bytes_left, C, W, tid);
     __syncthreads();
 
     float2 accE[CG][R], accO[CG][R];
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(kThreads) void conv_fast_kernel(const KArgs a)
         for (int j = 0; j < R; ++j) { accE[c][j] = make_float2(0.0f, 0.0f); accO[c][j] = make_float2(0.0f, 0.0f); }
         if (a.chan_flags != nullptr && (a.chan_flags[ch] & 1)) {       // unfiltered: copy through
 #pragma unroll
-            for (int j = 0; j < R; ++j) accE[c][j] = *(const float2 *)(pa + 2 * kThreads * j);
+            for (int j = 0; j < R; ++j) accE[c][j] = *(const float2 *)(pa + 2 * NT * j);
             continue;
         }
         const int first = __builtin_amdgcn_readfirstlane(a.fast_off[ch]);
@@ -632,8 +634,8 @@ __global__ __launch_bounds__(kThreads) void conv_fast_kernel(const KArgs a)
         const int n_all = __builtin_amdgcn_readfirstlane(a.fast_off[ch + 1]) - first;
         const int n_even = __builtin_amdgcn_readfirstlane(a.fast_even[ch]);
         const int n_odd = n_all - n_even;
-        run_tap_array<R>(tp, n_even, lds_addr(pa), accE[c]);
-        run_tap_array<R>(tp + n_even, n_odd, lds_addr(pa), accO[c]);
+        run_tap_array<NT, R>(tp, n_even, lds_addr(pa), accE[c]);
+        run_tap_array<NT, R>(tp + n_even, n_odd, lds_addr(pa), accO[c]);
         // frame T-1 pairs with frame T, which no lane owns: its odd taps, x[T-1+i] = plane[T + (i-1)],
         // are reduced across the wave (lane l takes odd tap l, l+64, ...)
         float part = 0.0f;
@@ -653,41 +655,42 @@ __global__ __launch_bounds__(kThreads) void conv_fast_kernel(const KArgs a)
 #pragma unroll
     for (int c = 0; c < CG; ++c) {
 #pragma unroll
-        for (int j = 0; j < R; ++j) xo[c * XS + tid + kThreads * j] = accO[c][j].x;
-        if (tid == kThreads - 1) xo[c * XS + T / 2] = edge[c];
+        for (int j = 0; j < R; ++j) xo[c * XS + tid + NT * j] = accO[c][j].x;
+        if (tid == NT - 1) xo[c * XS + T / 2] = edge[c];
     }
     __syncthreads();
 
-    {
-        float *dst = ys + t0 * C + c0;
-        const v4i rdst = make_rsrc(dst, ((a.n - t0) * C - c0) * 4);
-        const int shape = access_shape<CG>(dst, C);
-        const int strideG = C / CG;
+    float *dst = ys + t0 * C + c0;
+    const v4i rdst = make_rsrc(dst, bytes_left);
+    const int shape = access_shape<CG>(dst, C);
+    const int strideG = C / CG;
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const int q = tid + kThreads * j;
-            float v[2 * CG];
+    for (int j = 0; j < R; ++j) {
+        const int q = tid + NT * j;
+        float v[2 * CG];
 #pragma unroll
-            for (int c = 0; c < CG; ++c) {
-                v[c] = accE[c][j].x + accO[c][j].y;
-                v[CG + c] = accE[c][j].y + xo[c * XS + q + 1];
-            }
-            if (shape == kPair)       store_pair<CG, kPair>(rdst, q, strideG, C, v);
-            else if (shape == kFrame) store_pair<CG, kFrame>(rdst, q, strideG, C, v);
-            else                      store_pair<CG, kDword>(rdst, q, strideG, C, v);
+        for (int c = 0; c < CG; ++c) {
+            v[c] = accE[c][j].x + accO[c][j].y;
+            v[CG + c] = accE[c][j].y + xo[c * XS + q + 1];
         }
+        store_result<CG>(rdst, shape, q, strideG, C, v);
     }
 }
 
+// =====================================================================================
 // Fallback without LDS staging, for halos that do not fit a workgroup's LDS
-// (very long FIRs): one lane per (frame, channel), taps gathered through L1/L2.
+// (very long FIRs): one lane per (frame, channel), taps gathered through L1/L2,
+// table order and association (MODE as in the ordered kernel).
+// =====================================================================================
+constexpr int kDirectThreads = 256;
+
 template <int MODE>
-__global__ __launch_bounds__(kThreads) void conv_direct_kernel(const KArgs a)
+__global__ __launch_bounds__(kDirectThreads) void conv_direct_kernel(const KArgs a)
 {
     const int64_t per_stream = a.n * a.C;
     const int64_t total = per_stream * (int64_t)a.tiles;   // tiles carries the batch here
-    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total;
-         e += (int64_t)gridDim.x * kThreads) {
+    for (int64_t e = (int64_t)blockIdx.x * kDirectThreads + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * kDirectThreads) {
         const int64_t b = e / per_stream;
         const int64_t r = e - b * per_stream;
         const int64_t n0 = r / a.C;

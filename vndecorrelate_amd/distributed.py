@@ -1,0 +1,104 @@
+"""Batched many-stream mode across the GPUs of one node.
+
+The hot path shards by *independent streams* (reference: the channel loop and
+nothing else couples samples, decorrelation.py:649): every rank
+owns a contiguous block of the batch, runs the same kernels on its own GPU, and
+no collective sits on the data path.  The only communication is one broadcast of
+the shared tap-table image (8*K*C bytes + header) from the rank that built it -
+``torch.distributed`` with backend ``nccl`` is RCCL over xGMI on ROCm; ``gloo``
+works too (that is what the CPU tests use).
+
+One process per GPU (``torchrun --nproc-per-node N``); torch is used for process
+groups and device memory only.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+
+from .taps import TapArrays
+
+
+def shard_range(total: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block partition of ``total`` streams: ``(start, count)`` of
+    ``rank``; the remainder goes one each to the lowest ranks."""
+    if world_size <= 0 or not 0 <= rank < world_size:
+        raise ValueError(f'bad rank {rank} of {world_size}')
+    base, extra = divmod(total, world_size)
+    count = base + (1 if rank < extra else 0)
+    start = rank * base + min(rank, extra)
+    return start, count
+
+
+def broadcast_bytes(payload: Optional[bytes], src: int = 0, group=None, device=None) -> bytes:
+    """Every rank returns ``payload`` of rank ``src`` (two broadcasts: length, body).
+    Tensors live on ``device`` (a CUDA device for nccl/RCCL, CPU for gloo)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        if payload is None:
+            raise ValueError('payload missing on a single-rank run')
+        return payload
+    rank = dist.get_rank(group)
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) \
+            if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+    size = torch.tensor([len(payload) if rank == src else 0], dtype=torch.int64, device=device)
+    dist.broadcast(size, src=src, group=group)
+    body = torch.empty(int(size.item()), dtype=torch.uint8, device=device)
+    if rank == src:
+        body.copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
+    dist.broadcast(body, src=src, group=group)
+    return body.cpu().numpy().tobytes()
+
+
+class ShardedDecorrelator:
+    """Shared impulse table, streams sharded over the ranks of ``group``.
+
+    ``arrays`` (the table) is needed on ``src`` only; other ranks receive it.
+    ``backend(arrays) -> callable(x_local, mode)`` builds the per-rank compute
+    object; the default uploads the table to this rank's GPU.  (Tests on a
+    CPU-only box inject a checker here - there is no CPU path in the product.)
+    """
+
+    def __init__(self, arrays: Optional[TapArrays] = None, *, src: int = 0, group=None, device=None,
+                 backend: Optional[Callable] = None):
+        import torch.distributed as dist
+        self.group = group
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        image = arrays.to_bytes() if (arrays is not None and self.rank == src) else None
+        if self.world_size == 1 and image is None:
+            raise ValueError('the tap table is required on the source rank')
+        self.image = broadcast_bytes(image, src=src, group=group, device=device)
+        self.arrays = TapArrays.from_bytes(self.image)
+        self._convolve = (backend or self._gpu_backend)(self.arrays)
+
+    @staticmethod
+    def _gpu_backend(arrays: TapArrays):
+        from . import _native
+        table = _native.TapTable.from_bytes(_native.default_context(), arrays.to_bytes())
+
+        def run(x_local: np.ndarray, mode: int) -> np.ndarray:
+            return table.convolve_host(np.ascontiguousarray(x_local, dtype=np.float32), mode)
+
+        run.table = table
+        return run
+
+    def shard(self, total_streams: int) -> Tuple[int, int]:
+        return shard_range(total_streams, self.world_size, self.rank)
+
+    def convolve_local(self, x_local: np.ndarray, mode: int = 2) -> np.ndarray:
+        """This rank's ``(b_local, n, C)`` block -> same shape.  No communication."""
+        if x_local.ndim != 3:
+            raise ValueError(f'expected (streams, n, C), got {x_local.shape}')
+        if x_local.shape[0] == 0:
+            return np.zeros(x_local.shape, np.float32)
+        return self._convolve(x_local, mode)
+
+    def convolve_global(self, x_all: np.ndarray, mode: int = 2) -> np.ndarray:
+        """Convenience for small jobs: every rank passes the same full batch and gets
+        back only ITS block; stack blocks in rank order to rebuild the batch."""
+        start, count = self.shard(x_all.shape[0])
+        return self.convolve_local(x_all[start:start + count], mode)

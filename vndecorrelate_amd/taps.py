@@ -42,6 +42,58 @@ class TapArrays:
         return dict(seg_offsets=self.seg_offsets, seg_end=self.seg_end, seg_gain=self.seg_gain,
                     chan_flags=self.chan_flags, apply_gain=self.apply_gain)
 
+    # ---- transport image: byte-identical to vnd_taps_serialize (csrc/vnd_amd.hip) ----
+    # int32 header[8] = {magic "VNDT", ABI version, C, taps, segments, has_seg, has_flags,
+    # apply_gain}, then tap_offsets[C+1], tap_index, tap_weight, (seg_offsets[C+1], seg_end,
+    # seg_gain), (chan_flags padded to 4 bytes).  This is what travels over RCCL.
+    _MAGIC = 0x564E4454
+    _ABI = 1
+
+    def to_bytes(self) -> bytes:
+        channels, total = self.num_channels, len(self.tap_index)
+        has_seg = self.seg_offsets is not None
+        has_flags = self.chan_flags is not None
+        segs = len(self.seg_end) if has_seg else 0
+        head = np.array([self._MAGIC, self._ABI, channels, total, segs, int(has_seg), int(has_flags),
+                         int(bool(self.apply_gain))], np.int32)
+        parts = [head, self.tap_offsets.astype(np.int32), self.tap_index.astype(np.int32),
+                 self.tap_weight.astype(np.float32)]
+        if has_seg:
+            parts += [self.seg_offsets.astype(np.int32), self.seg_end.astype(np.int32),
+                      self.seg_gain.astype(np.float32)]
+        image = b''.join(np.ascontiguousarray(p).tobytes() for p in parts)
+        if has_flags:
+            flags = np.zeros((channels + 3) // 4 * 4, np.uint8)
+            flags[:channels] = self.chan_flags
+            image += flags.tobytes()
+        return image
+
+    @classmethod
+    def from_bytes(cls, image: bytes) -> 'TapArrays':
+        head = np.frombuffer(image, np.int32, 8)
+        if head[0] != cls._MAGIC or head[1] != cls._ABI:
+            raise ValueError('not a tap-table image of this ABI version')
+        channels, total, segs, has_seg, has_flags, gain = (int(v) for v in head[2:8])
+        pos = 32
+
+        def take(dtype, count):
+            nonlocal pos
+            out = np.frombuffer(image, dtype, count, pos).copy()
+            pos += out.nbytes
+            return out
+
+        arrays = cls(take(np.int32, channels + 1), take(np.int32, total), take(np.float32, total))
+        if has_seg:
+            arrays.seg_offsets = take(np.int32, channels + 1)
+            arrays.seg_end = take(np.int32, segs)
+            arrays.seg_gain = take(np.float32, segs)
+        if has_flags:
+            arrays.chan_flags = take(np.uint8, channels)
+        arrays.apply_gain = bool(gain)
+        if arrays.tap_offsets[-1] != total:
+            raise ValueError('corrupt tap-table image')
+        return arrays
+
 
 def function_path_arrays(fir: np.ndarray, num_channels: Optional[int] = None) -> TapArrays:
     """CSR table of the nonzeros of ``fir[:, c]`` for the first ``num_channels`` columns."""
