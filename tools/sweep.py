@@ -21,13 +21,13 @@ CONFIGS = {   # fs, fir seconds, taps, kappa, frames, channels, pool
 }
 
 
-def variant(r_log2=None, dual=None, cg=0, direct=False, nt=0):
+def variant(r_log2=None, dual=None, cg=0, direct=False, nt=0, nostream=0, percu=0):
     v = 0
     if r_log2 is not None:
         v |= r_log2 + 1
     if dual is not None:
         v |= (1 << 5) | (int(dual) << 4)
-    return v | (cg << 8) | (int(direct) << 12) | ({0: 0, 256: 1, 512: 2, 1024: 3}[nt] << 16)
+    return v | (cg << 8) | (int(direct) << 12) | ({0: 0, 256: 1, 512: 2, 1024: 3}[nt] << 16) | (nostream << 18) | (percu << 20)
 
 
 def main():
@@ -40,6 +40,7 @@ def main():
     ap.add_argument('--modes', default='0,1,2')
     ap.add_argument('--direct', action='store_true')
     ap.add_argument('--nts', default='256')
+    ap.add_argument('--stream', default='0', help=argparse.SUPPRESS)
     args = ap.parse_args()
     import torch
     import vndecorrelate_amd.decorrelation as vnd
@@ -65,14 +66,15 @@ def main():
                     if mode == 2 and r > 3:
                         continue
                     for nt in ([int(v) for v in args.nts.split(',')] if mode == 2 else [0]):
-                        cases.append((mode, cg, r, dual, False, nt))
+                        for sv in ([int(v) for v in args.stream.split(',')] if mode == 2 else [0]):
+                            cases.append((mode, cg, r, dual, False, nt, sv))
         if args.direct:
-            cases.append((mode, 0, None, None, True, 0))
+            cases.append((mode, 0, None, None, True, 0, 0))
     results = {c: [] for c in cases}
     for rnd in range(args.rounds + 1):
         for c in cases:
-            mode, cg, r, dual, direct, nt = c
-            ctx.set_variant(variant(r, dual, cg, direct, nt))
+            mode, cg, r, dual, direct, nt, sv = c
+            ctx.set_variant(variant(r, dual, cg, direct, nt, int(sv == 0), max(sv, 0)))
             iters = 2 if direct else args.iters
             ms = table.time_device(x.data_ptr(), y.data_ptr(), pool, n, ch, mode=mode, n_buffers=1,
                                    stride_elems=0, iters=iters, stream=stream)
@@ -81,8 +83,8 @@ def main():
     print(f'# {args.config}: pool={pool} n={n} C={ch} taps={taps} algorithmic bytes/launch={nbytes/1e6:.1f} MB')
     print('mode cg pairs dual direct   med_ms   min_ms   GB/s(med)  frac_of_8TB/s  launch')
     for c in cases:
-        mode, cg, r, dual, direct, nt = c
-        ctx.set_variant(variant(r, dual, cg, direct, nt))
+        mode, cg, r, dual, direct, nt, sv = c
+        ctx.set_variant(variant(r, dual, cg, direct, nt, int(sv == 0), max(sv, 0)))
         desc = table.describe(pool, n, ch, mode)
         med, mn = float(np.median(results[c])), float(np.min(results[c]))
         gbs = nbytes / med / 1e6

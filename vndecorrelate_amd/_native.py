@@ -20,7 +20,7 @@ MODE_FMA = 1     # acc = fma(x, w, acc), table order
 MODE_FAST = 2    # fma, free summation order, gains folded into weights: the throughput mode
 
 _PKG = pathlib.Path(__file__).resolve().parent
-LIB_PATH = _PKG / 'libvnd_amd.so'
+LIB_PATH = pathlib.Path(os.environ.get('VND_AMD_LIBRARY', _PKG / 'libvnd_amd.so'))   # override: tuning builds only
 
 _c_i32p = ctypes.POINTER(ctypes.c_int32)
 _c_f32p = ctypes.POINTER(ctypes.c_float)

@@ -246,7 +246,8 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
         if ((int64_t)batch * p.tiles * p.groups > 0x7fffffffLL)
             return fail(VND_ERR_UNSUPPORTED, "grid too large; split the batch");
         a.tiles = p.tiles; a.groups = p.groups; a.W = p.W;
-        kern_t k = mode == VND_MODE_FAST ? fast_kernel(p.nt, p.cg, p.r_log2) : ordered_kernel(p.cg, p.r_log2, mode, p.dual);
+        kern_t k = mode == VND_MODE_FAST ? fast_kernel(p.nt, p.cg, p.r_log2)
+                                         : ordered_kernel(p.cg, p.r_log2, mode, p.dual);
         if (p.lds_bytes > 65536)
             HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)p.lds_bytes));
@@ -604,7 +605,7 @@ vnd_status vnd_describe_launch(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, i
         snprintf(text, (size_t)len, "conv_direct mode=%d blocks=%u threads=%d", mode, p.nblocks, kDirectThreads);
     else
         snprintf(text, (size_t)len,
-                 "%s cg=%d pairs_per_lane=%d tile=%d halo=%d dual=%d mode=%d lds=%zuB blocks=%u threads=%d",
+                 "%s cg=%d pairs_per_lane=%d tile=%d halo=%d dual=%d mode=%d lds=%zuB workgroups=%u threads=%d",
                  mode == VND_MODE_FAST ? "conv_fast" : "conv_ordered", p.cg, 1 << p.r_log2, (2 * p.nt) << p.r_log2,
                  p.W - ((2 * p.nt) << p.r_log2), p.dual, mode, p.lds_bytes, p.nblocks, p.nt);
     return VND_OK;

@@ -488,6 +488,11 @@ __device__ __forceinline__ void issue_reads_seq(v2f (&buf)[R], unsigned addr, st
 template <int NT, int R>
 __device__ __forceinline__ void issue_reads(v2f (&buf)[R], unsigned addr)
 {
+#if defined(VND_ABLATE) && VND_ABLATE == 3      // timing-only build: FMAs without the LDS reads
+#pragma unroll
+    for (int j = 0; j < R; ++j) { buf[j] = v2f{1.0f, 2.0f}; asm volatile("" : "+v"(buf[j]) : "v"(addr)); }
+    return;
+#endif
     issue_reads_seq<NT, R>(buf, addr, std::make_integer_sequence<int, R>{});
 }
 
@@ -503,6 +508,11 @@ __device__ __forceinline__ void wait_reads(v2f (&buf)[R])
 template <int R>
 __device__ __forceinline__ void consume(float2 (&acc)[R], const v2f (&buf)[R], float w)
 {
+#if defined(VND_ABLATE) && VND_ABLATE == 2      // timing-only build: LDS reads without the FMAs
+#pragma unroll
+    for (int j = 0; j < R; ++j) asm volatile("" ::"v"(buf[j]));
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         acc[j].x = __builtin_fmaf(buf[j].x, w, acc[j].x);
@@ -549,8 +559,13 @@ __device__ __forceinline__ void tap_single(const FastTap &t, unsigned lane_addr,
 // earlier version that broadcast each record with two v_readlane and walked a
 // ballot mask with s_ff1 showed the kernel bound by instruction issue (VALU ~70 %
 // busy, SALU ~55 %).
-__device__ __forceinline__ void load_taps16(const FastTap *ptr, FastTap (&t)[16])
+__device__ __forceinline__ void load_taps16(const FastTap *ptr_any, FastTap (&t)[16])
 {
+    // "s" operands must be provably wave-uniform: re-assert it on both halves
+    const uint64_t p64 = (uint64_t)ptr_any;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p64);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p64 >> 32));
+    const FastTap *ptr = (const FastTap *)(((uint64_t)hi << 32) | lo);
     v2i r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;
     asm volatile(
         "s_load_dwordx2 %0, %16, 0x0\n\ts_load_dwordx2 %1, %16, 0x8\n\t"
@@ -632,20 +647,26 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
         const int first = __builtin_amdgcn_readfirstlane(a.fast_off[ch]);
         const FastTap *__restrict__ tp = a.taps_fast + first;
         const int n_all = __builtin_amdgcn_readfirstlane(a.fast_off[ch + 1]) - first;
+#if defined(VND_ABLATE) && VND_ABLATE == 1      // timing-only build: staging and stores, no taps
+        const int n_even = 0, n_odd = 0; (void)n_all;
+#else
         const int n_even = __builtin_amdgcn_readfirstlane(a.fast_even[ch]);
         const int n_odd = n_all - n_even;
+#endif
         run_tap_array<NT, R>(tp, n_even, lds_addr(pa), accE[c]);
         run_tap_array<NT, R>(tp + n_even, n_odd, lds_addr(pa), accO[c]);
         // frame T-1 pairs with frame T, which no lane owns: its odd taps, x[T-1+i] = plane[T + (i-1)],
-        // are reduced across the wave (lane l takes odd tap l, l+64, ...)
-        float part = 0.0f;
-        for (int k = lane; k < n_odd; k += 64) {
-            const FastTap t = tp[n_even + k];
-            part = __builtin_fmaf(pc[T + (t.off >> 2)], t.w, part);
-        }
+        // are reduced across the last wave (lane l takes odd tap l, l+64, ...)
+        if (tid >= NT - 64) {                      // only the last wave's last lane publishes it
+            float part = 0.0f;
+            for (int k = lane; k < n_odd; k += 64) {
+                const FastTap t = tp[n_even + k];
+                part = __builtin_fmaf(pc[T + (t.off >> 2)], t.w, part);
+            }
 #pragma unroll
-        for (int sh = 32; sh > 0; sh >>= 1) part += __shfl_xor(part, sh);
-        edge[c] = part;
+            for (int sh = 32; sh > 0; sh >>= 1) part += __shfl_xor(part, sh);
+            edge[c] = part;
+        }
     }
 
     // ---- merge the two accumulator sets: neighbour's accO.x through LDS -----------
