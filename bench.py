@@ -50,8 +50,11 @@ ALGO_BYTES_PER_SAMPLE = 8      # 4 B read + 4 B written per output channel-sampl
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=400)
+    ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--min-warmup-ms', type=float, default=150.0,
+                    help='keep issuing untimed warm-up steps until this much wall time has passed: the GPU '
+                         'ramps its clocks over the first ~40 ms of load (tools/sustain.py)')
     ap.add_argument('--pool', type=int, default=128, help='distinct cfg2 signals per rank and step')
     ap.add_argument('--mode', choices=['exact', 'fma', 'fast'], default=os.environ.get('VND_BENCH_MODE', 'fast'))
     ap.add_argument('--cpu-seconds', type=float, default=10.0, help='budget of the CPU baseline leg')
@@ -135,11 +138,18 @@ def main():
     def run(m):
         table.convolve_device(x.data_ptr(), y.data_ptr(), args.pool, n, CHANNELS, m, stream)
 
+    warmups = []
+
     def timed(m, steps, warmup):
         """warmup, barrier+sync, `steps` back-to-back steps, sync+barrier; wall seconds and the
         mean kernel time between two events on the launch stream."""
-        for _ in range(warmup):
+        done, t_w = 0, time.perf_counter()
+        while done < warmup or (time.perf_counter() - t_w) * 1e3 < args.min_warmup_ms:
             run(m)
+            done += 1
+            if done % 16 == 0:
+                torch.cuda.synchronize()
+        warmups.append(done)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -199,7 +209,7 @@ def main():
         line = {
             'metric': 'Msamples/sec decorrelated (stereo, 30 taps) + achieved HBM GB/s vs roofline',
             'value': round(value, 1), 'unit': 'Msamples/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+            'warmup': warmups[0], 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'cfg2: 48 kHz stereo float32, 10 s, 30 taps / 30 ms velvet FIR (seed 1); '
