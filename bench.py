@@ -61,6 +61,7 @@ def parse():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-exact', action='store_true', help='skip the extra exact-mode timing')
     ap.add_argument('--variant', type=int, default=-1, help='kernel variant override (tuning)')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo for rehearsals)')
     return ap.parse_args()
 
 
@@ -100,11 +101,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch multi-GPU runs with: python -m torch.distributed.run '
                              '--nproc-per-node N bench.py --gpus N ...')
+    if 'VND_BENCH_FORCE_DEVICE' in os.environ:                 # rehearsing N ranks on a 1-GPU box
+        local_rank = int(os.environ['VND_BENCH_FORCE_DEVICE'])
     os.environ['VND_DEVICE'] = str(local_rank)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
-        dist.init_process_group('nccl', device_id=device)      # nccl == RCCL on ROCm
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
 
     import vndecorrelate_amd.decorrelation as vnd
     from vndecorrelate_amd import _native
@@ -122,7 +128,7 @@ def main():
                                         num_outs=CHANNELS, sample_rate_hz=SAMPLE_RATE, seed=1)
         arrays = function_path_arrays(fir)
         image = arrays.to_bytes()
-    image = broadcast_bytes(image, src=0, device=device)
+    image = broadcast_bytes(image, src=0, device=device if args.backend == 'nccl' else None)
     table = _native.TapTable.from_bytes(ctx, image)
 
     # ---- resident synthetic pool: (pool, N, C) float32 in HBM --------------------
@@ -169,7 +175,7 @@ def main():
     y_timed = y[args.pool - 1].cpu().numpy() if rank == 0 else None
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

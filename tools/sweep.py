@@ -27,7 +27,7 @@ def variant(r_log2=None, dual=None, cg=0, direct=False, nt=0, nostream=0, percu=
         v |= r_log2 + 1
     if dual is not None:
         v |= (1 << 5) | (int(dual) << 4)
-    return v | (cg << 8) | (int(direct) << 12) | ({0: 0, 256: 1, 512: 2, 1024: 3}[nt] << 16) | (nostream << 18) | (percu << 20)
+    return v | (cg << 8) | (int(direct) << 12) | ({0: 0, 256: 0, 128: 1, 512: 2, 1024: 3}[nt] << 16) | (nostream << 18) | (percu << 20)
 
 
 def main():

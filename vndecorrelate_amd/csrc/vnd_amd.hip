@@ -135,6 +135,7 @@ static kern_t fast_by_cg(int cg, int r_log2)
 static kern_t fast_kernel(int nt, int cg, int r_log2)
 {
     switch (nt) {
+    case 128: return fast_by_cg<128>(cg, r_log2);
     case 256: return fast_by_cg<256>(cg, r_log2);
     case 512: return fast_by_cg<512>(cg, r_log2);
     default: return fast_by_cg<1024>(cg, r_log2);
@@ -151,7 +152,7 @@ static size_t lds_need(int nt, int cg, int r_log2, int dual, int max_index)
 
 // variant word (vnd_set_variant): bits 0-3 r_log2+1 (0 = auto), bit 4 dual,
 // bit 5 "dual given", bits 8-11 channels per workgroup (0 = auto), bit 12 direct,
-// bits 16-17 threads per workgroup of the fast kernel (0 auto, 1: 256, 2: 512, 3: 1024).
+// bits 16-17 threads per workgroup of the fast kernel (0: 256, 1: 128, 2: 512, 3: 1024).
 static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64_t n, int C, int mode)
 {
     Plan p;
@@ -168,7 +169,7 @@ static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int6
     int nt = kOrderedThreads;
     if (fast) {
         const int sel = v >= 0 ? ((v >> 16) & 3) : 0;
-        nt = sel == 1 ? 256 : sel == 2 ? 512 : sel == 3 ? 1024 : 256;
+        nt = sel == 1 ? 128 : sel == 2 ? 512 : sel == 3 ? 1024 : 256;
     }
     const int r_max = fast ? 3 : 4;
 
@@ -191,7 +192,7 @@ static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int6
         if (dual) dual = 0;
         else if (cg > 1) cg /= 2;
         else if (r_log2 > 0) --r_log2;
-        else if (nt > 256 && fast) nt /= 2;
+        else if (nt > 128 && fast) nt /= 2;
         else break;
     }
     if (force_direct || lds_need(nt, cg, r_log2, dual, t->max_index) > limit) {
@@ -610,5 +611,13 @@ vnd_status vnd_describe_launch(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, i
                  p.W - ((2 * p.nt) << p.r_log2), p.dual, mode, p.lds_bytes, p.nblocks, p.nt);
     return VND_OK;
 }
+
+#ifdef VND_STAMPS
+// diagnostic builds only (not declared in vnd_amd.h)
+int vnd_debug_read_stamps(unsigned long long *dst, int count)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(vnd::g_stamps), (size_t)count * sizeof(unsigned long long));
+}
+#endif
 
 }  // extern "C"

@@ -239,7 +239,10 @@ __device__ __forceinline__ void store_pair(v4i rdst, int q, int strideG, int C, 
 // kStageDepth independent loads are issued before the first LDS write, so every
 // wave keeps several KiB in flight; with one load per lane and iteration the
 // kernel is bound by HBM latency, not bandwidth.
-constexpr int kStageDepth = 4;
+#ifndef VND_STAGE_DEPTH
+#define VND_STAGE_DEPTH 4
+#endif
+constexpr int kStageDepth = VND_STAGE_DEPTH;
 
 template <int CG, bool DUAL>
 __device__ __forceinline__ void write_pair(float *planeA, float *planeB, int W, int f,
@@ -607,6 +610,22 @@ __device__ __forceinline__ void run_tap_array(const FastTap *__restrict__ tp, in
     }
 }
 
+#ifdef VND_STAMPS
+// Diagnostic build only (tools/ablate): per-workgroup s_memtime stamps of the phases,
+// written to a buffer of their own that nothing else reads.
+__device__ unsigned long long g_stamps[8 * 65536];
+#define VND_STAMP(slot)                                                                   \
+    do {                                                                                  \
+        unsigned long long t_;                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        if (threadIdx.x == 0 && blockIdx.x < 65536) g_stamps[blockIdx.x * 8 + (slot)] = t_; \
+    } while (0)
+#else
+#define VND_STAMP(slot) do { } while (0)
+#endif
+
 template <int NT, int CG, int R>
 __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
 {
@@ -614,6 +633,7 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
     constexpr int T = 2 * NT * R;
     const int tid = threadIdx.x;
     const int W = a.W;
+    VND_STAMP(0);
     const BlockCoord bc = decode_block(a);
     const int C = a.C;
     const int c0 = bc.group * CG;
@@ -623,8 +643,11 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
     const int64_t bytes_left = ((a.n - t0) * C - c0) * 4;
     float *plane = lds;                                      // [CG][W]
 
+    VND_STAMP(1);
     stage_window<NT, CG, false>(plane, plane, xs + t0 * C + c0, bytes_left, C, W, tid);
+    VND_STAMP(2);
     __syncthreads();
+    VND_STAMP(3);
 
     float2 accE[CG][R], accO[CG][R];
     float edge[CG];                       // odd-tap part of the tile's last output (frame T-1)
@@ -670,7 +693,9 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
     }
 
     // ---- merge the two accumulator sets: neighbour's accO.x through LDS -----------
+    VND_STAMP(4);
     __syncthreads();                                   // every wave is done reading the planes
+    VND_STAMP(5);
     float *xo = lds;                                   // [CG][T/2 + 1], reuses the window
     constexpr int XS = T / 2 + 1;
 #pragma unroll
@@ -696,6 +721,11 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
         }
         store_result<CG>(rdst, shape, q, strideG, C, v);
     }
+    VND_STAMP(6);
+#ifdef VND_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // diagnostic only: when the stores have left
+    VND_STAMP(7);
+#endif
 }
 
 // =====================================================================================
