@@ -102,6 +102,27 @@ vnd_status vnd_convolve_f32_host(vnd_ctx *ctx, const vnd_taps *taps, const float
                                  float *y, int64_t batch, int64_t n_frames,
                                  int32_t n_channels, int32_t mode);
 
+/* ---- the full stage: convolution + decorrelate epilogue on the device ----------
+ * Replaces VelvetNoise.decorrelate after its float32 cast / mono->stereo
+ * (decorrelation.py:431-440): convolve, then in place on y
+ *   ms_encode  encode_signal_to_side_channel(x, y)      utils/dsp.py:40-63   (2 channels)
+ *   use_width  apply_stereo_width(y, width)             utils/dsp.py:21-37   (2 channels)
+ *   normalize  rms_normalize(x, y), DUAL_MONO           utils/dsp.py:87-109  (eps = 1e-10 upstream)
+ * The pointwise steps are bit-identical to NumPy; the RMS scale uses an exactly
+ * rounded sum where NumPy's float32 reduction is sequential (see vnd_epilogue.hpp).
+ * `workspace` is device memory of >= vnd_decorrelate_workspace_bytes().          */
+vnd_status vnd_decorrelate_workspace_bytes(int64_t batch, int64_t n_frames, int32_t n_channels,
+                                           int64_t *bytes);
+vnd_status vnd_decorrelate_f32_dev(vnd_ctx *ctx, const vnd_taps *taps, const float *x_dev, float *y_dev,
+                                   int64_t batch, int64_t n_frames, int32_t n_channels, int32_t mode,
+                                   int32_t ms_encode, int32_t use_width, double width, int32_t normalize,
+                                   float eps, void *workspace_dev, int64_t workspace_bytes,
+                                   void *hip_stream);
+vnd_status vnd_decorrelate_f32_host(vnd_ctx *ctx, const vnd_taps *taps, const float *x, float *y,
+                                    int64_t batch, int64_t n_frames, int32_t n_channels, int32_t mode,
+                                    int32_t ms_encode, int32_t use_width, double width, int32_t normalize,
+                                    float eps);
+
 /* ---- measurement helpers (used by bench.py; not on the data path) ---------- */
 /* Launches the convolve `iters` times back to back on `hip_stream`, cycling
  * through `n_buffers` (x,y) pairs laid out at x_dev + i*stride_elems, and

@@ -330,3 +330,58 @@ def test_python_and_c_table_images_agree(vnd, golden):
     assert t.to_bytes() == cls.to_bytes()
     back = TapArrays.from_bytes(t.to_bytes())
     assert np.array_equal(back.seg_end, cls.seg_end) and back.apply_gain == cls.apply_gain
+
+
+# ---- f1: decorrelate epilogue on the device ----------------------------------------------
+def _exact_scale_oracle(x, kw):
+    """Reference pipeline with the RMS sums taken in float64 (what exact arithmetic gives);
+    the reference's own float32 axis-0 sum is sequential and ~1e-4 off on long signals."""
+    kw = dict(kw)
+    norm = kw.pop('normalizer', 'default') is not None
+    x32 = x.astype(np.float32, copy=False)
+    if x32.ndim == 1:
+        x32 = np.column_stack((x32, x32))
+    y = O.decorrelate(x32.copy(), normalize=False, **kw)
+    if norm:
+        mx = np.mean(np.square(x32.astype(np.float64)), axis=0).astype(np.float32)
+        my = np.mean(np.square(y.astype(np.float64)), axis=0).astype(np.float32)
+        y *= (np.sqrt(mx) / np.sqrt(my + np.float32(1e-10))).astype(np.float32)
+    return y
+
+
+@pytest.mark.parametrize('name', sorted(MANIFEST['cls_decorrelate']))
+def test_device_epilogue(vnd, golden, name):
+    meta = golden.manifest['cls_decorrelate'][name]
+    kw = _kw(golden.manifest['class_taps'][meta['class']]['kwargs'])
+    x = make_input(meta['input'])
+    vnd.set_device_epilogue(True)
+    try:
+        y = vnd.VelvetNoise(**kw).decorrelate(x.copy())
+    finally:
+        vnd.set_device_epilogue(False)
+    ref_meta = meta['out']
+    assert list(y.shape) == ref_meta['shape'] and y.dtype == np.float32
+    peak = max(ref_meta['max_abs'], 1e-30)
+    if kw.get('normalizer', 'default') is None:
+        golden.expect(name, y, exact=True)                       # pointwise steps are bit-identical
+    else:
+        golden.expect(name, y, exact=False, rtol_peak=5e-4)      # vs the reference's sequential float32 RMS
+        want = _exact_scale_oracle(x, kw)                        # vs exact arithmetic: float32 rounding only
+        assert np.max(np.abs(y.astype(np.float64) - want)) / peak <= 2e-6, name
+
+
+def test_device_epilogue_batched(vnd, golden):
+    kw = _kw(golden.manifest['class_taps']['v44k_width']['kwargs'])
+    vn = vnd.VelvetNoise(**kw)
+    x = make_input(dict(seed=12, shape=[9, 7001, 2]))
+    y = vn.decorrelate_batched(x)
+    for b in range(9):
+        want = _exact_scale_oracle(x[b], kw)
+        assert np.max(np.abs(y[b].astype(np.float64) - want)) <= 2e-6 * np.max(np.abs(want)), b
+    with pytest.raises(ValueError):
+        vnd.set_device_epilogue(True)
+        try:
+            vnd.VelvetNoise(sample_rate_hz=96000, seed=1, num_impulses=64, num_outs=8,
+                            filtered_channels=tuple(range(8))).decorrelate(np.zeros((100, 8), np.float32))
+        finally:
+            vnd.set_device_epilogue(False)

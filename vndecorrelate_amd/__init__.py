@@ -19,4 +19,5 @@ from .decorrelation import (  # noqa: F401
     convolve_velvet_noise_batched,
     generate_velvet_noise,
     set_default_mode,
+    set_device_epilogue,
 )

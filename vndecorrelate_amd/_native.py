@@ -50,6 +50,16 @@ SIGNATURES = {
     'vnd_convolve_f32_host': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_f32p, _c_f32p,
                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                              ctypes.c_int32]),
+    'vnd_decorrelate_workspace_bytes': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+                                                       ctypes.POINTER(ctypes.c_int64)]),
+    'vnd_decorrelate_f32_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                               ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_int32,
+                                               ctypes.c_float, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    'vnd_decorrelate_f32_host': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_f32p, _c_f32p,
+                                                ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_int32,
+                                                ctypes.c_float]),
     'vnd_time_convolve_f32_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                  ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
@@ -257,6 +267,33 @@ class TapTable:
                                                batch, n, c, int(mode)), 'vnd_convolve_f32_host')
         return y
 
+    def decorrelate_host(self, x: np.ndarray, mode: int = MODE_EXACT, *, ms_encode: bool, width,
+                         normalize: bool, eps: float = 1e-10) -> np.ndarray:
+        """Convolution + decorrelate epilogue on the device; x as in ``convolve_host``."""
+        if x.dtype != np.float32 or not x.flags.c_contiguous:
+            raise ValueError('decorrelate_host wants a C-contiguous float32 array')
+        if x.ndim == 2:
+            batch, (n, c) = 1, x.shape
+        elif x.ndim == 3:
+            batch, n, c = x.shape
+        else:
+            raise ValueError(f'expected (n, C) or (batch, n, C), got {x.shape}')
+        y = np.empty_like(x)
+        _check(self._lib.vnd_decorrelate_f32_host(
+            self.ctx.handle, self.handle, _ptr(x, ctypes.c_float), _ptr(y, ctypes.c_float), batch, n, c,
+            int(mode), int(bool(ms_encode)), int(width is not None), float(width or 0.0),
+            int(bool(normalize)), float(eps)), 'vnd_decorrelate_f32_host')
+        return y
+
+    def decorrelate_device(self, x_ptr: int, y_ptr: int, batch: int, n: int, channels: int, *, mode: int,
+                           ms_encode: bool, width, normalize: bool, workspace_ptr: int, workspace_bytes: int,
+                           eps: float = 1e-10, stream: int = 0):
+        _check(self._lib.vnd_decorrelate_f32_dev(
+            self.ctx.handle, self.handle, ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr), batch, n, channels,
+            int(mode), int(bool(ms_encode)), int(width is not None), float(width or 0.0), int(bool(normalize)),
+            float(eps), ctypes.c_void_p(workspace_ptr), workspace_bytes, ctypes.c_void_p(stream)),
+            'vnd_decorrelate_f32_dev')
+
     def convolve_device(self, x_ptr: int, y_ptr: int, batch: int, n: int, channels: int,
                         mode: int = MODE_EXACT, stream: int = 0):
         """Enqueue on ``stream`` (a hipStream_t as int); pointers are device addresses."""
@@ -280,6 +317,13 @@ class TapTable:
         _check(self._lib.vnd_describe_launch(self.ctx.handle, self.handle, batch, n, channels,
                                              int(mode), buf, 512), 'vnd_describe_launch')
         return buf.value.decode()
+
+
+def decorrelate_workspace_bytes(batch: int, n: int, channels: int) -> int:
+    need = ctypes.c_int64()
+    _check(load_library().vnd_decorrelate_workspace_bytes(batch, n, channels, ctypes.byref(need)),
+           'vnd_decorrelate_workspace_bytes')
+    return need.value
 
 
 def device_count() -> int:

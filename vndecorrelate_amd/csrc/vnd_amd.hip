@@ -1,6 +1,7 @@
 // vnd_amd.hip - C ABI (include/vnd_amd.h) over the gfx950 kernels.
 // Host-side only decides launch geometry; all arithmetic lives in vnd_kernels.hpp.
 #include "vnd_kernels.hpp"
+#include "vnd_epilogue.hpp"
 #include "../../include/vnd_amd.h"
 
 #include <algorithm>
@@ -610,6 +611,87 @@ vnd_status vnd_describe_launch(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, i
                  mode == VND_MODE_FAST ? "conv_fast" : "conv_ordered", p.cg, 1 << p.r_log2, (2 * p.nt) << p.r_log2,
                  p.W - ((2 * p.nt) << p.r_log2), p.dual, mode, p.lds_bytes, p.nblocks, p.nt);
     return VND_OK;
+}
+
+static int64_t epi_chunks(int64_t n) { return (n + kEpiChunk - 1) / kEpiChunk; }
+
+vnd_status vnd_decorrelate_workspace_bytes(int64_t batch, int64_t n, int32_t C, int64_t *bytes)
+{
+    if (!bytes || batch < 0 || n < 0 || C <= 0) return fail(VND_ERR_INVALID, "bad workspace query");
+    *bytes = std::max<int64_t>(batch * epi_chunks(n) * 2 * C * (int64_t)sizeof(double), 8);
+    return VND_OK;
+}
+
+static vnd_status launch_epilogue(const float *x, float *y, int64_t batch, int64_t n, int32_t C, int32_t ms_encode,
+                                  int32_t use_width, double width, int32_t normalize, float eps, void *workspace,
+                                  int64_t workspace_bytes, hipStream_t stream)
+{
+    if ((ms_encode || use_width) && C != 2)
+        return fail(VND_ERR_INVALID, "side-channel encode and stereo width need 2 channels, got %d", C);
+    if (!ms_encode && !use_width && !normalize) return VND_OK;
+    int64_t need = 0;
+    vnd_decorrelate_workspace_bytes(batch, n, C, &need);
+    if (normalize && (!workspace || workspace_bytes < need))
+        return fail(VND_ERR_INVALID, "workspace too small: need %lld bytes", (long long)need);
+    if (batch > 65535) return fail(VND_ERR_UNSUPPORTED, "more than 65535 streams per call: split the batch");
+    EArgs e{};
+    e.x = x; e.y = y; e.partials = (double *)workspace; e.n = n; e.C = C;
+    e.chunks = (int32_t)epi_chunks(n);
+    e.ms_encode = ms_encode ? 1 : 0; e.use_width = use_width ? 1 : 0;
+    e.w_mid = (float)(1.0 - width); e.w_side = (float)width;   // float32(python float), as NumPy's in-place multiply
+    e.normalize = normalize ? 1 : 0; e.eps = eps;
+    const dim3 grid((unsigned)e.chunks, (unsigned)batch);
+    hipLaunchKernelGGL(epilogue_pointwise_kernel, grid, dim3(kEpiThreads), 0, stream, e);
+    if (normalize)
+        hipLaunchKernelGGL(epilogue_scale_kernel, grid, dim3(kEpiThreads), (size_t)C * sizeof(float), stream, e);
+    HIP_TRY(hipGetLastError());
+    return VND_OK;
+}
+
+vnd_status vnd_decorrelate_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
+                                   int64_t n, int32_t C, int32_t mode, int32_t ms_encode, int32_t use_width,
+                                   double width, int32_t normalize, float eps, void *workspace,
+                                   int64_t workspace_bytes, void *stream)
+{
+    vnd_status st = vnd_convolve_f32_dev(ctx, t, x, y, batch, n, C, mode, stream);
+    if (st != VND_OK || batch == 0 || n == 0) return st;
+    return launch_epilogue(x, y, batch, n, C, ms_encode, use_width, width, normalize, eps, workspace,
+                           workspace_bytes, (hipStream_t)stream);
+}
+
+vnd_status vnd_decorrelate_f32_host(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
+                                    int64_t n, int32_t C, int32_t mode, int32_t ms_encode, int32_t use_width,
+                                    double width, int32_t normalize, float eps)
+{
+    vnd_status st = check_shape(ctx, t, batch, n, C, mode);
+    if (st != VND_OK) return st;
+    if (batch == 0 || n == 0) return VND_OK;
+    if (!x || !y) return fail(VND_ERR_INVALID, "null signal pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t elems = (size_t)batch * n * C;
+    if (elems > ctx->scratch_elems) {
+        if (ctx->scratch_x) (void)hipFree(ctx->scratch_x);
+        if (ctx->scratch_y) (void)hipFree(ctx->scratch_y);
+        ctx->scratch_x = ctx->scratch_y = nullptr;
+        ctx->scratch_elems = 0;
+        HIP_TRY(hipMalloc((void **)&ctx->scratch_x, elems * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&ctx->scratch_y, elems * sizeof(float)));
+        ctx->scratch_elems = elems;
+    }
+    int64_t ws = 0;
+    vnd_decorrelate_workspace_bytes(batch, n, C, &ws);
+    void *workspace = nullptr;
+    HIP_TRY(hipMalloc(&workspace, (size_t)ws));
+    HIP_TRY(hipMemcpyAsync(ctx->scratch_x, x, elems * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    st = vnd_decorrelate_f32_dev(ctx, t, ctx->scratch_x, ctx->scratch_y, batch, n, C, mode, ms_encode, use_width,
+                                 width, normalize, eps, workspace, ws, ctx->stream);
+    if (st == VND_OK) {
+        hipError_t e = hipMemcpyAsync(y, ctx->scratch_y, elems * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) st = fail(VND_ERR_HIP, "copy back: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(workspace);
+    return st;
 }
 
 #ifdef VND_STAMPS
