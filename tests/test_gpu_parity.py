@@ -160,12 +160,12 @@ def test_reference_equality_tests(vnd):
 
 
 # ---- kernel variants: every tiling must give the same bits ------------------------
-def _variant(r_log2=None, dual=None, cg=0, direct=False):
+def _variant(pairs=None, dual=None, cg=0, direct=False):
     v = 0
-    if r_log2 is not None:
-        v |= r_log2 + 1
+    if pairs is not None:
+        v |= pairs
     if dual is not None:
-        v |= (1 << 5) | (int(dual) << 4)
+        v |= (1 << 5) | (int(dual) << 6)
     v |= cg << 8
     v |= int(direct) << 12
     return v
@@ -185,7 +185,7 @@ def test_variants_agree(vnd, golden, channels, gname):
         for mode in (vnd.MODE_EXACT, vnd.MODE_FMA, vnd.MODE_FAST):
             for direct in (False, True):
                 for cg in ([0] if direct else cgs):
-                    for r in ([None] if direct else range(5)):
+                    for r in ([None] if direct else ((1, 2, 3, 4, 6, 8) if mode == vnd.MODE_FAST else (1, 2, 4, 8, 16))):
                         for dual in ([None] if direct or mode == vnd.MODE_FAST else (0, 1)):
                             ctx.set_variant(_variant(r, dual, cg, direct))
                             y = vnd.convolve_velvet_noise(x, fir, mode=mode)
@@ -206,7 +206,7 @@ def test_class_variants_agree(vnd, golden):
     vn = vnd.VelvetNoise(**_kw(golden.manifest['class_taps'][meta['class']]['kwargs']))
     x = make_input(meta['input'])
     try:
-        for v in (_variant(0, 0, 1), _variant(2, 1, 2), _variant(4, 1, 1), _variant(direct=True)):
+        for v in (_variant(1, 0, 1), _variant(4, 1, 2), _variant(16, 1, 1), _variant(direct=True)):
             ctx.set_variant(v)
             golden.expect('cls_k128_dups', vn.convolve(x))
     finally:
@@ -385,3 +385,22 @@ def test_device_epilogue_batched(vnd, golden):
                             filtered_channels=tuple(range(8))).decorrelate(np.zeros((100, 8), np.float32))
         finally:
             vnd.set_device_epilogue(False)
+
+
+def test_velvet_noise_regeneration_refreshes_device_table(vnd):
+    """Changing a key field regenerates the taps (decorrelation.py:368-379); the cached
+    device table must follow, and an envelope edit must take effect at convolve time."""
+    x = make_input(dict(seed=31, shape=[6000, 2]))
+    vn = vnd.VelvetNoise(sample_rate_hz=44100, seed=1)
+    y30 = vn.convolve(x)
+    assert np.array_equal(y30, O.class_convolve(x, O.generate_class_taps(sample_rate_hz=44100, seed=1),
+                                                (0.85, 0.55, 0.35, 0.2), 2))
+    for k in (20, 24, 28, 30, 26):                       # several regenerations: addresses get recycled
+        vn.num_impulses = k
+        want = O.class_convolve(x, O.generate_class_taps(sample_rate_hz=44100, num_impulses=k, seed=1),
+                                (0.85, 0.55, 0.35, 0.2), 2)
+        assert np.array_equal(vn.convolve(x), want), k
+    vn.segment_envelope = (1.0, 0.5, 0.25, 0.125)        # read at convolve time (decorrelation.py:411-412)
+    want = O.class_convolve(x, O.generate_class_taps(sample_rate_hz=44100, num_impulses=26, seed=1),
+                            (1.0, 0.5, 0.25, 0.125), 2)
+    assert np.array_equal(vn.convolve(x), want)

@@ -9,7 +9,7 @@ import vndecorrelate_amd.decorrelation as vnd
 from vndecorrelate_amd import _native
 from vndecorrelate_amd.taps import function_path_arrays
 ctx = _native.default_context()
-ctx.set_variant(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
+ctx.set_variant(int(sys.argv[1]) if len(sys.argv) > 1 else 4)
 fir = vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1)
 arr = function_path_arrays(fir)
 table = _native.TapTable.create(ctx, arr.tap_offsets, arr.tap_index, arr.tap_weight)

@@ -23,10 +23,10 @@ CONFIGS = {   # fs, fir seconds, taps, kappa, frames, channels, pool
 
 def variant(r_log2=None, dual=None, cg=0, direct=False, nt=0, nostream=0, percu=0):
     v = 0
-    if r_log2 is not None:
-        v |= r_log2 + 1
+    if r_log2 is not None:          # frame pairs per lane (the name is historical)
+        v |= r_log2
     if dual is not None:
-        v |= (1 << 5) | (int(dual) << 4)
+        v |= (1 << 5) | (int(dual) << 6)
     return v | (cg << 8) | (int(direct) << 12) | ({0: 0, 256: 0, 128: 1, 512: 2, 1024: 3}[nt] << 16) | (nostream << 18) | (percu << 20)
 
 
@@ -36,7 +36,7 @@ def main():
     ap.add_argument('--rounds', type=int, default=5)
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--cgs', default='')
-    ap.add_argument('--rs', default='1,2,3,4')
+    ap.add_argument('--rs', default='2,4,8', help='frame pairs per lane to try')
     ap.add_argument('--modes', default='0,1,2')
     ap.add_argument('--direct', action='store_true')
     ap.add_argument('--nts', default='256')
@@ -63,8 +63,6 @@ def main():
         for cg in cgs:
             for r in [int(v) for v in args.rs.split(',')]:
                 for dual in ((0,) if mode == 2 else (0, 1)):
-                    if mode == 2 and r > 3:
-                        continue
                     for nt in ([int(v) for v in args.nts.split(',')] if mode == 2 else [0]):
                         for sv in ([int(v) for v in args.stream.split(',')] if mode == 2 else [0]):
                             cases.append((mode, cg, r, dual, False, nt, sv))
@@ -88,7 +86,7 @@ def main():
         desc = table.describe(pool, n, ch, mode)
         med, mn = float(np.median(results[c])), float(np.min(results[c]))
         gbs = nbytes / med / 1e6
-        print(f'{("exact", "fma  ", "fast ")[mode]} {cg:2d} {(1 << r) if r is not None else 0:5d} '
+        print(f'{("exact", "fma  ", "fast ")[mode]} {cg:2d} {r if r is not None else 0:5d} '
               f'{dual if dual is not None else "-":>4} {int(direct):6d} {med:8.4f} {mn:8.4f} '
               f'{gbs:10.1f} {gbs / 8000:10.4f}   {desc}')
     ctx.set_variant(-1)

@@ -72,7 +72,7 @@ struct vnd_taps {
 // ------------------------------------------------------------------------------
 struct Plan {
     bool direct = false;
-    int nt = 256, cg = 1, r_log2 = 0, dual = 0;
+    int nt = 256, cg = 1, r = 1, dual = 0;      // r = frame pairs per lane; tile = 2 * nt * r frames
     int W = 0;
     size_t lds_bytes = 0;
     uint32_t nblocks = 0;
@@ -84,75 +84,88 @@ typedef void (*kern_t)(const KArgs);
 constexpr int kOrderedThreads = 256;
 
 template <int CG, int MODE, bool DUAL>
-static kern_t ordered_by_r(int r_log2)
+static kern_t ordered_by_r(int r)
 {
-    switch (r_log2) {
-    case 0: return conv_ordered_kernel<kOrderedThreads, CG, 1, MODE, DUAL>;
-    case 1: return conv_ordered_kernel<kOrderedThreads, CG, 2, MODE, DUAL>;
-    case 2: return conv_ordered_kernel<kOrderedThreads, CG, 4, MODE, DUAL>;
-    case 3: return conv_ordered_kernel<kOrderedThreads, CG, 8, MODE, DUAL>;
-    default: return conv_ordered_kernel<kOrderedThreads, CG, 16, MODE, DUAL>;
+    switch (r) {
+    case 1: return conv_ordered_kernel<kOrderedThreads, CG, 1, MODE, DUAL>;
+    case 2: return conv_ordered_kernel<kOrderedThreads, CG, 2, MODE, DUAL>;
+    case 4: return conv_ordered_kernel<kOrderedThreads, CG, 4, MODE, DUAL>;
+    case 8: return conv_ordered_kernel<kOrderedThreads, CG, 8, MODE, DUAL>;
+    case 16: return conv_ordered_kernel<kOrderedThreads, CG, 16, MODE, DUAL>;
+    default: return nullptr;
     }
 }
 
 template <int CG>
-static kern_t ordered_by_mode(int r_log2, int mode, int dual)
+static kern_t ordered_by_mode(int r, int mode, int dual)
 {
     if (mode == VND_MODE_EXACT)
-        return dual ? ordered_by_r<CG, 0, true>(r_log2) : ordered_by_r<CG, 0, false>(r_log2);
-    return dual ? ordered_by_r<CG, 1, true>(r_log2) : ordered_by_r<CG, 1, false>(r_log2);
+        return dual ? ordered_by_r<CG, 0, true>(r) : ordered_by_r<CG, 0, false>(r);
+    return dual ? ordered_by_r<CG, 1, true>(r) : ordered_by_r<CG, 1, false>(r);
 }
 
-static kern_t ordered_kernel(int cg, int r_log2, int mode, int dual)
+static kern_t ordered_kernel(int cg, int r, int mode, int dual)
 {
     switch (cg) {
-    case 1: return ordered_by_mode<1>(r_log2, mode, dual);
-    case 2: return ordered_by_mode<2>(r_log2, mode, dual);
-    default: return ordered_by_mode<4>(r_log2, mode, dual);
+    case 1: return ordered_by_mode<1>(r, mode, dual);
+    case 2: return ordered_by_mode<2>(r, mode, dual);
+    default: return ordered_by_mode<4>(r, mode, dual);
     }
 }
 
 template <int NT, int CG>
-static kern_t fast_by_r(int r_log2)
+static kern_t fast_by_r(int r)
 {
-    switch (r_log2) {
-    case 0: return conv_fast_kernel<NT, CG, 1>;
-    case 1: return conv_fast_kernel<NT, CG, 2>;
-    case 2: return conv_fast_kernel<NT, CG, 4>;
-    default: return conv_fast_kernel<NT, CG, 8>;
+    switch (r) {
+    case 1: return conv_fast_kernel<NT, CG, 1>;
+    case 2: return conv_fast_kernel<NT, CG, 2>;
+    case 3: return conv_fast_kernel<NT, CG, 3>;
+    case 4: return conv_fast_kernel<NT, CG, 4>;
+    case 6: return conv_fast_kernel<NT, CG, 6>;
+    case 8: return conv_fast_kernel<NT, CG, 8>;
+    default: return nullptr;
     }
 }
 
 template <int NT>
-static kern_t fast_by_cg(int cg, int r_log2)
+static kern_t fast_by_cg(int cg, int r)
 {
     switch (cg) {
-    case 1: return fast_by_r<NT, 1>(r_log2);
-    case 2: return fast_by_r<NT, 2>(r_log2);
-    default: return fast_by_r<NT, 4>(r_log2);
+    case 1: return fast_by_r<NT, 1>(r);
+    case 2: return fast_by_r<NT, 2>(r);
+    default: return fast_by_r<NT, 4>(r);
     }
 }
 
-static kern_t fast_kernel(int nt, int cg, int r_log2)
+static kern_t fast_kernel(int nt, int cg, int r)
 {
     switch (nt) {
-    case 128: return fast_by_cg<128>(cg, r_log2);
-    case 256: return fast_by_cg<256>(cg, r_log2);
-    case 512: return fast_by_cg<512>(cg, r_log2);
-    default: return fast_by_cg<1024>(cg, r_log2);
+    case 128: return fast_by_cg<128>(cg, r);
+    case 256: return fast_by_cg<256>(cg, r);
+    case 512: return fast_by_cg<512>(cg, r);
+    default: return fast_by_cg<1024>(cg, r);
     }
+}
+
+static kern_t pick_kernel(const Plan &p, int mode)
+{
+    return mode == VND_MODE_FAST ? fast_kernel(p.nt, p.cg, p.r) : ordered_kernel(p.cg, p.r, mode, p.dual);
 }
 
 static int halo_of(int max_index) { return (max_index + 2 + 15) & ~15; }
 
-static size_t lds_need(int nt, int cg, int r_log2, int dual, int max_index)
+static size_t lds_need(int nt, int cg, int r, int dual, int max_index)
 {
-    const size_t T = (size_t)2 * nt << r_log2;
+    const size_t T = (size_t)2 * nt * r;
     return (size_t)(dual ? 2 : 1) * cg * (T + halo_of(max_index)) * sizeof(float);
 }
 
-// variant word (vnd_set_variant): bits 0-3 r_log2+1 (0 = auto), bit 4 dual,
-// bit 5 "dual given", bits 8-11 channels per workgroup (0 = auto), bit 12 direct,
+// Tile sizes a mode supports, largest first (frame pairs per lane).
+static const int kFastR[] = {8, 6, 4, 3, 2, 1};
+static const int kOrderedR[] = {16, 8, 4, 2, 1};
+
+// variant word (vnd_set_variant): bits 0-4 frame pairs per lane (0 = auto), bit 5 "dual given",
+// bit 6 dual, bits 8-11 channels per workgroup (0 = auto), bit 12 direct,
 // bits 16-17 threads per workgroup of the fast kernel (0: 256, 1: 128, 2: 512, 3: 1024).
 static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64_t n, int C, int mode)
 {
@@ -164,49 +177,57 @@ static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int6
     int cg = (v >= 0 && ((v >> 8) & 15)) ? ((v >> 8) & 15) : 0;
     if (cg == 0) cg = (C % 2 == 0) ? 2 : 1;
     if (C % cg != 0 || (cg != 1 && cg != 2 && cg != 4)) cg = 1;
-    int dual = (v >= 0 && ((v >> 5) & 1)) ? ((v >> 4) & 1) : 0;
+    int dual = (v >= 0 && ((v >> 5) & 1)) ? ((v >> 6) & 1) : 0;
     if (fast) dual = 0;
-    int r_log2 = (v >= 0 && (v & 15)) ? (v & 15) - 1 : -1;
     int nt = kOrderedThreads;
     if (fast) {
         const int sel = v >= 0 ? ((v >> 16) & 3) : 0;
         nt = sel == 1 ? 128 : sel == 2 ? 512 : sel == 3 ? 1024 : 256;
     }
-    const int r_max = fast ? 3 : 4;
-
+    const int *sizes = fast ? kFastR : kOrderedR;
+    const int nsizes = fast ? (int)(sizeof kFastR / sizeof *kFastR) : (int)(sizeof kOrderedR / sizeof *kOrderedR);
     const size_t limit = (size_t)ctx->lds_limit;
-    if (r_log2 < 0) {
-        // Largest tile that still gives every CU several workgroups, within an
-        // LDS budget that keeps several workgroups resident per CU.
+    auto fits = [&](int r_) { return lds_need(nt, cg, r_, dual, t->max_index) <= limit; };
+
+    int r = (v >= 0) ? (v & 31) : 0;
+    if (r != 0) {
+        bool known = false;
+        for (int i = 0; i < nsizes; ++i) known |= sizes[i] == r;
+        if (!known) r = 0;
+    }
+    if (r == 0) {
+        // 4 pairs per lane (tile 2048) measured best wherever it leaves every CU >= 6 workgroups
+        // (LDS-bound residency); smaller tiles for small problems, so the grid still fills the chip.
+        r = 1;
         const size_t budget = limit / 4;
-        r_log2 = 2;
-        while (r_log2 > 0) {
-            const int64_t T = (int64_t)2 * nt << r_log2;
+        for (int i = 0; i < nsizes; ++i) {
+            if (sizes[i] > 4) continue;
+            const int64_t T = (int64_t)2 * nt * sizes[i];
             const int64_t blocks = batch * ((n + T - 1) / T) * (C / cg);
-            if (blocks >= (int64_t)cus * 6 && lds_need(nt, cg, r_log2, dual, t->max_index) <= budget) break;
-            --r_log2;
+            if (blocks >= (int64_t)cus * 6 && lds_need(nt, cg, sizes[i], dual, t->max_index) <= budget) { r = sizes[i]; break; }
         }
     }
-    if (r_log2 > r_max) r_log2 = r_max;
     // shrink until the tile fits one workgroup's LDS at all
-    while (lds_need(nt, cg, r_log2, dual, t->max_index) > limit) {
-        if (dual) dual = 0;
-        else if (cg > 1) cg /= 2;
-        else if (r_log2 > 0) --r_log2;
-        else if (nt > 128 && fast) nt /= 2;
-        else break;
+    while (!fits(r)) {
+        if (dual) { dual = 0; continue; }
+        if (cg > 1) { cg /= 2; continue; }
+        int smaller = 0;
+        for (int i = 0; i < nsizes; ++i) if (sizes[i] < r) { smaller = sizes[i]; break; }
+        if (smaller) { r = smaller; continue; }
+        if (nt > 128 && fast) { nt /= 2; continue; }
+        break;
     }
-    if (force_direct || lds_need(nt, cg, r_log2, dual, t->max_index) > limit) {
+    if (force_direct || !fits(r)) {
         p.direct = true;
         const int64_t total = batch * n * C;
         int64_t blocks = (total + kDirectThreads - 1) / kDirectThreads;
         p.nblocks = (uint32_t)std::min<int64_t>(std::max<int64_t>(blocks, 1), (int64_t)cus * 32);
         return p;
     }
-    const int64_t T = (int64_t)2 * nt << r_log2;
-    p.nt = nt; p.cg = cg; p.r_log2 = r_log2; p.dual = dual;
+    const int64_t T = (int64_t)2 * nt * r;
+    p.nt = nt; p.cg = cg; p.r = r; p.dual = dual;
     p.W = (int)T + halo_of(t->max_index);
-    p.lds_bytes = lds_need(nt, cg, r_log2, dual, t->max_index);
+    p.lds_bytes = lds_need(nt, cg, r, dual, t->max_index);
     p.tiles = (int)((n + T - 1) / T);
     p.groups = C / cg;
     p.nblocks = (uint32_t)(batch * p.tiles * p.groups);
@@ -248,11 +269,16 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
         if ((int64_t)batch * p.tiles * p.groups > 0x7fffffffLL)
             return fail(VND_ERR_UNSUPPORTED, "grid too large; split the batch");
         a.tiles = p.tiles; a.groups = p.groups; a.W = p.W;
-        kern_t k = mode == VND_MODE_FAST ? fast_kernel(p.nt, p.cg, p.r_log2)
-                                         : ordered_kernel(p.cg, p.r_log2, mode, p.dual);
-        if (p.lds_bytes > 65536)
-            HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)p.lds_bytes));
+        kern_t k = pick_kernel(p, mode);
+        if (!k) return fail(VND_ERR_UNSUPPORTED, "no kernel for this tile shape");
+        if (p.lds_bytes > 65536) {           // opt in to > 64 KiB of dynamic LDS, once per kernel
+            static thread_local std::vector<const void *> raised;
+            if (std::find(raised.begin(), raised.end(), (const void *)k) == raised.end()) {
+                HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            ctx->lds_limit));
+                raised.push_back((const void *)k);
+            }
+        }
         hipLaunchKernelGGL(k, dim3(p.nblocks), dim3(p.nt), p.lds_bytes, stream, a);
     }
     HIP_TRY(hipGetLastError());
@@ -608,8 +634,8 @@ vnd_status vnd_describe_launch(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, i
     else
         snprintf(text, (size_t)len,
                  "%s cg=%d pairs_per_lane=%d tile=%d halo=%d dual=%d mode=%d lds=%zuB workgroups=%u threads=%d",
-                 mode == VND_MODE_FAST ? "conv_fast" : "conv_ordered", p.cg, 1 << p.r_log2, (2 * p.nt) << p.r_log2,
-                 p.W - ((2 * p.nt) << p.r_log2), p.dual, mode, p.lds_bytes, p.nblocks, p.nt);
+                 mode == VND_MODE_FAST ? "conv_fast" : "conv_ordered", p.cg, p.r, 2 * p.nt * p.r,
+                 p.W - 2 * p.nt * p.r, p.dual, mode, p.lds_bytes, p.nblocks, p.nt);
     return VND_OK;
 }
 

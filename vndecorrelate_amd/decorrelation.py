@@ -365,7 +365,7 @@ class VelvetNoise(Decorrelator):
     seed: Optional[int] = None
 
     _velvet_noise: Any = field(default=None, repr=False, compare=False)
-    _device: Any = field(default=None, repr=False, compare=False)   # (key, TapTable)
+    _device: Any = field(default=None, repr=False, compare=False)   # (impulse table, envelope key, device, TapTable)
 
     def __post_init__(self) -> None:
         if self.num_impulses >= self.fir_length_samples * 0.2:
@@ -446,18 +446,22 @@ class VelvetNoise(Decorrelator):
         return class_path_arrays(channels, self.segment_envelope, apply_gain)
 
     def _device_table(self) -> _native.TapTable:
+        """Device image of the current impulse table + envelope, uploaded once.  The
+        cache holds the impulse-table OBJECT (compared with ``is``), not its id: a
+        regenerated table may be allocated at a freed table's address."""
         vn = self.velvet_noise
         env = self.segment_envelope
-        key = (id(vn), tuple(env) if not isinstance(env, tuple) else env, type(env).__name__,
-               _native.default_context().device)
-        if self._device is None or self._device[0] != key:
+        env_key = (type(env).__name__, tuple(env))
+        device = _native.default_context().device
+        cached = self._device
+        if cached is None or cached[0] is not vn or cached[1] != env_key or cached[2] != device:
             arrays = self._tap_arrays()
-            if self._device is not None:
-                self._device[1].close()
-            self._device = (key, _native.TapTable.create(
-                _native.default_context(), arrays.tap_offsets, arrays.tap_index,
-                arrays.tap_weight, **arrays.kwargs()))
-        return self._device[1]
+            if cached is not None:
+                cached[3].close()
+            table = _native.TapTable.create(_native.default_context(), arrays.tap_offsets, arrays.tap_index,
+                                            arrays.tap_weight, **arrays.kwargs())
+            self._device = cached = (vn, env_key, device, table)
+        return cached[3]
 
     def convolve(self, input_signal: NDArray) -> NDArray:
         """Velvet-noise filter every ``filtered_channel`` of a ``(n, >= num_outs)``
