@@ -25,8 +25,6 @@ def variant(r_log2=None, dual=None, cg=0, direct=False, nt=0, nostream=0, percu=
     v = 0
     if r_log2 is not None:          # frame pairs per lane (the name is historical)
         v |= r_log2
-    if dual is not None:
-        v |= (1 << 5) | (int(dual) << 6)
     return v | (cg << 8) | (int(direct) << 12) | ({0: 0, 256: 0, 128: 1, 512: 2, 1024: 3}[nt] << 16) | (nostream << 18) | (percu << 20)
 
 
@@ -62,7 +60,7 @@ def main():
     for mode in [int(m) for m in args.modes.split(',')]:
         for cg in cgs:
             for r in [int(v) for v in args.rs.split(',')]:
-                for dual in ((0,) if mode == 2 else (0, 1)):
+                for dual in (0,):
                     for nt in ([int(v) for v in args.nts.split(',')] if mode == 2 else [0]):
                         for sv in ([int(v) for v in args.stream.split(',')] if mode == 2 else [0]):
                             cases.append((mode, cg, r, dual, False, nt, sv))

@@ -60,7 +60,7 @@ struct vnd_taps {
     std::vector<uint8_t> flags;
     // device image
     Tap *d_taps = nullptr;
-    FastTap *d_taps_fast = nullptr;
+    FastTap *d_taps_fast = nullptr, *d_taps_ord = nullptr;
     int32_t *d_fast_off = nullptr, *d_fast_even = nullptr;
     int32_t *d_tap_off = nullptr, *d_seg_off = nullptr, *d_seg_end = nullptr;
     float *d_seg_gain = nullptr;
@@ -72,7 +72,7 @@ struct vnd_taps {
 // ------------------------------------------------------------------------------
 struct Plan {
     bool direct = false;
-    int nt = 256, cg = 1, r = 1, dual = 0;      // r = frame pairs per lane; tile = 2 * nt * r frames
+    int nt = 256, cg = 1, r = 1;                // r = frame pairs per lane; tile = 2 * nt * r frames
     int W = 0;
     size_t lds_bytes = 0;
     uint32_t nblocks = 0;
@@ -83,33 +83,25 @@ typedef void (*kern_t)(const KArgs);
 
 constexpr int kOrderedThreads = 256;
 
-template <int CG, int MODE, bool DUAL>
+template <int CG, int MODE>
 static kern_t ordered_by_r(int r)
 {
     switch (r) {
-    case 1: return conv_ordered_kernel<kOrderedThreads, CG, 1, MODE, DUAL>;
-    case 2: return conv_ordered_kernel<kOrderedThreads, CG, 2, MODE, DUAL>;
-    case 4: return conv_ordered_kernel<kOrderedThreads, CG, 4, MODE, DUAL>;
-    case 8: return conv_ordered_kernel<kOrderedThreads, CG, 8, MODE, DUAL>;
-    case 16: return conv_ordered_kernel<kOrderedThreads, CG, 16, MODE, DUAL>;
+    case 1: return conv_ordered_kernel<kOrderedThreads, CG, 1, MODE>;
+    case 2: return conv_ordered_kernel<kOrderedThreads, CG, 2, MODE>;
+    case 4: return conv_ordered_kernel<kOrderedThreads, CG, 4, MODE>;
+    case 8: return conv_ordered_kernel<kOrderedThreads, CG, 8, MODE>;
     default: return nullptr;
     }
 }
 
-template <int CG>
-static kern_t ordered_by_mode(int r, int mode, int dual)
+static kern_t ordered_kernel(int cg, int r, int mode)
 {
-    if (mode == VND_MODE_EXACT)
-        return dual ? ordered_by_r<CG, 0, true>(r) : ordered_by_r<CG, 0, false>(r);
-    return dual ? ordered_by_r<CG, 1, true>(r) : ordered_by_r<CG, 1, false>(r);
-}
-
-static kern_t ordered_kernel(int cg, int r, int mode, int dual)
-{
+    const bool exact = mode == VND_MODE_EXACT;
     switch (cg) {
-    case 1: return ordered_by_mode<1>(r, mode, dual);
-    case 2: return ordered_by_mode<2>(r, mode, dual);
-    default: return ordered_by_mode<4>(r, mode, dual);
+    case 1: return exact ? ordered_by_r<1, 0>(r) : ordered_by_r<1, 1>(r);
+    case 2: return exact ? ordered_by_r<2, 0>(r) : ordered_by_r<2, 1>(r);
+    default: return exact ? ordered_by_r<4, 0>(r) : ordered_by_r<4, 1>(r);
     }
 }
 
@@ -149,23 +141,23 @@ static kern_t fast_kernel(int nt, int cg, int r)
 
 static kern_t pick_kernel(const Plan &p, int mode)
 {
-    return mode == VND_MODE_FAST ? fast_kernel(p.nt, p.cg, p.r) : ordered_kernel(p.cg, p.r, mode, p.dual);
+    return mode == VND_MODE_FAST ? fast_kernel(p.nt, p.cg, p.r) : ordered_kernel(p.cg, p.r, mode);
 }
 
 static int halo_of(int max_index) { return (max_index + 2 + 15) & ~15; }
 
-static size_t lds_need(int nt, int cg, int r, int dual, int max_index)
+static size_t lds_need(int nt, int cg, int r, int max_index)
 {
     const size_t T = (size_t)2 * nt * r;
-    return (size_t)(dual ? 2 : 1) * cg * (T + halo_of(max_index)) * sizeof(float);
+    return (size_t)cg * (T + halo_of(max_index)) * sizeof(float);
 }
 
 // Tile sizes a mode supports, largest first (frame pairs per lane).
 static const int kFastR[] = {8, 6, 4, 3, 2, 1};
-static const int kOrderedR[] = {16, 8, 4, 2, 1};
+static const int kOrderedR[] = {8, 4, 2, 1};
 
-// variant word (vnd_set_variant): bits 0-4 frame pairs per lane (0 = auto), bit 5 "dual given",
-// bit 6 dual, bits 8-11 channels per workgroup (0 = auto), bit 12 direct,
+// variant word (vnd_set_variant): bits 0-4 frame pairs per lane (0 = auto),
+// bits 8-11 channels per workgroup (0 = auto), bit 12 direct,
 // bits 16-17 threads per workgroup of the fast kernel (0: 256, 1: 128, 2: 512, 3: 1024).
 static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64_t n, int C, int mode)
 {
@@ -177,8 +169,6 @@ static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int6
     int cg = (v >= 0 && ((v >> 8) & 15)) ? ((v >> 8) & 15) : 0;
     if (cg == 0) cg = (C % 2 == 0) ? 2 : 1;
     if (C % cg != 0 || (cg != 1 && cg != 2 && cg != 4)) cg = 1;
-    int dual = (v >= 0 && ((v >> 5) & 1)) ? ((v >> 6) & 1) : 0;
-    if (fast) dual = 0;
     int nt = kOrderedThreads;
     if (fast) {
         const int sel = v >= 0 ? ((v >> 16) & 3) : 0;
@@ -187,7 +177,7 @@ static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int6
     const int *sizes = fast ? kFastR : kOrderedR;
     const int nsizes = fast ? (int)(sizeof kFastR / sizeof *kFastR) : (int)(sizeof kOrderedR / sizeof *kOrderedR);
     const size_t limit = (size_t)ctx->lds_limit;
-    auto fits = [&](int r_) { return lds_need(nt, cg, r_, dual, t->max_index) <= limit; };
+    auto fits = [&](int r_) { return lds_need(nt, cg, r_, t->max_index) <= limit; };
 
     int r = (v >= 0) ? (v & 31) : 0;
     if (r != 0) {
@@ -204,12 +194,11 @@ static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int6
             if (sizes[i] > 4) continue;
             const int64_t T = (int64_t)2 * nt * sizes[i];
             const int64_t blocks = batch * ((n + T - 1) / T) * (C / cg);
-            if (blocks >= (int64_t)cus * 6 && lds_need(nt, cg, sizes[i], dual, t->max_index) <= budget) { r = sizes[i]; break; }
+            if (blocks >= (int64_t)cus * 6 && lds_need(nt, cg, sizes[i], t->max_index) <= budget) { r = sizes[i]; break; }
         }
     }
     // shrink until the tile fits one workgroup's LDS at all
     while (!fits(r)) {
-        if (dual) { dual = 0; continue; }
         if (cg > 1) { cg /= 2; continue; }
         int smaller = 0;
         for (int i = 0; i < nsizes; ++i) if (sizes[i] < r) { smaller = sizes[i]; break; }
@@ -225,9 +214,9 @@ static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int6
         return p;
     }
     const int64_t T = (int64_t)2 * nt * r;
-    p.nt = nt; p.cg = cg; p.r = r; p.dual = dual;
+    p.nt = nt; p.cg = cg; p.r = r;
     p.W = (int)T + halo_of(t->max_index);
-    p.lds_bytes = lds_need(nt, cg, r, dual, t->max_index);
+    p.lds_bytes = lds_need(nt, cg, r, t->max_index);
     p.tiles = (int)((n + T - 1) / T);
     p.groups = C / cg;
     p.nblocks = (uint32_t)(batch * p.tiles * p.groups);
@@ -254,7 +243,7 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
     if (batch == 0 || n == 0) return VND_OK;
     const Plan p = make_plan(ctx, t, batch, n, C, mode);
     KArgs a{};
-    a.x = x; a.y = y; a.taps = t->d_taps; a.taps_fast = t->d_taps_fast; a.fast_off = t->d_fast_off; a.fast_even = t->d_fast_even; a.tap_off = t->d_tap_off;
+    a.x = x; a.y = y; a.taps = t->d_taps; a.taps_fast = t->d_taps_fast; a.taps_ord = t->d_taps_ord; a.fast_off = t->d_fast_off; a.fast_even = t->d_fast_even; a.tap_off = t->d_tap_off;
     a.seg_off = t->has_seg ? t->d_seg_off : nullptr;
     a.seg_end = t->d_seg_end; a.seg_gain = t->d_seg_gain;
     a.chan_flags = t->has_flags ? t->d_flags : nullptr;
@@ -289,6 +278,7 @@ static void free_taps_dev(vnd_taps *t)
 {
     if (t->d_taps) (void)hipFree(t->d_taps);
     if (t->d_taps_fast) (void)hipFree(t->d_taps_fast);
+    if (t->d_taps_ord) (void)hipFree(t->d_taps_ord);
     if (t->d_fast_off) (void)hipFree(t->d_fast_off);
     if (t->d_fast_even) (void)hipFree(t->d_fast_even);
     if (t->d_tap_off) (void)hipFree(t->d_tap_off);
@@ -462,6 +452,11 @@ vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, 
         fast.resize(fast.size() + 16, FastTap{0.0f, 0});
     }
     if (e == hipSuccess) e = upload(&t->d_taps_fast, fast.data(), fast.size());
+    {   // ordered image: table order, weight first (SGPR pair layout), byte offsets, padded
+        std::vector<FastTap> ord((size_t)total + 16, FastTap{0.0f, 0});
+        for (int32_t k = 0; k < total; ++k) ord[k] = FastTap{tap_weight[k], tap_index[k] * 4};
+        if (e == hipSuccess) e = upload(&t->d_taps_ord, ord.data(), ord.size());
+    }
     if (e == hipSuccess) e = upload(&t->d_fast_off, fast_off.data(), fast_off.size());
     if (e == hipSuccess) e = upload(&t->d_fast_even, fast_even.data(), fast_even.size());
     if (e == hipSuccess) e = upload(&t->d_tap_off, t->tap_off.data(), t->tap_off.size());
@@ -633,9 +628,9 @@ vnd_status vnd_describe_launch(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, i
         snprintf(text, (size_t)len, "conv_direct mode=%d blocks=%u threads=%d", mode, p.nblocks, kDirectThreads);
     else
         snprintf(text, (size_t)len,
-                 "%s cg=%d pairs_per_lane=%d tile=%d halo=%d dual=%d mode=%d lds=%zuB workgroups=%u threads=%d",
+                 "%s cg=%d pairs_per_lane=%d tile=%d halo=%d mode=%d lds=%zuB workgroups=%u threads=%d",
                  mode == VND_MODE_FAST ? "conv_fast" : "conv_ordered", p.cg, p.r, 2 * p.nt * p.r,
-                 p.W - 2 * p.nt * p.r, p.dual, mode, p.lds_bytes, p.nblocks, p.nt);
+                 p.W - 2 * p.nt * p.r, mode, p.lds_bytes, p.nblocks, p.nt);
     return VND_OK;
 }
 

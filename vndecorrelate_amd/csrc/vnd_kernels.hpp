@@ -53,6 +53,7 @@ struct KArgs {
     float *__restrict__ y;
     const Tap *__restrict__ taps;
     const FastTap *__restrict__ taps_fast;  // fast mode: per channel [even taps | odd taps], zero-padded
+    const FastTap *__restrict__ taps_ord;   // ordered modes: table order, {w, idx * 4}, zero-padded
     const int32_t *__restrict__ fast_off;   // [C+1] start of each channel's list in taps_fast
     const int32_t *__restrict__ fast_even;  // [C]   number of even-offset taps (the odd ones follow)
     const int32_t *__restrict__ tap_off;    // [C+1]
@@ -244,23 +245,15 @@ __device__ __forceinline__ void store_pair(v4i rdst, int q, int strideG, int C, 
 #endif
 constexpr int kStageDepth = VND_STAGE_DEPTH;
 
-template <int CG, bool DUAL>
-__device__ __forceinline__ void write_pair(float *planeA, float *planeB, int W, int f,
-                                           const float (&v)[2 * CG])
+template <int CG>
+__device__ __forceinline__ void write_pair(float *plane, int W, int f, const float (&v)[2 * CG])
 {
 #pragma unroll
-    for (int c = 0; c < CG; ++c) {
-        *(float2 *)(planeA + c * W + f) = make_float2(v[c], v[CG + c]);
-        if constexpr (DUAL) {
-            // B[m] = A[m+1]: frame f lands on slot f-1, frame f+1 on slot f
-            if (f > 0) planeB[c * W + f - 1] = v[c];
-            planeB[c * W + f] = v[CG + c];
-        }
-    }
+    for (int c = 0; c < CG; ++c) *(float2 *)(plane + c * W + f) = make_float2(v[c], v[CG + c]);
 }
 
-template <int NT, int CG, bool DUAL, int SHAPE>
-__device__ __forceinline__ void stage_window_shape(float *planeA, float *planeB, v4i rsrc, int C, int W, int tid)
+template <int NT, int CG, int SHAPE>
+__device__ __forceinline__ void stage_window_shape(float *plane, v4i rsrc, int C, int W, int tid)
 {
     const int npairs = W >> 1;
     const int strideG = C / CG;
@@ -275,20 +268,20 @@ __device__ __forceinline__ void stage_window_shape(float *planeA, float *planeB,
             load_pair<CG, SHAPE>(rsrc, q[u], strideG, C, v[u]);   // in range, or zero-filled by the descriptor
         }
 #pragma unroll
-        for (int u = 0; u < kStageDepth; ++u) write_pair<CG, DUAL>(planeA, planeB, W, 2 * q[u], v[u]);
+        for (int u = 0; u < kStageDepth; ++u) write_pair<CG>(plane, W, 2 * q[u], v[u]);
     }
 }
 
 // src = this block's first sample; bytes_left = bytes from there to the end of the stream
-template <int NT, int CG, bool DUAL>
-__device__ __forceinline__ void stage_window(float *planeA, float *planeB, const float *src,
-                                             int64_t bytes_left, int C, int W, int tid)
+template <int NT, int CG>
+__device__ __forceinline__ void stage_window(float *plane, const float *src, int64_t bytes_left, int C, int W,
+                                             int tid)
 {
     const v4i rsrc = make_rsrc(src, bytes_left);
     const int shape = access_shape<CG>(src, C);          // workgroup-uniform
-    if (shape == kPair)       stage_window_shape<NT, CG, DUAL, kPair>(planeA, planeB, rsrc, C, W, tid);
-    else if (shape == kFrame) stage_window_shape<NT, CG, DUAL, kFrame>(planeA, planeB, rsrc, C, W, tid);
-    else                      stage_window_shape<NT, CG, DUAL, kDword>(planeA, planeB, rsrc, C, W, tid);
+    if (shape == kPair)       stage_window_shape<NT, CG, kPair>(plane, rsrc, C, W, tid);
+    else if (shape == kFrame) stage_window_shape<NT, CG, kFrame>(plane, rsrc, C, W, tid);
+    else                      stage_window_shape<NT, CG, kDword>(plane, rsrc, C, W, tid);
 }
 
 // One (frame pair, CG channels) result per lane and j: v[c] = frame 2q, v[CG+c] = frame 2q+1.
@@ -303,149 +296,9 @@ __device__ __forceinline__ void store_result(v4i rdst, int shape, int q, int str
 }
 
 // ---- LDS reads ---------------------------------------------------------------------
-// One aligned ds_read_b64, compiler-tracked.  Volatile on purpose: hipcc otherwise
-// fuses neighbouring pairs into ds_read2st64_b64 / ds_read2_b32, which move half
-// the bytes per LDS cycle of plain ds_read_b64 (MI355X LDS table: 128 vs 256 B/clk).
-__device__ __forceinline__ v2f lds_pair(const float *p)
-{
-    typedef __attribute__((address_space(3))) const volatile v2f *lds_v2f_ptr;
-    return *(lds_v2f_ptr)p;
-}
-
 __device__ __forceinline__ unsigned lds_addr(const float *p)
 {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)p;
-}
-
-// =====================================================================================
-// Ordered kernel: taps in table order, the reference's association.
-//   MODE 0  acc = f32(acc + f32(x*w))   bit-identical to NumPy's  out += x * w
-//   MODE 1  acc = fma(x, w, acc)
-// Odd tap offsets are 4-byte-misaligned for a b64 pair: DUAL keeps a second plane
-// shifted by one frame, !DUAL straddles the pair with two aligned reads.
-// Tap records: a wave parks 64 of them in two VGPRs (lane l <-> tap l) and
-// broadcasts one per step with v_readlane.
-// =====================================================================================
-template <int MODE>
-__device__ __forceinline__ float tap_op(float acc, float v, float w)
-{
-    if constexpr (MODE == 0) {
-        float p = v * w;          // file is built with -ffp-contract=off: two roundings
-        return acc + p;
-    } else {
-        return __builtin_fmaf(v, w, acc);
-    }
-}
-
-template <int NT, int CG, int R, int MODE, bool DUAL>
-__global__ __launch_bounds__(NT) void conv_ordered_kernel(const KArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int T = 2 * NT * R;
-    const int tid = threadIdx.x;
-    const int W = a.W;
-    const BlockCoord bc = decode_block(a);
-    const int C = a.C;
-    const int c0 = bc.group * CG;
-    const int64_t t0 = (int64_t)bc.tile * T;
-    const float *__restrict__ xs = a.x + bc.stream * a.n * C;
-    float *__restrict__ ys = a.y + bc.stream * a.n * C;
-    const int64_t bytes_left = ((a.n - t0) * C - c0) * 4;
-
-    float *planeA = lds;                       // [CG][W]   dword m = x[t0 + m]
-    float *planeB = lds + (DUAL ? CG * W : 0); // [CG][W]   dword m = x[t0 + m + 1]
-    stage_window<NT, CG, DUAL>(planeA, planeB, xs + t0 * C + c0, bytes_left, C, W, tid);
-    __syncthreads();
-
-    float2 out[CG][R];
-    const int lane = tid & 63;
-    const int lane_base = 2 * tid;
-    const bool has_seg = a.seg_off != nullptr;
-
-#pragma unroll
-    for (int c = 0; c < CG; ++c) {
-        const int ch = c0 + c;
-        const float *pa = planeA + c * W + lane_base;
-        if (a.chan_flags != nullptr && (a.chan_flags[ch] & 1)) {      // unfiltered: copy through
-#pragma unroll
-            for (int j = 0; j < R; ++j) out[c][j] = *(const float2 *)(pa + 2 * NT * j);
-            continue;
-        }
-#pragma unroll
-        for (int j = 0; j < R; ++j) out[c][j] = make_float2(0.0f, 0.0f);
-
-        int k = a.tap_off[ch];
-        const int k_last = a.tap_off[ch + 1];
-        const int s_begin = has_seg ? a.seg_off[ch] : 0;
-        const int nseg = has_seg ? a.seg_off[ch + 1] - s_begin : 1;
-        int chunk = k;                      // first tap held in the VGPR chunk
-        int tv_off = 0;
-        float tv_w = 0.0f;
-        auto load_chunk = [&](int base) {
-            const int kk = base + lane;
-            Tap t;
-            t.idx = 0; t.w = 0.0f;
-            if (kk < k_last) t = a.taps[kk];
-            // DUAL: odd offsets read the shifted plane (CG*W floats further) at an even slot
-            tv_off = (DUAL && (t.idx & 1)) ? CG * W + t.idx - 1 : t.idx;
-            tv_w = t.w;
-        };
-        load_chunk(chunk);
-        for (int s = 0; s < nseg; ++s) {
-            const int kend = has_seg ? a.seg_end[s_begin + s] : k_last;
-            float2 sb[R];
-#pragma unroll
-            for (int j = 0; j < R; ++j) sb[j] = make_float2(0.0f, 0.0f);
-            for (; k < kend; ++k) {
-                if (k - chunk >= 64) { chunk += 64; load_chunk(chunk); }
-                const int off = __builtin_amdgcn_readlane(tv_off, k - chunk);
-                const float w = __builtin_bit_cast(float,
-                    __builtin_amdgcn_readlane(__builtin_bit_cast(int, tv_w), k - chunk));
-                if (DUAL || (off & 1) == 0) {
-                    const float *p = pa + off;
-#pragma unroll
-                    for (int j = 0; j < R; ++j) {
-                        const v2f v = lds_pair(p + 2 * NT * j);
-                        sb[j].x = tap_op<MODE>(sb[j].x, v.x, w);
-                        sb[j].y = tap_op<MODE>(sb[j].y, v.y, w);
-                    }
-                } else {
-                    const float *p = pa + (off - 1);     // two aligned pairs straddle ours
-#pragma unroll
-                    for (int j = 0; j < R; ++j) {
-                        const v2f lo = lds_pair(p + 2 * NT * j);
-                        const v2f hi = lds_pair(p + 2 * NT * j + 2);
-                        sb[j].x = tap_op<MODE>(sb[j].x, lo.y, w);
-                        sb[j].y = tap_op<MODE>(sb[j].y, hi.x, w);
-                    }
-                }
-            }
-            if (has_seg) {          // class path: seg *= envelope (unless identity); out += seg
-                if (a.apply_gain) {
-                    const float gain = a.seg_gain[s_begin + s];
-#pragma unroll
-                    for (int j = 0; j < R; ++j) { sb[j].x = sb[j].x * gain; sb[j].y = sb[j].y * gain; }
-                }
-#pragma unroll
-                for (int j = 0; j < R; ++j) { out[c][j].x = out[c][j].x + sb[j].x; out[c][j].y = out[c][j].y + sb[j].y; }
-            } else {
-#pragma unroll
-                for (int j = 0; j < R; ++j) out[c][j] = sb[j];
-            }
-        }
-    }
-
-    float *dst = ys + t0 * C + c0;
-    const v4i rdst = make_rsrc(dst, bytes_left);
-    const int shape = access_shape<CG>(dst, C);
-    const int strideG = C / CG;
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        float v[2 * CG];
-#pragma unroll
-        for (int c = 0; c < CG; ++c) { v[c] = out[c][j].x; v[CG + c] = out[c][j].y; }
-        store_result<CG>(rdst, shape, tid + NT * j, strideG, C, v);
-    }
 }
 
 // =====================================================================================
@@ -644,7 +497,7 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
     float *plane = lds;                                      // [CG][W]
 
     VND_STAMP(1);
-    stage_window<NT, CG, false>(plane, plane, xs + t0 * C + c0, bytes_left, C, W, tid);
+    stage_window<NT, CG>(plane, xs + t0 * C + c0, bytes_left, C, W, tid);
     VND_STAMP(2);
     __syncthreads();
     VND_STAMP(3);
@@ -729,11 +582,147 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
 }
 
 // =====================================================================================
+// Ordered kernel: taps in table order, the reference's association.
+//   MODE 0  acc = f32(acc + f32(x*w))   bit-identical to NumPy's  out += x * w
+//           (one v_pk_mul_f32 + one v_pk_add_f32 per pair; file built with -ffp-contract=off)
+//   MODE 1  acc = fma(x, w, acc)
+// Class-path tables add the segment loop: seg = (+0 ∓x ...) ; seg *= gain ; out += seg.
+// An odd tap offset is 4-byte-misaligned for a b64 pair, so two aligned reads
+// straddle it and the pair (lo.y, hi.x) is used.  (A second LDS plane shifted by
+// one frame was measured slower: it halves the workgroups a CU can hold.)
+// Records {w, byte offset} come 16 at a time into SGPRs, like the fast kernel's.
+// =====================================================================================
+template <int MODE, int R>
+__device__ __forceinline__ void ordered_consume(v2f (&sb)[R], const v2f (&v)[R], float w)
+{
+    const v2f ww = {w, w};
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        if constexpr (MODE == 0) {
+            const v2f p = v[j] * ww;          // two roundings: exactly NumPy's  out += x * w
+            sb[j] = sb[j] + p;
+        } else {
+            sb[j] = __builtin_elementwise_fma(v[j], ww, sb[j]);
+        }
+    }
+}
+
+template <int NT, int R, int MODE>
+__device__ __forceinline__ void ordered_tap(const FastTap &t, unsigned lane_addr, v2f (&sb)[R])
+{
+    if ((t.off & 4) == 0) {
+        v2f b0[R];
+        issue_reads<NT, R>(b0, lane_addr + (unsigned)t.off);
+        wait_reads<0, R>(b0);
+        ordered_consume<MODE, R>(sb, b0, t.w);
+    } else {
+        v2f lo[R], hi[R], mid[R];
+        issue_reads<NT, R>(lo, lane_addr + (unsigned)t.off - 4u);
+        issue_reads<NT, R>(hi, lane_addr + (unsigned)t.off + 4u);
+        wait_reads<0, R>(lo);
+        wait_reads<0, R>(hi);
+#pragma unroll
+        for (int j = 0; j < R; ++j) mid[j] = v2f{lo[j].y, hi[j].x};
+        ordered_consume<MODE, R>(sb, mid, t.w);
+    }
+}
+
+template <int NT, int CG, int R, int MODE>
+__global__ __launch_bounds__(NT) void conv_ordered_kernel(const KArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int T = 2 * NT * R;
+    const int tid = threadIdx.x;
+    const int W = a.W;
+    const BlockCoord bc = decode_block(a);
+    const int C = a.C;
+    const int c0 = bc.group * CG;
+    const int64_t t0 = (int64_t)bc.tile * T;
+    const float *__restrict__ xs = a.x + bc.stream * a.n * C;
+    float *__restrict__ ys = a.y + bc.stream * a.n * C;
+    const int64_t bytes_left = ((a.n - t0) * C - c0) * 4;
+
+    stage_window<NT, CG>(lds, xs + t0 * C + c0, bytes_left, C, W, tid);
+    __syncthreads();
+
+    v2f out[CG][R];
+    const bool has_seg = a.seg_off != nullptr;
+#pragma unroll
+    for (int c = 0; c < CG; ++c) {
+        const int ch = c0 + c;
+        const float *pa = lds + c * W + 2 * tid;
+        if (a.chan_flags != nullptr && (a.chan_flags[ch] & 1)) {      // unfiltered: copy through
+#pragma unroll
+            for (int j = 0; j < R; ++j) out[c][j] = *(const v2f *)(pa + 2 * NT * j);
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) out[c][j] = v2f{0.0f, 0.0f};
+        const unsigned lane_addr = lds_addr(pa);
+        int k = __builtin_amdgcn_readfirstlane(a.tap_off[ch]);
+        const int k_last = __builtin_amdgcn_readfirstlane(a.tap_off[ch + 1]);
+        const int s_begin = has_seg ? __builtin_amdgcn_readfirstlane(a.seg_off[ch]) : 0;
+        const int nseg = has_seg ? __builtin_amdgcn_readfirstlane(a.seg_off[ch + 1]) - s_begin : 1;
+        for (int s = 0; s < nseg; ++s) {
+            const int kend = has_seg ? __builtin_amdgcn_readfirstlane(a.seg_end[s_begin + s]) : k_last;
+            v2f sb[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) sb[j] = v2f{0.0f, 0.0f};
+            while (k < kend) {
+                FastTap t[16];
+                load_taps16(a.taps_ord + k, t);          // zero-padded by 16 records
+                const int m = kend - k;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (i < m) ordered_tap<NT, R, MODE>(t[i], lane_addr, sb);
+                k += m < 16 ? m : 16;
+            }
+            if (has_seg) {          // class path: seg *= envelope (unless identity); out += seg
+                if (a.apply_gain) {
+                    const float gain = a.seg_gain[s_begin + s];
+                    const v2f gg = {gain, gain};
+#pragma unroll
+                    for (int j = 0; j < R; ++j) sb[j] = sb[j] * gg;
+                }
+#pragma unroll
+                for (int j = 0; j < R; ++j) out[c][j] = out[c][j] + sb[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < R; ++j) out[c][j] = sb[j];
+            }
+        }
+    }
+
+    float *dst = ys + t0 * C + c0;
+    const v4i rdst = make_rsrc(dst, bytes_left);
+    const int shape = access_shape<CG>(dst, C);
+    const int strideG = C / CG;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        float v[2 * CG];
+#pragma unroll
+        for (int c = 0; c < CG; ++c) { v[c] = out[c][j].x; v[CG + c] = out[c][j].y; }
+        store_result<CG>(rdst, shape, tid + NT * j, strideG, C, v);
+    }
+}
+
+// =====================================================================================
 // Fallback without LDS staging, for halos that do not fit a workgroup's LDS
 // (very long FIRs): one lane per (frame, channel), taps gathered through L1/L2,
 // table order and association (MODE as in the ordered kernel).
 // =====================================================================================
 constexpr int kDirectThreads = 256;
+
+template <int MODE>
+__device__ __forceinline__ float tap_op(float acc, float v, float w)
+{
+    if constexpr (MODE == 0) {
+        float p = v * w;          // -ffp-contract=off: two roundings
+        return acc + p;
+    } else {
+        return __builtin_fmaf(v, w, acc);
+    }
+}
 
 template <int MODE>
 __global__ __launch_bounds__(kDirectThreads) void conv_direct_kernel(const KArgs a)
