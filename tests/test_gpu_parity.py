@@ -346,25 +346,51 @@ def _exact_scale_oracle(x, kw):
     return y
 
 
+@pytest.mark.parametrize('mode', ['exact', 'fast'])
 @pytest.mark.parametrize('name', sorted(MANIFEST['cls_decorrelate']))
-def test_device_epilogue(vnd, golden, name):
+def test_device_epilogue(vnd, golden, name, mode):
+    """exact: separate epilogue passes behind the bit-exact convolution;
+    fast: the epilogue fused into the fast kernel's store phase."""
     meta = golden.manifest['cls_decorrelate'][name]
     kw = _kw(golden.manifest['class_taps'][meta['class']]['kwargs'])
     x = make_input(meta['input'])
     vnd.set_device_epilogue(True)
+    vnd.set_default_mode(vnd.MODE_EXACT if mode == 'exact' else vnd.MODE_FAST)
     try:
         y = vnd.VelvetNoise(**kw).decorrelate(x.copy())
     finally:
         vnd.set_device_epilogue(False)
+        vnd.set_default_mode(vnd.MODE_EXACT)
     ref_meta = meta['out']
     assert list(y.shape) == ref_meta['shape'] and y.dtype == np.float32
     peak = max(ref_meta['max_abs'], 1e-30)
     if kw.get('normalizer', 'default') is None:
-        golden.expect(name, y, exact=True)                       # pointwise steps are bit-identical
+        # pointwise steps are bit-identical; the fast convolution stays within 1e-6 of peak
+        golden.expect(name, y, exact=mode == 'exact', rtol_peak=TOL_PEAK)
     else:
         golden.expect(name, y, exact=False, rtol_peak=5e-4)      # vs the reference's sequential float32 RMS
         want = _exact_scale_oracle(x, kw)                        # vs exact arithmetic: float32 rounding only
-        assert np.max(np.abs(y.astype(np.float64) - want)) / peak <= 2e-6, name
+        assert np.max(np.abs(y.astype(np.float64) - want)) / peak <= (2e-6 if mode == 'exact' else 3e-6), name
+
+
+def test_fused_and_unfused_epilogue_agree(vnd, golden):
+    """Same FAST convolution, epilogue fused vs as separate passes (variant bit 24)."""
+    from vndecorrelate_amd import _native
+    ctx = _native.default_context()
+    x = make_input(dict(seed=14, shape=[5, 30011, 2]))
+    outs = []
+    vnd.set_default_mode(vnd.MODE_FAST)
+    try:
+        for variant in (-1, 1 << 24, 2, 8):              # auto (fused), unfused, fused at other tile sizes
+            ctx.set_variant(variant)
+            vn = vnd.VelvetNoise(sample_rate_hz=48000, seed=1, width=0.3)
+            outs.append(vn.decorrelate_batched(x))
+    finally:
+        ctx.set_variant(-1)
+        vnd.set_default_mode(vnd.MODE_EXACT)
+    peak = np.max(np.abs(outs[0]))
+    for y in outs[1:]:
+        assert np.max(np.abs(y - outs[0])) <= 2e-6 * peak
 
 
 def test_device_epilogue_batched(vnd, golden):

@@ -49,6 +49,7 @@ struct vnd_ctx {
     float *scratch_x = nullptr, *scratch_y = nullptr;
     size_t scratch_elems = 0;
     int variant = -1;
+    int variant_nofuse = 0;       // tuning: 1 = keep the decorrelate epilogue as separate passes
 };
 
 struct vnd_taps {
@@ -136,6 +137,30 @@ static kern_t fast_kernel(int nt, int cg, int r)
     case 256: return fast_by_cg<256>(cg, r);
     case 512: return fast_by_cg<512>(cg, r);
     default: return fast_by_cg<1024>(cg, r);
+    }
+}
+
+// fused-epilogue instantiations of the fast kernel (256 threads)
+template <int CG>
+static kern_t fast_epi_by_r(int r)
+{
+    switch (r) {
+    case 2: return conv_fast_kernel<256, CG, 2, true>;
+    case 4: return conv_fast_kernel<256, CG, 4, true>;
+    case 8: return conv_fast_kernel<256, CG, 8, true>;
+    default: return nullptr;
+    }
+}
+
+static kern_t fast_epi_kernel(const Plan &p)
+{
+    if (p.direct || p.nt != 256) return nullptr;
+    const int T = 2 * p.nt * p.r;
+    if (p.W - T < T / 2 + 1) return nullptr;          // the exchange buffer must fit the halo part
+    switch (p.cg) {
+    case 1: return fast_epi_by_r<1>(p.r);
+    case 2: return fast_epi_by_r<2>(p.r);
+    default: return fast_epi_by_r<4>(p.r);
     }
 }
 
@@ -237,8 +262,14 @@ static vnd_status check_shape(const vnd_ctx *ctx, const vnd_taps *t, int64_t bat
     return VND_OK;
 }
 
+struct EpiFuse {                 // non-null => launch the fused-epilogue instantiation
+    double *partials;
+    int ms_encode, use_width, normalize;
+    float w_mid, w_side;
+};
+
 static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
-                         int64_t n, int32_t C, int32_t mode, hipStream_t stream)
+                         int64_t n, int32_t C, int32_t mode, hipStream_t stream, const EpiFuse *epi = nullptr)
 {
     if (batch == 0 || n == 0) return VND_OK;
     const Plan p = make_plan(ctx, t, batch, n, C, mode);
@@ -258,8 +289,12 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
         if ((int64_t)batch * p.tiles * p.groups > 0x7fffffffLL)
             return fail(VND_ERR_UNSUPPORTED, "grid too large; split the batch");
         a.tiles = p.tiles; a.groups = p.groups; a.W = p.W;
-        kern_t k = pick_kernel(p, mode);
+        kern_t k = epi ? fast_epi_kernel(p) : pick_kernel(p, mode);
         if (!k) return fail(VND_ERR_UNSUPPORTED, "no kernel for this tile shape");
+        if (epi) {
+            a.epi_partials = epi->partials; a.epi_ms_encode = epi->ms_encode; a.epi_use_width = epi->use_width;
+            a.epi_normalize = epi->normalize; a.epi_w_mid = epi->w_mid; a.epi_w_side = epi->w_side;
+        }
         if (p.lds_bytes > 65536) {           // opt in to > 64 KiB of dynamic LDS, once per kernel
             static thread_local std::vector<const void *> raised;
             if (std::find(raised.begin(), raised.end(), (const void *)k) == raised.end()) {
@@ -614,6 +649,7 @@ vnd_status vnd_set_variant(vnd_ctx *ctx, int32_t variant)
 {
     if (!ctx) return fail(VND_ERR_INVALID, "null context");
     ctx->variant = variant;
+    ctx->variant_nofuse = (variant >= 0 && ((variant >> 24) & 1)) ? 1 : 0;   // bit 24: unfused epilogue
     return VND_OK;
 }
 
@@ -636,48 +672,66 @@ vnd_status vnd_describe_launch(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, i
 
 static int64_t epi_chunks(int64_t n) { return (n + kEpiChunk - 1) / kEpiChunk; }
 
+// rows of partial sums per stream: pass-1 chunks, or - fused - one row per tile (>= 512 frames each)
+static int64_t epi_rows_max(int64_t n) { return std::max<int64_t>(epi_chunks(n), (n + 511) / 512 + 1); }
+
 vnd_status vnd_decorrelate_workspace_bytes(int64_t batch, int64_t n, int32_t C, int64_t *bytes)
 {
     if (!bytes || batch < 0 || n < 0 || C <= 0) return fail(VND_ERR_INVALID, "bad workspace query");
-    *bytes = std::max<int64_t>(batch * epi_chunks(n) * 2 * C * (int64_t)sizeof(double), 8);
-    return VND_OK;
-}
-
-static vnd_status launch_epilogue(const float *x, float *y, int64_t batch, int64_t n, int32_t C, int32_t ms_encode,
-                                  int32_t use_width, double width, int32_t normalize, float eps, void *workspace,
-                                  int64_t workspace_bytes, hipStream_t stream)
-{
-    if ((ms_encode || use_width) && C != 2)
-        return fail(VND_ERR_INVALID, "side-channel encode and stereo width need 2 channels, got %d", C);
-    if (!ms_encode && !use_width && !normalize) return VND_OK;
-    int64_t need = 0;
-    vnd_decorrelate_workspace_bytes(batch, n, C, &need);
-    if (normalize && (!workspace || workspace_bytes < need))
-        return fail(VND_ERR_INVALID, "workspace too small: need %lld bytes", (long long)need);
-    if (batch > 65535) return fail(VND_ERR_UNSUPPORTED, "more than 65535 streams per call: split the batch");
-    EArgs e{};
-    e.x = x; e.y = y; e.partials = (double *)workspace; e.n = n; e.C = C;
-    e.chunks = (int32_t)epi_chunks(n);
-    e.ms_encode = ms_encode ? 1 : 0; e.use_width = use_width ? 1 : 0;
-    e.w_mid = (float)(1.0 - width); e.w_side = (float)width;   // float32(python float), as NumPy's in-place multiply
-    e.normalize = normalize ? 1 : 0; e.eps = eps;
-    const dim3 grid((unsigned)e.chunks, (unsigned)batch);
-    hipLaunchKernelGGL(epilogue_pointwise_kernel, grid, dim3(kEpiThreads), 0, stream, e);
-    if (normalize)
-        hipLaunchKernelGGL(epilogue_scale_kernel, grid, dim3(kEpiThreads), (size_t)C * sizeof(float), stream, e);
-    HIP_TRY(hipGetLastError());
+    *bytes = batch * epi_rows_max(n) * 2 * C * (int64_t)sizeof(double) + batch * C * (int64_t)sizeof(float) + 16;
     return VND_OK;
 }
 
 vnd_status vnd_decorrelate_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
                                    int64_t n, int32_t C, int32_t mode, int32_t ms_encode, int32_t use_width,
                                    double width, int32_t normalize, float eps, void *workspace,
-                                   int64_t workspace_bytes, void *stream)
+                                   int64_t workspace_bytes, void *stream_)
 {
-    vnd_status st = vnd_convolve_f32_dev(ctx, t, x, y, batch, n, C, mode, stream);
-    if (st != VND_OK || batch == 0 || n == 0) return st;
-    return launch_epilogue(x, y, batch, n, C, ms_encode, use_width, width, normalize, eps, workspace,
-                           workspace_bytes, (hipStream_t)stream);
+    vnd_status st = check_shape(ctx, t, batch, n, C, mode);
+    if (st != VND_OK) return st;
+    if (batch == 0 || n == 0) return VND_OK;
+    if (!x || !y) return fail(VND_ERR_INVALID, "null signal pointer");
+    const int64_t elems = batch * n * C;
+    if ((x < y + elems) && (y < x + elems)) return fail(VND_ERR_INVALID, "x and y overlap");
+    if ((ms_encode || use_width) && C != 2)
+        return fail(VND_ERR_INVALID, "side-channel encode and stereo width need 2 channels, got %d", C);
+    int64_t need = 0;
+    vnd_decorrelate_workspace_bytes(batch, n, C, &need);
+    if (normalize && (!workspace || workspace_bytes < need))
+        return fail(VND_ERR_INVALID, "workspace too small: need %lld bytes", (long long)need);
+    if (batch > 65535) return fail(VND_ERR_UNSUPPORTED, "more than 65535 streams per call: split the batch");
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool any = ms_encode || use_width || normalize;
+
+    EArgs e{};
+    e.x = x; e.y = y; e.partials = (double *)workspace; e.n = n; e.C = C;
+    e.scales = (float *)((double *)workspace + batch * epi_rows_max(n) * 2 * C);
+    e.ms_encode = ms_encode ? 1 : 0; e.use_width = use_width ? 1 : 0;
+    e.w_mid = (float)(1.0 - width); e.w_side = (float)width;   // float32(python float), as NumPy's in-place multiply
+    e.normalize = normalize ? 1 : 0; e.eps = eps;
+    const dim3 grid((unsigned)epi_chunks(n), (unsigned)batch);
+
+    // Fused form: the fast kernel applies the pointwise steps and writes one row of sums per tile.
+    const Plan p = make_plan(ctx, t, batch, n, C, mode);
+    const bool fused = any && mode == VND_MODE_FAST && ctx->variant_nofuse == 0 && fast_epi_kernel(p) != nullptr &&
+                       (!(ms_encode || use_width) || p.cg == 2);
+    if (fused) {
+        EpiFuse f{(double *)workspace, e.ms_encode, e.use_width, e.normalize, e.w_mid, e.w_side};
+        st = launch(ctx, t, x, y, batch, n, C, mode, stream, &f);
+        if (st != VND_OK) return st;
+        e.rows = p.tiles;
+    } else {
+        st = launch(ctx, t, x, y, batch, n, C, mode, stream);
+        if (st != VND_OK || !any) return st;
+        e.rows = (int32_t)epi_chunks(n);
+        hipLaunchKernelGGL(epilogue_pointwise_kernel, grid, dim3(kEpiThreads), 0, stream, e);
+    }
+    if (normalize) {
+        hipLaunchKernelGGL(epilogue_reduce_kernel, dim3((unsigned)batch), dim3(kEpiThreads), 0, stream, e);
+        hipLaunchKernelGGL(epilogue_scale_kernel, grid, dim3(kEpiThreads), 0, stream, e);
+    }
+    HIP_TRY(hipGetLastError());
+    return VND_OK;
 }
 
 vnd_status vnd_decorrelate_f32_host(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,

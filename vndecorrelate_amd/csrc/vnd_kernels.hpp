@@ -68,6 +68,10 @@ struct KArgs {
     int32_t W;                 // floats per LDS plane (tile + halo, even)
     int32_t apply_gain;
     uint32_t nblocks;
+    // fused decorrelate epilogue (fast kernel, EPI instantiation; vnd_epilogue.hpp has the two-pass form)
+    double *__restrict__ epi_partials;      // [batch][tiles][2*C]: sum x_c^2, then sum y_c^2, per tile
+    int32_t epi_ms_encode, epi_use_width, epi_normalize;
+    float epi_w_mid, epi_w_side;
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Map
@@ -479,7 +483,13 @@ __device__ unsigned long long g_stamps[8 * 65536];
 #define VND_STAMP(slot) do { } while (0)
 #endif
 
-template <int NT, int CG, int R>
+// EPI: the decorrelate epilogue's pointwise steps (side-channel encode, stereo width;
+// reference utils/dsp.py:21-63) are applied to the tile before it is stored, in the
+// reference's float32 operation order, and the tile's sums of x^2 and y^2 go to
+// epi_partials for the scaling pass - the tile's input is still in LDS, so the fused
+// form saves a full read of x and a read + write of y.  The exchange buffer then lives
+// in the halo part of the planes (the host only picks EPI when it fits there).
+template <int NT, int CG, int R, bool EPI = false>
 __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -549,13 +559,16 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
     VND_STAMP(4);
     __syncthreads();                                   // every wave is done reading the planes
     VND_STAMP(5);
-    float *xo = lds;                                   // [CG][T/2 + 1], reuses the window
     constexpr int XS = T / 2 + 1;
+    // exchange buffer [CG][T/2 + 1]: over the dead window, or (EPI) in each plane's halo part,
+    // which keeps the tile's own input x[0 .. T) readable for the epilogue
+    float *xo = EPI ? lds + T : lds;
+    const int xs_stride = EPI ? W : XS;
 #pragma unroll
     for (int c = 0; c < CG; ++c) {
 #pragma unroll
-        for (int j = 0; j < R; ++j) xo[c * XS + tid + NT * j] = accO[c][j].x;
-        if (tid == NT - 1) xo[c * XS + T / 2] = edge[c];
+        for (int j = 0; j < R; ++j) xo[c * xs_stride + tid + NT * j] = accO[c][j].x;
+        if (tid == NT - 1) xo[c * xs_stride + T / 2] = edge[c];
     }
     __syncthreads();
 
@@ -563,6 +576,9 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
     const v4i rdst = make_rsrc(dst, bytes_left);
     const int shape = access_shape<CG>(dst, C);
     const int strideG = C / CG;
+    float sum_x[CG], sum_y[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) { sum_x[c] = 0.0f; sum_y[c] = 0.0f; }
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const int q = tid + NT * j;
@@ -570,9 +586,67 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
 #pragma unroll
         for (int c = 0; c < CG; ++c) {
             v[c] = accE[c][j].x + accO[c][j].y;
-            v[CG + c] = accE[c][j].y + xo[c * XS + q + 1];
+            v[CG + c] = accE[c][j].y + xo[c * xs_stride + q + 1];
+        }
+        if constexpr (EPI) {
+            float xin[2 * CG];
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {
+                const float2 xp = *(const float2 *)(lds + c * W + 2 * q);
+                xin[c] = xp.x; xin[CG + c] = xp.y;
+            }
+            if constexpr (CG == 2) {
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {            // the pair's two frames
+                    float y0 = v[f * CG], y1 = v[f * CG + 1];
+                    if (a.epi_ms_encode) {               // utils/dsp.py:59-63
+                        const float mid = xin[f * CG] + xin[f * CG + 1];
+                        const float side = (y0 - y1) * 0.5f;
+                        y0 = (mid + side) * 0.5f;
+                        y1 = (mid - side) * 0.5f;
+                    }
+                    if (a.epi_use_width) {               // utils/dsp.py:34-37
+                        float m = (y0 + y1) * 0.5f, sd = (y0 - y1) * 0.5f;
+                        m = m * a.epi_w_mid;
+                        sd = sd * a.epi_w_side;
+                        y0 = m + sd;
+                        y1 = m - sd;
+                    }
+                    v[f * CG] = y0; v[f * CG + 1] = y1;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {               // frames past the stream's end are zeros
+                sum_x[c] += xin[c] * xin[c] + xin[CG + c] * xin[CG + c];
+                sum_y[c] += v[c] * v[c] + v[CG + c] * v[CG + c];
+            }
         }
         store_result<CG>(rdst, shape, q, strideG, C, v);
+    }
+    if constexpr (EPI) {
+        if (a.epi_normalize) {
+            __shared__ double red[NT / 64][2 * CG];
+            double r[2 * CG];
+#pragma unroll
+            for (int c = 0; c < CG; ++c) { r[c] = (double)sum_x[c]; r[CG + c] = (double)sum_y[c]; }
+#pragma unroll
+            for (int i = 0; i < 2 * CG; ++i) {
+#pragma unroll
+                for (int sh = 32; sh > 0; sh >>= 1) r[i] += __shfl_xor(r[i], sh);
+            }
+            if ((tid & 63) == 0) {
+#pragma unroll
+                for (int i = 0; i < 2 * CG; ++i) red[tid >> 6][i] = r[i];
+            }
+            __syncthreads();
+            if (tid < 2 * CG) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < NT / 64; ++w) t += red[w][tid];          // fixed order
+                double *row = a.epi_partials + ((int64_t)bc.stream * a.tiles + bc.tile) * 2 * C;
+                row[tid < CG ? c0 + tid : C + c0 + (tid - CG)] = t;
+            }
+        }
     }
     VND_STAMP(6);
 #ifdef VND_STAMPS
