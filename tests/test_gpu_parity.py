@@ -427,3 +427,21 @@ def test_velvet_noise_regeneration_refreshes_device_table(vnd):
     want = O.class_convolve(x, O.generate_class_taps(sample_rate_hz=44100, num_impulses=26, seed=1),
                             (1.0, 0.5, 0.25, 0.125), 2)
     assert np.array_equal(vn.convolve(x), want)
+
+
+def test_integration_stub_runs(vnd, golden):
+    """The ctypes stub printed in INTEGRATION.md (what a reference maintainer would add) is
+    executed as written, against the in-tree library, and must reproduce the reference."""
+    import re
+    from vndecorrelate_amd import _native
+    from vndecorrelate_amd.utils.dsp import check_equal_length
+    text = (pathlib.Path(__file__).resolve().parents[1] / 'INTEGRATION.md').read_text()
+    block = re.search(r'```python\nimport ctypes, numpy as np\n(.*?)```', text, re.S).group(0)
+    code = block.strip('`').replace('python\n', '', 1).replace('"libvnd_amd.so"', repr(str(_native.LIB_PATH)))
+    ns = {'check_equal_length': check_equal_length}
+    exec(compile(code, 'INTEGRATION.md', 'exec'), ns)
+    fir = golden.fir('g48k_k30')
+    x = make_input(dict(seed=41, shape=[25000, 2]))
+    assert np.array_equal(ns['convolve_velvet_noise'](x, fir), O.convolve_velvet_noise(x, fir))
+    with pytest.raises(ValueError):
+        ns['convolve_velvet_noise'](x, golden.fir('g96k_k64_c8'))

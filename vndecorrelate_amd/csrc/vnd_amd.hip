@@ -625,22 +625,22 @@ vnd_status vnd_time_convolve_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const floa
     if (st != VND_OK) return st;
     if (!avg_ms || iters <= 0 || n_buffers <= 0) return fail(VND_ERR_INVALID, "bad timing arguments");
     hipStream_t stream = (hipStream_t)stream_;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, stream));
-    for (int i = 0; i < iters; ++i) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t he = hipEventCreate(&e0);
+    if (he == hipSuccess) he = hipEventCreate(&e1);
+    if (he == hipSuccess) he = hipEventRecord(e0, stream);
+    for (int i = 0; he == hipSuccess && st == VND_OK && i < iters; ++i) {
         const int64_t off = (int64_t)(i % n_buffers) * stride;
         st = launch(ctx, t, x + off, y + off, batch, n, C, mode, stream);
-        if (st != VND_OK) break;
     }
-    HIP_TRY(hipEventRecord(e1, stream));
-    HIP_TRY(hipEventSynchronize(e1));
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    if (he == hipSuccess) he = hipEventRecord(e1, stream);
+    if (he == hipSuccess) he = hipEventSynchronize(e1);
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
     if (st != VND_OK) return st;
+    if (he != hipSuccess) return fail(VND_ERR_HIP, "timing: %s", hipGetErrorString(he));
     *avg_ms = ms / iters;
     return VND_OK;
 }
