@@ -155,19 +155,29 @@ __device__ __forceinline__ int access_shape(const void *base, int C)
 }
 
 // strideG = C / CG  (frame stride in units of CG floats);  q = pair index in the window
+// Cache policy of the streaming traffic (aux operand of the buffer intrinsics:
+// bit0 sc0, bit1 nt, bit4 sc1).  Build-time knobs for experiments.
+#ifndef VND_LOAD_AUX
+#define VND_LOAD_AUX 0
+#endif
+#ifndef VND_STORE_AUX
+#define VND_STORE_AUX 0
+#endif
+constexpr int kLoadAux = VND_LOAD_AUX, kStoreAux = VND_STORE_AUX;
+
 template <int CG, int SHAPE>
 __device__ __forceinline__ void load_pair(v4i rsrc, int q, int strideG, int C, float (&v)[2 * CG])
 {
     if constexpr (SHAPE == kPair) {
         const int off = q * (8 * CG);
         if constexpr (CG == 1) {
-            const v2f t = buf_load2(rsrc, off, 0, 0);
+            const v2f t = buf_load2(rsrc, off, 0, kLoadAux);
             v[0] = t.x; v[1] = t.y;
         } else if constexpr (CG == 2) {
-            const v4f t = buf_load4(rsrc, off, 0, 0);
+            const v4f t = buf_load4(rsrc, off, 0, kLoadAux);
             v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
         } else {
-            const v4f p = buf_load4(rsrc, off, 0, 0), t = buf_load4(rsrc, off + 16, 0, 0);
+            const v4f p = buf_load4(rsrc, off, 0, kLoadAux), t = buf_load4(rsrc, off + 16, 0, kLoadAux);
             v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w;
             v[4] = t.x; v[5] = t.y; v[6] = t.z; v[7] = t.w;
         }
@@ -175,12 +185,12 @@ __device__ __forceinline__ void load_pair(v4i rsrc, int q, int strideG, int C, f
         const int off0 = (2 * q) * strideG * (4 * CG);
         const int off1 = (2 * q + 1) * strideG * (4 * CG);
         if constexpr (CG == 1) {
-            v[0] = buf_load1(rsrc, off0, 0, 0); v[1] = buf_load1(rsrc, off1, 0, 0);
+            v[0] = buf_load1(rsrc, off0, 0, kLoadAux); v[1] = buf_load1(rsrc, off1, 0, kLoadAux);
         } else if constexpr (CG == 2) {
-            const v2f p = buf_load2(rsrc, off0, 0, 0), t = buf_load2(rsrc, off1, 0, 0);
+            const v2f p = buf_load2(rsrc, off0, 0, kLoadAux), t = buf_load2(rsrc, off1, 0, kLoadAux);
             v[0] = p.x; v[1] = p.y; v[2] = t.x; v[3] = t.y;
         } else {
-            const v4f p = buf_load4(rsrc, off0, 0, 0), t = buf_load4(rsrc, off1, 0, 0);
+            const v4f p = buf_load4(rsrc, off0, 0, kLoadAux), t = buf_load4(rsrc, off1, 0, kLoadAux);
             v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w;
             v[4] = t.x; v[5] = t.y; v[6] = t.z; v[7] = t.w;
         }
@@ -188,8 +198,8 @@ __device__ __forceinline__ void load_pair(v4i rsrc, int q, int strideG, int C, f
         const int off0 = (2 * q) * C * 4;
 #pragma unroll
         for (int c = 0; c < CG; ++c) {
-            v[c] = buf_load1(rsrc, off0 + 4 * c, 0, 0);
-            v[CG + c] = buf_load1(rsrc, off0 + C * 4 + 4 * c, 0, 0);
+            v[c] = buf_load1(rsrc, off0 + 4 * c, 0, kLoadAux);
+            v[CG + c] = buf_load1(rsrc, off0 + C * 4 + 4 * c, 0, kLoadAux);
         }
     }
 }
@@ -202,40 +212,40 @@ __device__ __forceinline__ void store_pair(v4i rdst, int q, int strideG, int C, 
         const int off = q * (8 * CG);
         if constexpr (CG == 1) {
             v2f t; t.x = v[0]; t.y = v[1];
-            buf_store2(t, rdst, off, 0, 0);
+            buf_store2(t, rdst, off, 0, kStoreAux);
         } else if constexpr (CG == 2) {
             v4f t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
-            buf_store4(t, rdst, off, 0, 0);
+            buf_store4(t, rdst, off, 0, kStoreAux);
         } else {
             v4f t, u;
             t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
             u.x = v[4]; u.y = v[5]; u.z = v[6]; u.w = v[7];
-            buf_store4(t, rdst, off, 0, 0);
-            buf_store4(u, rdst, off + 16, 0, 0);
+            buf_store4(t, rdst, off, 0, kStoreAux);
+            buf_store4(u, rdst, off + 16, 0, kStoreAux);
         }
     } else if constexpr (SHAPE == kFrame) {
         const int off0 = (2 * q) * strideG * (4 * CG);
         const int off1 = (2 * q + 1) * strideG * (4 * CG);
         if constexpr (CG == 1) {
-            buf_store1(v[0], rdst, off0, 0, 0);
-            buf_store1(v[1], rdst, off1, 0, 0);
+            buf_store1(v[0], rdst, off0, 0, kStoreAux);
+            buf_store1(v[1], rdst, off1, 0, kStoreAux);
         } else if constexpr (CG == 2) {
             v2f t, u; t.x = v[0]; t.y = v[1]; u.x = v[2]; u.y = v[3];
-            buf_store2(t, rdst, off0, 0, 0);
-            buf_store2(u, rdst, off1, 0, 0);
+            buf_store2(t, rdst, off0, 0, kStoreAux);
+            buf_store2(u, rdst, off1, 0, kStoreAux);
         } else {
             v4f t, u;
             t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
             u.x = v[4]; u.y = v[5]; u.z = v[6]; u.w = v[7];
-            buf_store4(t, rdst, off0, 0, 0);
-            buf_store4(u, rdst, off1, 0, 0);
+            buf_store4(t, rdst, off0, 0, kStoreAux);
+            buf_store4(u, rdst, off1, 0, kStoreAux);
         }
     } else {
         const int off0 = (2 * q) * C * 4;
 #pragma unroll
         for (int c = 0; c < CG; ++c) {
-            buf_store1(v[c], rdst, off0 + 4 * c, 0, 0);
-            buf_store1(v[CG + c], rdst, off0 + C * 4 + 4 * c, 0, 0);
+            buf_store1(v[c], rdst, off0 + 4 * c, 0, kStoreAux);
+            buf_store1(v[CG + c], rdst, off0 + C * 4 + 4 * c, 0, kStoreAux);
         }
     }
 }
@@ -557,7 +567,9 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
 
     // ---- merge the two accumulator sets: neighbour's accO.x through LDS -----------
     VND_STAMP(4);
+#if !(defined(VND_ABLATE) && VND_ABLATE == 4)
     __syncthreads();                                   // every wave is done reading the planes
+#endif
     VND_STAMP(5);
     constexpr int XS = T / 2 + 1;
     // exchange buffer [CG][T/2 + 1]: over the dead window, or (EPI) in each plane's halo part,
@@ -570,7 +582,9 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
         for (int j = 0; j < R; ++j) xo[c * xs_stride + tid + NT * j] = accO[c][j].x;
         if (tid == NT - 1) xo[c * xs_stride + T / 2] = edge[c];
     }
+#if !(defined(VND_ABLATE) && VND_ABLATE == 4)
     __syncthreads();
+#endif
 
     float *dst = ys + t0 * C + c0;
     const v4i rdst = make_rsrc(dst, bytes_left);
