@@ -201,6 +201,21 @@ def main():
                           'parity': 'bit-identical to the oracle (sha-checked in tests)',
                           'launch': table.describe(args.pool, n, CHANNELS, vnd.MODE_EXACT)}
 
+    # the device's own streaming ceiling on the same pool: a plain device copy (4 B read + 4 B
+    # written per sample, the kernel's algorithmic traffic), the honest companion of the 8 TB/s figure
+    copy_gbs = None
+    if rank == 0:
+        for _ in range(5):
+            y.copy_(x)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        c0.record()
+        for _ in range(20):
+            y.copy_(x)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbs = ALGO_BYTES_PER_SAMPLE * samples_per_step / (c0.elapsed_time(c1) / 20 * 1e-3) / 1e9
+
     if rank == 0:
         value = world * samples_per_step * args.steps / elapsed / 1e6
         achieved = ALGO_BYTES_PER_SAMPLE * samples_per_step / (kernel_ms * 1e-3) / 1e9
@@ -226,7 +241,8 @@ def main():
                        'sharding': 'independent streams per rank; RCCL broadcast of the tap table only'},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                         'kernel_ms': round(kernel_ms, 4),
+                         'kernel_ms': round(kernel_ms, 4), 'device_copy_GBs': round(copy_gbs, 1),
+                         'limit': 'board power cap (1400 W; clock falls to ~1.83 GHz under this kernel), DESIGN.md 3.5',
                          'algorithmic_bytes_per_launch': ALGO_BYTES_PER_SAMPLE * samples_per_step},
         }
         if world == 1 and not args.no_cpu:

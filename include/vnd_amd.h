@@ -123,6 +123,36 @@ vnd_status vnd_decorrelate_f32_host(vnd_ctx *ctx, const vnd_taps *taps, const fl
                                     int32_t ms_encode, int32_t use_width, double width, int32_t normalize,
                                     float eps);
 
+/* ---- fan-out: fewer input channels than table channels ------------------------
+ * x is [batch][n_frames][in_channels], y is [batch][n_frames][C] with C the table's
+ * num_channels (a multiple of in_channels); output channel c reads input channel
+ * c % in_channels:
+ *   y[b,n,c] = sum_k w[c,k] * x[b, n + i[c,k], c % in_channels]
+ * in_channels = 1, C = 2: VelvetNoise.decorrelate on a mono signal without the
+ * mono_to_stereo copy (decorrelation.py:431-432, utils/dsp.py:112-115) - the input is
+ * staged once per tile and read by both channels' taps.
+ * in_channels = 2, C = 2F: one stereo signal through a bank of F filter pairs in a
+ * single launch - the candidate scan of optimization.py:107-117 (grid_scan), with
+ * the F tables concatenated channel-wise; y[..., 2f:2f+2] is filter f's output.
+ * Results are those of vnd_convolve / vnd_decorrelate on the replicated input, bit
+ * for bit in VND_MODE_EXACT.  The decorrelate epilogue pairs output channel c with
+ * input channel c % in_channels.                                                 */
+vnd_status vnd_convolve_fanout_f32_dev(vnd_ctx *ctx, const vnd_taps *taps, const float *x_dev,
+                                       float *y_dev, int64_t batch, int64_t n_frames,
+                                       int32_t in_channels, int32_t mode, void *hip_stream);
+vnd_status vnd_convolve_fanout_f32_host(vnd_ctx *ctx, const vnd_taps *taps, const float *x,
+                                        float *y, int64_t batch, int64_t n_frames,
+                                        int32_t in_channels, int32_t mode);
+vnd_status vnd_decorrelate_fanout_f32_dev(vnd_ctx *ctx, const vnd_taps *taps, const float *x_dev,
+                                          float *y_dev, int64_t batch, int64_t n_frames,
+                                          int32_t in_channels, int32_t mode, int32_t ms_encode,
+                                          int32_t use_width, double width, int32_t normalize, float eps,
+                                          void *workspace_dev, int64_t workspace_bytes, void *hip_stream);
+vnd_status vnd_decorrelate_fanout_f32_host(vnd_ctx *ctx, const vnd_taps *taps, const float *x, float *y,
+                                           int64_t batch, int64_t n_frames, int32_t in_channels,
+                                           int32_t mode, int32_t ms_encode, int32_t use_width, double width,
+                                           int32_t normalize, float eps);
+
 /* ---- measurement helpers (used by bench.py; not on the data path) ---------- */
 /* Launches the convolve `iters` times back to back on `hip_stream`, cycling
  * through `n_buffers` (x,y) pairs laid out at x_dev + i*stride_elems, and
@@ -139,6 +169,10 @@ vnd_status vnd_set_variant(vnd_ctx *ctx, int32_t variant);
 vnd_status vnd_describe_launch(vnd_ctx *ctx, const vnd_taps *taps, int64_t batch,
                                int64_t n_frames, int32_t n_channels, int32_t mode,
                                char *text, int32_t len);
+
+vnd_status vnd_describe_fanout_launch(vnd_ctx *ctx, const vnd_taps *taps, int64_t batch,
+                                      int64_t n_frames, int32_t in_channels, int32_t mode,
+                                      char *text, int32_t len);
 
 #ifdef __cplusplus
 }

@@ -205,3 +205,41 @@ def test_function_path_host_validation():
         vnd.convolve_velvet_noise_batched(np.zeros((4, 2), np.float32), fir)
     with pytest.raises(ValueError):
         vnd.set_default_mode(7)
+
+
+# ---- filter banks: channel-wise concatenation of tap tables -------------------------
+def test_concat_tap_arrays_against_the_oracle(golden):
+    """A bank's table on the replicated signal == each member's table on the signal
+    (checked with the C oracle: no GPU involved)."""
+    from oracle import c_oracle
+    from vndecorrelate_amd.taps import TapArrays, concat_tap_arrays
+    x = np.random.default_rng(5).uniform(-1, 1, (3001, 2)).astype(np.float32)
+    # function path
+    firs = [vnd.generate_velvet_noise(duration_seconds=0.01, num_impulses=20 + f, sample_rate_hz=48000, seed=f)
+            for f in range(3)]
+    members = [function_path_arrays(f) for f in firs]
+    bank = concat_tap_arrays(members)
+    assert bank.num_channels == 6 and bank.seg_offsets is None
+    y = c_oracle.convolve(np.tile(x, (1, 3)), bank.tap_offsets, bank.tap_index, bank.tap_weight)
+    for f, m in enumerate(members):
+        assert np.array_equal(y[:, 2 * f:2 * f + 2], c_oracle.convolve(x, m.tap_offsets, m.tap_index, m.tap_weight))
+    assert TapArrays.from_bytes(bank.to_bytes()).tap_index.tolist() == bank.tap_index.tolist()
+    # class path: gains, an identity envelope (gain skipped upstream), a pass-through channel
+    vns = [vnd.VelvetNoise(sample_rate_hz=48000, seed=1),
+           vnd.VelvetNoise(sample_rate_hz=48000, seed=2, segment_envelope=(1.0,)),
+           vnd.VelvetNoise(sample_rate_hz=48000, seed=3, filtered_channels=(0,))]
+    members = [v._tap_arrays() for v in vns]
+    bank = concat_tap_arrays(members)
+    assert bank.apply_gain and bank.chan_flags.tolist() == [0, 0, 0, 0, 0, 1]
+    def oracle(sig, t):
+        return c_oracle.convolve(sig, t.tap_offsets, t.tap_index, t.tap_weight, seg_off=t.seg_offsets,
+                                 seg_end=t.seg_end, seg_gain=t.seg_gain, chan_flags=t.chan_flags,
+                                 apply_gain=t.apply_gain)
+    y = oracle(np.tile(x, (1, 3)), bank)
+    for f, m in enumerate(members):
+        want = oracle(x, m)
+        assert np.array_equal(y[:, 2 * f:2 * f + 2], want), f
+    with pytest.raises(ValueError):
+        concat_tap_arrays([function_path_arrays(firs[0]), members[0]])
+    with pytest.raises(ValueError):
+        concat_tap_arrays([])

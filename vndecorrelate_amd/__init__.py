@@ -16,7 +16,9 @@ from .decorrelation import (  # noqa: F401
     VelvetNoise,
     WhiteNoise,
     convolve_velvet_noise,
+    convolve_velvet_noise_bank,
     convolve_velvet_noise_batched,
+    decorrelate_bank,
     generate_velvet_noise,
     set_default_mode,
     set_device_epilogue,

@@ -60,6 +60,25 @@ SIGNATURES = {
                                                 ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                                 ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_int32,
                                                 ctypes.c_float]),
+    'vnd_convolve_fanout_f32_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                   ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                                   ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    'vnd_convolve_fanout_f32_host': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_f32p, _c_f32p,
+                                                    ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+                                                    ctypes.c_int32]),
+    'vnd_decorrelate_fanout_f32_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                      ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                                      ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                      ctypes.c_int32, ctypes.c_double, ctypes.c_int32,
+                                                      ctypes.c_float, ctypes.c_void_p, ctypes.c_int64,
+                                                      ctypes.c_void_p]),
+    'vnd_decorrelate_fanout_f32_host': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_f32p, _c_f32p,
+                                                       ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+                                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                       ctypes.c_double, ctypes.c_int32, ctypes.c_float]),
+    'vnd_describe_fanout_launch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                                  ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                                  ctypes.c_char_p, ctypes.c_int32]),
     'vnd_time_convolve_f32_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                  ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
@@ -251,56 +270,70 @@ class TapTable:
             pass
 
     # ---- the hot path ---------------------------------------------------------
-    def convolve_host(self, x: np.ndarray, mode: int = MODE_EXACT) -> np.ndarray:
-        """x: C-contiguous float32 ``(n, C)`` or ``(batch, n, C)``; returns a new array."""
+    # A signal with fewer channels than the table is fanned out: output channel c reads
+    # input channel c % in_channels (vnd_*_fanout_*; mono -> stereo, or one signal through
+    # a bank of filters).  The result always has the table's channel count.
+    def _host_shapes(self, x: np.ndarray, what: str):
         if x.dtype != np.float32 or not x.flags.c_contiguous:
-            raise ValueError('convolve_host wants a C-contiguous float32 array')
+            raise ValueError(f'{what} wants a C-contiguous float32 array')
         if x.ndim == 2:
             batch, (n, c) = 1, x.shape
         elif x.ndim == 3:
             batch, n, c = x.shape
         else:
             raise ValueError(f'expected (n, C) or (batch, n, C), got {x.shape}')
-        y = np.empty_like(x)
-        _check(self._lib.vnd_convolve_f32_host(self.ctx.handle, self.handle,
-                                               _ptr(x, ctypes.c_float), _ptr(y, ctypes.c_float),
-                                               batch, n, c, int(mode)), 'vnd_convolve_f32_host')
+        y = np.empty(x.shape[:-1] + (self.num_channels,), np.float32)
+        return batch, n, c, y
+
+    def convolve_host(self, x: np.ndarray, mode: int = MODE_EXACT) -> np.ndarray:
+        """x: C-contiguous float32 ``(n, C)`` or ``(batch, n, C)``; returns a new array."""
+        batch, n, c, y = self._host_shapes(x, 'convolve_host')
+        if c == self.num_channels:
+            _check(self._lib.vnd_convolve_f32_host(self.ctx.handle, self.handle,
+                                                   _ptr(x, ctypes.c_float), _ptr(y, ctypes.c_float),
+                                                   batch, n, c, int(mode)), 'vnd_convolve_f32_host')
+        else:
+            _check(self._lib.vnd_convolve_fanout_f32_host(self.ctx.handle, self.handle,
+                                                          _ptr(x, ctypes.c_float), _ptr(y, ctypes.c_float),
+                                                          batch, n, c, int(mode)), 'vnd_convolve_fanout_f32_host')
         return y
 
     def decorrelate_host(self, x: np.ndarray, mode: int = MODE_EXACT, *, ms_encode: bool, width,
                          normalize: bool, eps: float = 1e-10) -> np.ndarray:
         """Convolution + decorrelate epilogue on the device; x as in ``convolve_host``."""
-        if x.dtype != np.float32 or not x.flags.c_contiguous:
-            raise ValueError('decorrelate_host wants a C-contiguous float32 array')
-        if x.ndim == 2:
-            batch, (n, c) = 1, x.shape
-        elif x.ndim == 3:
-            batch, n, c = x.shape
+        batch, n, c, y = self._host_shapes(x, 'decorrelate_host')
+        tail = (int(mode), int(bool(ms_encode)), int(width is not None), float(width or 0.0),
+                int(bool(normalize)), float(eps))
+        if c == self.num_channels:
+            _check(self._lib.vnd_decorrelate_f32_host(
+                self.ctx.handle, self.handle, _ptr(x, ctypes.c_float), _ptr(y, ctypes.c_float), batch, n, c,
+                *tail), 'vnd_decorrelate_f32_host')
         else:
-            raise ValueError(f'expected (n, C) or (batch, n, C), got {x.shape}')
-        y = np.empty_like(x)
-        _check(self._lib.vnd_decorrelate_f32_host(
-            self.ctx.handle, self.handle, _ptr(x, ctypes.c_float), _ptr(y, ctypes.c_float), batch, n, c,
-            int(mode), int(bool(ms_encode)), int(width is not None), float(width or 0.0),
-            int(bool(normalize)), float(eps)), 'vnd_decorrelate_f32_host')
+            _check(self._lib.vnd_decorrelate_fanout_f32_host(
+                self.ctx.handle, self.handle, _ptr(x, ctypes.c_float), _ptr(y, ctypes.c_float), batch, n, c,
+                *tail), 'vnd_decorrelate_fanout_f32_host')
         return y
 
     def decorrelate_device(self, x_ptr: int, y_ptr: int, batch: int, n: int, channels: int, *, mode: int,
                            ms_encode: bool, width, normalize: bool, workspace_ptr: int, workspace_bytes: int,
                            eps: float = 1e-10, stream: int = 0):
-        _check(self._lib.vnd_decorrelate_f32_dev(
-            self.ctx.handle, self.handle, ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr), batch, n, channels,
-            int(mode), int(bool(ms_encode)), int(width is not None), float(width or 0.0), int(bool(normalize)),
-            float(eps), ctypes.c_void_p(workspace_ptr), workspace_bytes, ctypes.c_void_p(stream)),
-            'vnd_decorrelate_f32_dev')
+        """``channels`` = channels of x; y has the table's channel count."""
+        fn, name = ((self._lib.vnd_decorrelate_f32_dev, 'vnd_decorrelate_f32_dev')
+                    if channels == self.num_channels else
+                    (self._lib.vnd_decorrelate_fanout_f32_dev, 'vnd_decorrelate_fanout_f32_dev'))
+        _check(fn(self.ctx.handle, self.handle, ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr), batch, n, channels,
+                  int(mode), int(bool(ms_encode)), int(width is not None), float(width or 0.0), int(bool(normalize)),
+                  float(eps), ctypes.c_void_p(workspace_ptr), workspace_bytes, ctypes.c_void_p(stream)), name)
 
     def convolve_device(self, x_ptr: int, y_ptr: int, batch: int, n: int, channels: int,
                         mode: int = MODE_EXACT, stream: int = 0):
-        """Enqueue on ``stream`` (a hipStream_t as int); pointers are device addresses."""
-        _check(self._lib.vnd_convolve_f32_dev(self.ctx.handle, self.handle,
-                                              ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr),
-                                              batch, n, channels, int(mode),
-                                              ctypes.c_void_p(stream)), 'vnd_convolve_f32_dev')
+        """Enqueue on ``stream`` (a hipStream_t as int); pointers are device addresses.
+        ``channels`` = channels of x; y has the table's channel count."""
+        fn, name = ((self._lib.vnd_convolve_f32_dev, 'vnd_convolve_f32_dev')
+                    if channels == self.num_channels else
+                    (self._lib.vnd_convolve_fanout_f32_dev, 'vnd_convolve_fanout_f32_dev'))
+        _check(fn(self.ctx.handle, self.handle, ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr),
+                  batch, n, channels, int(mode), ctypes.c_void_p(stream)), name)
 
     def time_device(self, x_ptr: int, y_ptr: int, batch: int, n: int, channels: int, *, mode: int,
                     n_buffers: int, stride_elems: int, iters: int, stream: int = 0) -> float:
@@ -314,8 +347,10 @@ class TapTable:
 
     def describe(self, batch: int, n: int, channels: int, mode: int = MODE_EXACT) -> str:
         buf = ctypes.create_string_buffer(512)
-        _check(self._lib.vnd_describe_launch(self.ctx.handle, self.handle, batch, n, channels,
-                                             int(mode), buf, 512), 'vnd_describe_launch')
+        fn, name = ((self._lib.vnd_describe_launch, 'vnd_describe_launch')
+                    if channels == self.num_channels else
+                    (self._lib.vnd_describe_fanout_launch, 'vnd_describe_fanout_launch'))
+        _check(fn(self.ctx.handle, self.handle, batch, n, channels, int(mode), buf, 512), name)
         return buf.value.decode()
 
 

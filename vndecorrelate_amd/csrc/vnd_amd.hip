@@ -73,6 +73,7 @@ struct vnd_taps {
 // ------------------------------------------------------------------------------
 struct Plan {
     bool direct = false;
+    bool bc = false;                            // mono input fanned out: one staged plane per workgroup
     int nt = 256, cg = 1, r = 1;                // r = frame pairs per lane; tile = 2 * nt * r frames
     int W = 0;
     size_t lds_bytes = 0;
@@ -140,6 +141,20 @@ static kern_t fast_kernel(int nt, int cg, int r)
     }
 }
 
+// fan-out instantiations (mono input, two output channels per workgroup, 256 threads)
+static kern_t fast_bc_kernel(int r, bool epi)
+{
+    switch (r) {
+    case 1: return epi ? nullptr : conv_fast_kernel<256, 2, 1, false, true>;
+    case 2: return epi ? conv_fast_kernel<256, 2, 2, true, true> : conv_fast_kernel<256, 2, 2, false, true>;
+    case 3: return epi ? nullptr : conv_fast_kernel<256, 2, 3, false, true>;
+    case 4: return epi ? conv_fast_kernel<256, 2, 4, true, true> : conv_fast_kernel<256, 2, 4, false, true>;
+    case 6: return epi ? nullptr : conv_fast_kernel<256, 2, 6, false, true>;
+    case 8: return epi ? conv_fast_kernel<256, 2, 8, true, true> : conv_fast_kernel<256, 2, 8, false, true>;
+    default: return nullptr;
+    }
+}
+
 // fused-epilogue instantiations of the fast kernel (256 threads)
 template <int CG>
 static kern_t fast_epi_by_r(int r)
@@ -155,6 +170,7 @@ static kern_t fast_epi_by_r(int r)
 static kern_t fast_epi_kernel(const Plan &p)
 {
     if (p.direct || p.nt != 256) return nullptr;
+    if (p.bc) return fast_bc_kernel(p.r, true);       // its exchange buffer has room of its own
     const int T = 2 * p.nt * p.r;
     if (p.W - T < T / 2 + 1) return nullptr;          // the exchange buffer must fit the halo part
     switch (p.cg) {
@@ -164,16 +180,33 @@ static kern_t fast_epi_kernel(const Plan &p)
     }
 }
 
+template <int MODE>
+static kern_t ordered_bc_by_r(int r)
+{
+    switch (r) {
+    case 1: return conv_ordered_kernel<kOrderedThreads, 2, 1, MODE, true>;
+    case 2: return conv_ordered_kernel<kOrderedThreads, 2, 2, MODE, true>;
+    case 4: return conv_ordered_kernel<kOrderedThreads, 2, 4, MODE, true>;
+    case 8: return conv_ordered_kernel<kOrderedThreads, 2, 8, MODE, true>;
+    default: return nullptr;
+    }
+}
+
 static kern_t pick_kernel(const Plan &p, int mode)
 {
+    if (p.bc)
+        return mode == VND_MODE_FAST ? fast_bc_kernel(p.r, false)
+                                     : (mode == VND_MODE_EXACT ? ordered_bc_by_r<0>(p.r) : ordered_bc_by_r<1>(p.r));
     return mode == VND_MODE_FAST ? fast_kernel(p.nt, p.cg, p.r) : ordered_kernel(p.cg, p.r, mode);
 }
 
 static int halo_of(int max_index) { return (max_index + 2 + 15) & ~15; }
 
-static size_t lds_need(int nt, int cg, int r, int max_index)
+// bc: one plane, then the fast kernel's exchange buffer [cg][T/2 + 1] (rounded up to 16 B)
+static size_t lds_need(int nt, int cg, int r, int max_index, bool bc = false)
 {
     const size_t T = (size_t)2 * nt * r;
+    if (bc) return ((T + halo_of(max_index)) + (((size_t)cg * (T / 2 + 1) + 3) & ~(size_t)3)) * sizeof(float);
     return (size_t)cg * (T + halo_of(max_index)) * sizeof(float);
 }
 
@@ -184,7 +217,8 @@ static const int kOrderedR[] = {8, 4, 2, 1};
 // variant word (vnd_set_variant): bits 0-4 frame pairs per lane (0 = auto),
 // bits 8-11 channels per workgroup (0 = auto), bit 12 direct,
 // bits 16-17 threads per workgroup of the fast kernel (0: 256, 1: 128, 2: 512, 3: 1024).
-static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64_t n, int C, int mode)
+// Cx = interleaved input channels (== C for the plain call; a divisor of C for a fan-out).
+static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64_t n, int C, int mode, int Cx)
 {
     Plan p;
     const int v = ctx->variant;
@@ -199,10 +233,17 @@ static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int6
         const int sel = v >= 0 ? ((v >> 16) & 3) : 0;
         nt = sel == 1 ? 128 : sel == 2 ? 512 : sel == 3 ? 1024 : 256;
     }
+    // a workgroup's cg output channels must come from cg consecutive input channels, or all from
+    // the one channel of a mono input (bc: staged once)
+    bool bc = false;
+    if (Cx != C) {
+        if (Cx == 1 && C % 2 == 0 && !(v >= 0 && ((v >> 8) & 15) == 1)) { bc = true; cg = 2; nt = 256; }
+        else if (Cx % cg != 0) cg = (Cx % 2 == 0 && cg >= 2) ? 2 : 1;
+    }
     const int *sizes = fast ? kFastR : kOrderedR;
     const int nsizes = fast ? (int)(sizeof kFastR / sizeof *kFastR) : (int)(sizeof kOrderedR / sizeof *kOrderedR);
     const size_t limit = (size_t)ctx->lds_limit;
-    auto fits = [&](int r_) { return lds_need(nt, cg, r_, t->max_index) <= limit; };
+    auto fits = [&](int r_) { return lds_need(nt, cg, r_, t->max_index, bc) <= limit; };
 
     int r = (v >= 0) ? (v & 31) : 0;
     if (r != 0) {
@@ -219,11 +260,12 @@ static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int6
             if (sizes[i] > 4) continue;
             const int64_t T = (int64_t)2 * nt * sizes[i];
             const int64_t blocks = batch * ((n + T - 1) / T) * (C / cg);
-            if (blocks >= (int64_t)cus * 6 && lds_need(nt, cg, sizes[i], t->max_index) <= budget) { r = sizes[i]; break; }
+            if (blocks >= (int64_t)cus * 6 && lds_need(nt, cg, sizes[i], t->max_index, bc) <= budget) { r = sizes[i]; break; }
         }
     }
     // shrink until the tile fits one workgroup's LDS at all
     while (!fits(r)) {
+        if (bc) { bc = false; cg = 1; continue; }      // one plane per output channel, plain staging
         if (cg > 1) { cg /= 2; continue; }
         int smaller = 0;
         for (int i = 0; i < nsizes; ++i) if (sizes[i] < r) { smaller = sizes[i]; break; }
@@ -239,9 +281,9 @@ static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int6
         return p;
     }
     const int64_t T = (int64_t)2 * nt * r;
-    p.nt = nt; p.cg = cg; p.r = r;
+    p.nt = nt; p.cg = cg; p.r = r; p.bc = bc;
     p.W = (int)T + halo_of(t->max_index);
-    p.lds_bytes = lds_need(nt, cg, r, t->max_index);
+    p.lds_bytes = lds_need(nt, cg, r, t->max_index, bc);
     p.tiles = (int)((n + T - 1) / T);
     p.groups = C / cg;
     p.nblocks = (uint32_t)(batch * p.tiles * p.groups);
@@ -249,12 +291,14 @@ static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int6
 }
 
 static vnd_status check_shape(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64_t n,
-                              int32_t C, int32_t mode)
+                              int32_t C, int32_t mode, int32_t Cx = 0)
 {
     if (!ctx || !t) return fail(VND_ERR_INVALID, "null context or tap table");
     if (batch < 0 || n < 0) return fail(VND_ERR_INVALID, "negative batch or frame count");
     if (C != t->C)
         return fail(VND_ERR_INVALID, "signal has %d channels but the tap table has %d", C, t->C);
+    if (Cx != 0 && (Cx < 0 || C % Cx != 0))
+        return fail(VND_ERR_INVALID, "%d input channels do not divide the tap table's %d channels", Cx, C);
     if (mode != VND_MODE_EXACT && mode != VND_MODE_FMA && mode != VND_MODE_FAST)
         return fail(VND_ERR_INVALID, "unknown mode %d", mode);
     if (n > (int64_t)1 << 40 || batch * n * C / std::max<int64_t>(n, 1) > (int64_t)1 << 40)
@@ -269,16 +313,18 @@ struct EpiFuse {                 // non-null => launch the fused-epilogue instan
 };
 
 static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
-                         int64_t n, int32_t C, int32_t mode, hipStream_t stream, const EpiFuse *epi = nullptr)
+                         int64_t n, int32_t C, int32_t mode, hipStream_t stream, const EpiFuse *epi = nullptr,
+                         int32_t Cx = 0)
 {
     if (batch == 0 || n == 0) return VND_OK;
-    const Plan p = make_plan(ctx, t, batch, n, C, mode);
+    if (Cx == 0) Cx = C;
+    const Plan p = make_plan(ctx, t, batch, n, C, mode, Cx);
     KArgs a{};
     a.x = x; a.y = y; a.taps = t->d_taps; a.taps_fast = t->d_taps_fast; a.taps_ord = t->d_taps_ord; a.fast_off = t->d_fast_off; a.fast_even = t->d_fast_even; a.tap_off = t->d_tap_off;
     a.seg_off = t->has_seg ? t->d_seg_off : nullptr;
     a.seg_end = t->d_seg_end; a.seg_gain = t->d_seg_gain;
     a.chan_flags = t->has_flags ? t->d_flags : nullptr;
-    a.n = n; a.C = C; a.apply_gain = t->apply_gain;
+    a.n = n; a.C = C; a.Cx = Cx; a.apply_gain = t->apply_gain;
     a.nblocks = p.nblocks;
     if (p.direct) {
         a.tiles = (int32_t)batch; a.groups = 1; a.W = 0;
@@ -579,42 +625,81 @@ vnd_status vnd_taps_deserialize(vnd_ctx *ctx, const void *buf, int64_t bytes, vn
     return vnd_taps_create(ctx, C, tap_off, idx, w, seg_off, seg_end, seg_gain, flags, gain, out);
 }
 
-vnd_status vnd_convolve_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
-                                int64_t n, int32_t C, int32_t mode, void *stream)
+static vnd_status ensure_scratch(vnd_ctx *ctx, size_t elems)
 {
-    vnd_status st = check_shape(ctx, t, batch, n, C, mode);
+    if (elems <= ctx->scratch_elems) return VND_OK;
+    if (ctx->scratch_x) (void)hipFree(ctx->scratch_x);
+    if (ctx->scratch_y) (void)hipFree(ctx->scratch_y);
+    ctx->scratch_x = ctx->scratch_y = nullptr;
+    ctx->scratch_elems = 0;
+    HIP_TRY(hipMalloc((void **)&ctx->scratch_x, elems * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&ctx->scratch_y, elems * sizeof(float)));
+    ctx->scratch_elems = elems;
+    return VND_OK;
+}
+
+static bool overlaps(const float *x, int64_t x_elems, const float *y, int64_t y_elems)
+{
+    return (x < y + y_elems) && (y < x + x_elems);
+}
+
+// x: [batch][n][Cx], y: [batch][n][C]
+static vnd_status convolve_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
+                               int64_t n, int32_t Cx, int32_t C, int32_t mode, void *stream)
+{
+    vnd_status st = check_shape(ctx, t, batch, n, C, mode, Cx);
     if (st != VND_OK) return st;
     if (batch == 0 || n == 0) return VND_OK;
     if (!x || !y) return fail(VND_ERR_INVALID, "null signal pointer");
-    const int64_t elems = batch * n * C;
-    if ((x < y + elems) && (y < x + elems)) return fail(VND_ERR_INVALID, "x and y overlap");
-    return launch(ctx, t, x, y, batch, n, C, mode, (hipStream_t)stream);
+    if (overlaps(x, batch * n * Cx, y, batch * n * C)) return fail(VND_ERR_INVALID, "x and y overlap");
+    return launch(ctx, t, x, y, batch, n, C, mode, (hipStream_t)stream, nullptr, Cx);
+}
+
+static vnd_status convolve_host(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
+                                int64_t n, int32_t Cx, int32_t C, int32_t mode)
+{
+    vnd_status st = check_shape(ctx, t, batch, n, C, mode, Cx);
+    if (st != VND_OK) return st;
+    if (batch == 0 || n == 0) return VND_OK;
+    if (!x || !y) return fail(VND_ERR_INVALID, "null signal pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t in_elems = (size_t)batch * n * Cx, out_elems = (size_t)batch * n * C;
+    st = ensure_scratch(ctx, out_elems);
+    if (st != VND_OK) return st;
+    HIP_TRY(hipMemcpyAsync(ctx->scratch_x, x, in_elems * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    st = launch(ctx, t, ctx->scratch_x, ctx->scratch_y, batch, n, C, mode, ctx->stream, nullptr, Cx);
+    if (st != VND_OK) return st;
+    HIP_TRY(hipMemcpyAsync(y, ctx->scratch_y, out_elems * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VND_OK;
+}
+
+vnd_status vnd_convolve_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
+                                int64_t n, int32_t C, int32_t mode, void *stream)
+{
+    return convolve_dev(ctx, t, x, y, batch, n, C, C, mode, stream);
 }
 
 vnd_status vnd_convolve_f32_host(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
                                  int64_t n, int32_t C, int32_t mode)
 {
-    vnd_status st = check_shape(ctx, t, batch, n, C, mode);
-    if (st != VND_OK) return st;
-    if (batch == 0 || n == 0) return VND_OK;
-    if (!x || !y) return fail(VND_ERR_INVALID, "null signal pointer");
-    HIP_TRY(hipSetDevice(ctx->device));
-    const size_t elems = (size_t)batch * n * C;
-    if (elems > ctx->scratch_elems) {
-        if (ctx->scratch_x) (void)hipFree(ctx->scratch_x);
-        if (ctx->scratch_y) (void)hipFree(ctx->scratch_y);
-        ctx->scratch_x = ctx->scratch_y = nullptr;
-        ctx->scratch_elems = 0;
-        HIP_TRY(hipMalloc((void **)&ctx->scratch_x, elems * sizeof(float)));
-        HIP_TRY(hipMalloc((void **)&ctx->scratch_y, elems * sizeof(float)));
-        ctx->scratch_elems = elems;
-    }
-    HIP_TRY(hipMemcpyAsync(ctx->scratch_x, x, elems * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    st = launch(ctx, t, ctx->scratch_x, ctx->scratch_y, batch, n, C, mode, ctx->stream);
-    if (st != VND_OK) return st;
-    HIP_TRY(hipMemcpyAsync(y, ctx->scratch_y, elems * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return VND_OK;
+    return convolve_host(ctx, t, x, y, batch, n, C, C, mode);
+}
+
+vnd_status vnd_convolve_fanout_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
+                                       int64_t n, int32_t in_channels, int32_t mode, void *stream)
+{
+    if (!t) return fail(VND_ERR_INVALID, "null context or tap table");
+    if (in_channels <= 0) return fail(VND_ERR_INVALID, "in_channels must be positive");
+    return convolve_dev(ctx, t, x, y, batch, n, in_channels, t->C, mode, stream);
+}
+
+vnd_status vnd_convolve_fanout_f32_host(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
+                                        int64_t n, int32_t in_channels, int32_t mode)
+{
+    if (!t) return fail(VND_ERR_INVALID, "null context or tap table");
+    if (in_channels <= 0) return fail(VND_ERR_INVALID, "in_channels must be positive");
+    return convolve_host(ctx, t, x, y, batch, n, in_channels, t->C, mode);
 }
 
 vnd_status vnd_time_convolve_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
@@ -653,21 +738,35 @@ vnd_status vnd_set_variant(vnd_ctx *ctx, int32_t variant)
     return VND_OK;
 }
 
-vnd_status vnd_describe_launch(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64_t n, int32_t C,
-                               int32_t mode, char *text, int32_t len)
+static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64_t n, int32_t Cx, int32_t C,
+                           int32_t mode, char *text, int32_t len)
 {
-    vnd_status st = check_shape(ctx, t, batch, n, C, mode);
+    vnd_status st = check_shape(ctx, t, batch, n, C, mode, Cx);
     if (st != VND_OK) return st;
     if (!text || len <= 0) return fail(VND_ERR_INVALID, "null text buffer");
-    const Plan p = make_plan(ctx, t, batch, n, C, mode);
+    const Plan p = make_plan(ctx, t, batch, n, C, mode, Cx);
     if (p.direct)
         snprintf(text, (size_t)len, "conv_direct mode=%d blocks=%u threads=%d", mode, p.nblocks, kDirectThreads);
     else
         snprintf(text, (size_t)len,
-                 "%s cg=%d pairs_per_lane=%d tile=%d halo=%d mode=%d lds=%zuB workgroups=%u threads=%d",
-                 mode == VND_MODE_FAST ? "conv_fast" : "conv_ordered", p.cg, p.r, 2 * p.nt * p.r,
-                 p.W - 2 * p.nt * p.r, mode, p.lds_bytes, p.nblocks, p.nt);
+                 "%s%s cg=%d pairs_per_lane=%d tile=%d halo=%d mode=%d lds=%zuB workgroups=%u threads=%d",
+                 mode == VND_MODE_FAST ? "conv_fast" : "conv_ordered", p.bc ? "_fanout" : "", p.cg, p.r,
+                 2 * p.nt * p.r, p.W - 2 * p.nt * p.r, mode, p.lds_bytes, p.nblocks, p.nt);
     return VND_OK;
+}
+
+vnd_status vnd_describe_launch(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64_t n, int32_t C,
+                               int32_t mode, char *text, int32_t len)
+{
+    return describe(ctx, t, batch, n, C, C, mode, text, len);
+}
+
+vnd_status vnd_describe_fanout_launch(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64_t n,
+                                      int32_t in_channels, int32_t mode, char *text, int32_t len)
+{
+    if (!t) return fail(VND_ERR_INVALID, "null context or tap table");
+    if (in_channels <= 0) return fail(VND_ERR_INVALID, "in_channels must be positive");
+    return describe(ctx, t, batch, n, in_channels, t->C, mode, text, len);
 }
 
 static int64_t epi_chunks(int64_t n) { return (n + kEpiChunk - 1) / kEpiChunk; }
@@ -682,17 +781,16 @@ vnd_status vnd_decorrelate_workspace_bytes(int64_t batch, int64_t n, int32_t C, 
     return VND_OK;
 }
 
-vnd_status vnd_decorrelate_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
-                                   int64_t n, int32_t C, int32_t mode, int32_t ms_encode, int32_t use_width,
-                                   double width, int32_t normalize, float eps, void *workspace,
-                                   int64_t workspace_bytes, void *stream_)
+static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
+                                  int64_t n, int32_t Cx, int32_t C, int32_t mode, int32_t ms_encode,
+                                  int32_t use_width, double width, int32_t normalize, float eps, void *workspace,
+                                  int64_t workspace_bytes, void *stream_)
 {
-    vnd_status st = check_shape(ctx, t, batch, n, C, mode);
+    vnd_status st = check_shape(ctx, t, batch, n, C, mode, Cx);
     if (st != VND_OK) return st;
     if (batch == 0 || n == 0) return VND_OK;
     if (!x || !y) return fail(VND_ERR_INVALID, "null signal pointer");
-    const int64_t elems = batch * n * C;
-    if ((x < y + elems) && (y < x + elems)) return fail(VND_ERR_INVALID, "x and y overlap");
+    if (overlaps(x, batch * n * Cx, y, batch * n * C)) return fail(VND_ERR_INVALID, "x and y overlap");
     if ((ms_encode || use_width) && C != 2)
         return fail(VND_ERR_INVALID, "side-channel encode and stereo width need 2 channels, got %d", C);
     int64_t need = 0;
@@ -704,7 +802,7 @@ vnd_status vnd_decorrelate_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const float 
     const bool any = ms_encode || use_width || normalize;
 
     EArgs e{};
-    e.x = x; e.y = y; e.partials = (double *)workspace; e.n = n; e.C = C;
+    e.x = x; e.y = y; e.partials = (double *)workspace; e.n = n; e.C = C; e.Cx = Cx;
     e.scales = (float *)((double *)workspace + batch * epi_rows_max(n) * 2 * C);
     e.ms_encode = ms_encode ? 1 : 0; e.use_width = use_width ? 1 : 0;
     e.w_mid = (float)(1.0 - width); e.w_side = (float)width;   // float32(python float), as NumPy's in-place multiply
@@ -712,16 +810,16 @@ vnd_status vnd_decorrelate_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const float 
     const dim3 grid((unsigned)epi_chunks(n), (unsigned)batch);
 
     // Fused form: the fast kernel applies the pointwise steps and writes one row of sums per tile.
-    const Plan p = make_plan(ctx, t, batch, n, C, mode);
+    const Plan p = make_plan(ctx, t, batch, n, C, mode, Cx);
     const bool fused = any && mode == VND_MODE_FAST && ctx->variant_nofuse == 0 && fast_epi_kernel(p) != nullptr &&
                        (!(ms_encode || use_width) || p.cg == 2);
     if (fused) {
         EpiFuse f{(double *)workspace, e.ms_encode, e.use_width, e.normalize, e.w_mid, e.w_side};
-        st = launch(ctx, t, x, y, batch, n, C, mode, stream, &f);
+        st = launch(ctx, t, x, y, batch, n, C, mode, stream, &f, Cx);
         if (st != VND_OK) return st;
         e.rows = p.tiles;
     } else {
-        st = launch(ctx, t, x, y, batch, n, C, mode, stream);
+        st = launch(ctx, t, x, y, batch, n, C, mode, stream, nullptr, Cx);
         if (st != VND_OK || !any) return st;
         e.rows = (int32_t)epi_chunks(n);
         hipLaunchKernelGGL(epilogue_pointwise_kernel, grid, dim3(kEpiThreads), 0, stream, e);
@@ -734,39 +832,74 @@ vnd_status vnd_decorrelate_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const float 
     return VND_OK;
 }
 
-vnd_status vnd_decorrelate_f32_host(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
-                                    int64_t n, int32_t C, int32_t mode, int32_t ms_encode, int32_t use_width,
-                                    double width, int32_t normalize, float eps)
+static vnd_status decorrelate_host(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
+                                   int64_t n, int32_t Cx, int32_t C, int32_t mode, int32_t ms_encode,
+                                   int32_t use_width, double width, int32_t normalize, float eps)
 {
-    vnd_status st = check_shape(ctx, t, batch, n, C, mode);
+    vnd_status st = check_shape(ctx, t, batch, n, C, mode, Cx);
     if (st != VND_OK) return st;
     if (batch == 0 || n == 0) return VND_OK;
     if (!x || !y) return fail(VND_ERR_INVALID, "null signal pointer");
     HIP_TRY(hipSetDevice(ctx->device));
-    const size_t elems = (size_t)batch * n * C;
-    if (elems > ctx->scratch_elems) {
-        if (ctx->scratch_x) (void)hipFree(ctx->scratch_x);
-        if (ctx->scratch_y) (void)hipFree(ctx->scratch_y);
-        ctx->scratch_x = ctx->scratch_y = nullptr;
-        ctx->scratch_elems = 0;
-        HIP_TRY(hipMalloc((void **)&ctx->scratch_x, elems * sizeof(float)));
-        HIP_TRY(hipMalloc((void **)&ctx->scratch_y, elems * sizeof(float)));
-        ctx->scratch_elems = elems;
-    }
+    const size_t in_elems = (size_t)batch * n * Cx, out_elems = (size_t)batch * n * C;
+    st = ensure_scratch(ctx, out_elems);
+    if (st != VND_OK) return st;
     int64_t ws = 0;
     vnd_decorrelate_workspace_bytes(batch, n, C, &ws);
     void *workspace = nullptr;
     HIP_TRY(hipMalloc(&workspace, (size_t)ws));
-    HIP_TRY(hipMemcpyAsync(ctx->scratch_x, x, elems * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    st = vnd_decorrelate_f32_dev(ctx, t, ctx->scratch_x, ctx->scratch_y, batch, n, C, mode, ms_encode, use_width,
-                                 width, normalize, eps, workspace, ws, ctx->stream);
+    hipError_t he = hipMemcpyAsync(ctx->scratch_x, x, in_elems * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (he != hipSuccess) {
+        (void)hipFree(workspace);
+        return fail(VND_ERR_HIP, "copy in: %s", hipGetErrorString(he));
+    }
+    st = decorrelate_dev(ctx, t, ctx->scratch_x, ctx->scratch_y, batch, n, Cx, C, mode, ms_encode, use_width,
+                         width, normalize, eps, workspace, ws, ctx->stream);
     if (st == VND_OK) {
-        hipError_t e = hipMemcpyAsync(y, ctx->scratch_y, elems * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t e = hipMemcpyAsync(y, ctx->scratch_y, out_elems * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) st = fail(VND_ERR_HIP, "copy back: %s", hipGetErrorString(e));
     }
     (void)hipFree(workspace);
     return st;
+}
+
+vnd_status vnd_decorrelate_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
+                                   int64_t n, int32_t C, int32_t mode, int32_t ms_encode, int32_t use_width,
+                                   double width, int32_t normalize, float eps, void *workspace,
+                                   int64_t workspace_bytes, void *stream)
+{
+    return decorrelate_dev(ctx, t, x, y, batch, n, C, C, mode, ms_encode, use_width, width, normalize, eps,
+                           workspace, workspace_bytes, stream);
+}
+
+vnd_status vnd_decorrelate_f32_host(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
+                                    int64_t n, int32_t C, int32_t mode, int32_t ms_encode, int32_t use_width,
+                                    double width, int32_t normalize, float eps)
+{
+    return decorrelate_host(ctx, t, x, y, batch, n, C, C, mode, ms_encode, use_width, width, normalize, eps);
+}
+
+vnd_status vnd_decorrelate_fanout_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y,
+                                          int64_t batch, int64_t n, int32_t in_channels, int32_t mode,
+                                          int32_t ms_encode, int32_t use_width, double width, int32_t normalize,
+                                          float eps, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (!t) return fail(VND_ERR_INVALID, "null context or tap table");
+    if (in_channels <= 0) return fail(VND_ERR_INVALID, "in_channels must be positive");
+    return decorrelate_dev(ctx, t, x, y, batch, n, in_channels, t->C, mode, ms_encode, use_width, width, normalize,
+                           eps, workspace, workspace_bytes, stream);
+}
+
+vnd_status vnd_decorrelate_fanout_f32_host(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y,
+                                           int64_t batch, int64_t n, int32_t in_channels, int32_t mode,
+                                           int32_t ms_encode, int32_t use_width, double width, int32_t normalize,
+                                           float eps)
+{
+    if (!t) return fail(VND_ERR_INVALID, "null context or tap table");
+    if (in_channels <= 0) return fail(VND_ERR_INVALID, "in_channels must be positive");
+    return decorrelate_host(ctx, t, x, y, batch, n, in_channels, t->C, mode, ms_encode, use_width, width,
+                            normalize, eps);
 }
 
 #ifdef VND_STAMPS

@@ -29,6 +29,7 @@ struct EArgs {
     float *__restrict__ scales;      // [batch][C], written by the reduce kernel
     int64_t n;
     int32_t C;
+    int32_t Cx;                      // input channels: output channel c pairs with input channel c % Cx
     int32_t rows;                    // rows of partial sums per stream (pass-1 chunks, or tiles when fused)
     int32_t ms_encode;               // stereo only
     int32_t use_width;               // stereo only
@@ -58,8 +59,8 @@ __global__ __launch_bounds__(kEpiThreads) void epilogue_pointwise_kernel(const E
     __shared__ double scratch[kEpiThreads / 64];
     const int64_t b = blockIdx.y;
     const int chunk = blockIdx.x;
-    const int C = a.C;
-    const float *__restrict__ xs = a.x + b * a.n * C;
+    const int C = a.C, Cx = a.Cx;
+    const float *__restrict__ xs = a.x + b * a.n * Cx;
     float *__restrict__ ys = a.y + b * a.n * C;
     const int64_t f0 = (int64_t)chunk * kEpiChunk;
     double *out = a.partials + (b * a.rows + chunk) * 2 * C;
@@ -70,7 +71,9 @@ __global__ __launch_bounds__(kEpiThreads) void epilogue_pointwise_kernel(const E
         for (int i = 0; i < kEpiFramesPerThread; ++i) {
             const int64_t f = f0 + threadIdx.x + (int64_t)i * kEpiThreads;
             if (f >= a.n) break;
-            const float2 xv = *(const float2 *)(xs + 2 * f);
+            float2 xv;
+            if (Cx == 2) xv = *(const float2 *)(xs + 2 * f);
+            else { xv.x = xs[f]; xv.y = xv.x; }          // mono input fanned out to both channels
             float2 yv = *(const float2 *)(ys + 2 * f);
             if (a.ms_encode) {                       // utils/dsp.py:59-63
                 const float mid = xv.x + xv.y;
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(kEpiThreads) void epilogue_pointwise_kernel(const E
         for (int i = 0; i < kEpiFramesPerThread; ++i) {
             const int64_t f = f0 + threadIdx.x + (int64_t)i * kEpiThreads;
             if (f >= a.n) break;
-            const float xv = xs[f * C + c], yv = ys[f * C + c];
+            const float xv = xs[f * Cx + c % Cx], yv = ys[f * C + c];
             sx += xv * xv;
             sy += yv * yv;
         }

@@ -62,7 +62,8 @@ struct KArgs {
     const float *__restrict__ seg_gain;
     const uint8_t *__restrict__ chan_flags; // bit0: pass-through, or nullptr
     int64_t n;                 // frames per stream
-    int32_t C;                 // interleaved channels
+    int32_t C;                 // interleaved output channels (= channels of the tap table)
+    int32_t Cx;                // interleaved input channels; output channel c reads input channel c % Cx
     int32_t groups;            // C / CG
     int32_t tiles;             // tiles per stream
     int32_t W;                 // floats per LDS plane (tile + halo, even)
@@ -499,25 +500,30 @@ __device__ unsigned long long g_stamps[8 * 65536];
 // epi_partials for the scaling pass - the tile's input is still in LDS, so the fused
 // form saves a full read of x and a read + write of y.  The exchange buffer then lives
 // in the halo part of the planes (the host only picks EPI when it fits there).
-template <int NT, int CG, int R, bool EPI = false>
+//
+// BC (fan-out of a mono input, Cx == 1): ONE plane is staged and every output channel of
+// the group reads it; the exchange buffer then follows the plane instead of reusing it.
+template <int NT, int CG, int R, bool EPI = false, bool BC = false>
 __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int T = 2 * NT * R;
+    constexpr int PG = BC ? 1 : CG;                          // planes staged
     const int tid = threadIdx.x;
     const int W = a.W;
     VND_STAMP(0);
     const BlockCoord bc = decode_block(a);
-    const int C = a.C;
+    const int C = a.C, Cx = a.Cx;
     const int c0 = bc.group * CG;
+    const int cx0 = BC ? 0 : (Cx == C ? c0 : c0 % Cx);       // the host keeps Cx % CG == 0 unless BC
     const int64_t t0 = (int64_t)bc.tile * T;
-    const float *__restrict__ xs = a.x + bc.stream * a.n * C;
+    const float *__restrict__ xs = a.x + bc.stream * a.n * Cx;
     float *__restrict__ ys = a.y + bc.stream * a.n * C;
     const int64_t bytes_left = ((a.n - t0) * C - c0) * 4;
-    float *plane = lds;                                      // [CG][W]
+    float *plane = lds;                                      // [PG][W]
 
     VND_STAMP(1);
-    stage_window<NT, CG>(plane, xs + t0 * C + c0, bytes_left, C, W, tid);
+    stage_window<NT, PG>(plane, xs + t0 * Cx + cx0, ((a.n - t0) * Cx - cx0) * 4, Cx, W, tid);
     VND_STAMP(2);
     __syncthreads();
     VND_STAMP(3);
@@ -530,7 +536,7 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
 #pragma unroll
     for (int c = 0; c < CG; ++c) {
         const int ch = c0 + c;
-        const float *pc = plane + c * W;
+        const float *pc = plane + (BC ? 0 : c * W);
         const float *pa = pc + lane_base;
         edge[c] = 0.0f;
 #pragma unroll
@@ -573,9 +579,9 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
     VND_STAMP(5);
     constexpr int XS = T / 2 + 1;
     // exchange buffer [CG][T/2 + 1]: over the dead window, or (EPI) in each plane's halo part,
-    // which keeps the tile's own input x[0 .. T) readable for the epilogue
-    float *xo = EPI ? lds + T : lds;
-    const int xs_stride = EPI ? W : XS;
+    // which keeps the tile's own input x[0 .. T) readable for the epilogue, or (BC) behind the plane
+    float *xo = BC ? lds + W : (EPI ? lds + T : lds);
+    const int xs_stride = (EPI && !BC) ? W : XS;
 #pragma unroll
     for (int c = 0; c < CG; ++c) {
 #pragma unroll
@@ -606,7 +612,7 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
             float xin[2 * CG];
 #pragma unroll
             for (int c = 0; c < CG; ++c) {
-                const float2 xp = *(const float2 *)(lds + c * W + 2 * q);
+                const float2 xp = *(const float2 *)(lds + (BC ? 0 : c * W) + 2 * q);
                 xin[c] = xp.x; xin[CG + c] = xp.y;
             }
             if constexpr (CG == 2) {
@@ -715,22 +721,24 @@ __device__ __forceinline__ void ordered_tap(const FastTap &t, unsigned lane_addr
     }
 }
 
-template <int NT, int CG, int R, int MODE>
+template <int NT, int CG, int R, int MODE, bool BC = false>
 __global__ __launch_bounds__(NT) void conv_ordered_kernel(const KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int T = 2 * NT * R;
+    constexpr int PG = BC ? 1 : CG;
     const int tid = threadIdx.x;
     const int W = a.W;
     const BlockCoord bc = decode_block(a);
-    const int C = a.C;
+    const int C = a.C, Cx = a.Cx;
     const int c0 = bc.group * CG;
+    const int cx0 = BC ? 0 : (Cx == C ? c0 : c0 % Cx);
     const int64_t t0 = (int64_t)bc.tile * T;
-    const float *__restrict__ xs = a.x + bc.stream * a.n * C;
+    const float *__restrict__ xs = a.x + bc.stream * a.n * Cx;
     float *__restrict__ ys = a.y + bc.stream * a.n * C;
     const int64_t bytes_left = ((a.n - t0) * C - c0) * 4;
 
-    stage_window<NT, CG>(lds, xs + t0 * C + c0, bytes_left, C, W, tid);
+    stage_window<NT, PG>(lds, xs + t0 * Cx + cx0, ((a.n - t0) * Cx - cx0) * 4, Cx, W, tid);
     __syncthreads();
 
     v2f out[CG][R];
@@ -738,7 +746,7 @@ __global__ __launch_bounds__(NT) void conv_ordered_kernel(const KArgs a)
 #pragma unroll
     for (int c = 0; c < CG; ++c) {
         const int ch = c0 + c;
-        const float *pa = lds + c * W + 2 * tid;
+        const float *pa = lds + (BC ? 0 : c * W) + 2 * tid;
         if (a.chan_flags != nullptr && (a.chan_flags[ch] & 1)) {      // unfiltered: copy through
 #pragma unroll
             for (int j = 0; j < R; ++j) out[c][j] = *(const v2f *)(pa + 2 * NT * j);
@@ -823,8 +831,9 @@ __global__ __launch_bounds__(kDirectThreads) void conv_direct_kernel(const KArgs
         const int64_t r = e - b * per_stream;
         const int64_t n0 = r / a.C;
         const int ch = (int)(r - n0 * a.C);
-        const float *__restrict__ xs = a.x + b * per_stream;
-        if (a.chan_flags != nullptr && (a.chan_flags[ch] & 1)) { a.y[e] = xs[r]; continue; }
+        const int Cx = a.Cx, cx = ch % Cx;
+        const float *__restrict__ xs = a.x + b * a.n * Cx;
+        if (a.chan_flags != nullptr && (a.chan_flags[ch] & 1)) { a.y[e] = xs[n0 * Cx + cx]; continue; }
         const bool has_seg = a.seg_off != nullptr;
         int k = a.tap_off[ch];
         const int k_last = a.tap_off[ch + 1];
@@ -837,7 +846,7 @@ __global__ __launch_bounds__(kDirectThreads) void conv_direct_kernel(const KArgs
             for (; k < kend; ++k) {
                 const Tap tp = a.taps[k];
                 const int64_t m = n0 + tp.idx;
-                const float v = m < a.n ? xs[m * a.C + ch] : 0.0f;
+                const float v = m < a.n ? xs[m * Cx + cx] : 0.0f;
                 sb = tap_op<MODE>(sb, v, tp.w);
             }
             if (has_seg) {

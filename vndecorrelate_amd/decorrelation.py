@@ -36,7 +36,7 @@ import numpy as np
 from numpy.typing import NDArray
 
 from . import _native
-from .taps import TapArrays, class_path_arrays, function_path_arrays
+from .taps import TapArrays, class_path_arrays, concat_tap_arrays, function_path_arrays
 from .utils.dsp import (
     IDENTITY_ENVELOPE,
     LayoutMode,
@@ -254,6 +254,33 @@ def convolve_velvet_noise_batched(input_signals: NDArray, velvet_noise_filters: 
     table = _fir_tables.get(_fir_key(fir, num_channels),
                             lambda: function_path_arrays(fir, num_channels))
     return table.convolve_host(x, _default_mode if mode is None else mode)
+
+
+def convolve_velvet_noise_bank(input_signal: NDArray, filter_bank: Sequence[NDArray], *,
+                               mode: Optional[int] = None) -> NDArray:
+    """One ``(n, C)`` signal through F filters ``(L_f, C)`` in a single launch; returns
+    ``(F, n, C)`` float32 (a transposed view of the device result) with
+    ``out[f] == convolve_velvet_noise(input_signal, filter_bank[f])``, bit for bit in the
+    exact mode.  This is the candidate scan of the reference's optimiser
+    (optimization.py:107-117 runs the F convolutions one after the other): the signal is
+    uploaded once and every tile is staged per filter from L2, not from the host."""
+    if input_signal.ndim != 2:
+        raise ValueError(f'expected a (n, C) signal, got shape {input_signal.shape}')
+    firs = [np.asarray(f) if np.asarray(f).ndim == 2 else np.asarray(f)[:, None] for f in filter_bank]
+    if not firs:
+        raise ValueError('empty filter bank')
+    num_channels = input_signal.shape[1]
+    for fir in firs:
+        if num_channels > 1:
+            check_equal_length(input_signal, fir, dim=1)
+    x = np.ascontiguousarray(input_signal, dtype=np.float32)
+    if x.shape[0] == 0 or num_channels == 0:
+        return np.zeros((len(firs),) + x.shape, dtype=np.float32)
+    key = ('bank', num_channels) + tuple(_fir_key(fir, num_channels) for fir in firs)
+    table = _fir_tables.get(key, lambda: concat_tap_arrays([function_path_arrays(fir, num_channels)
+                                                             for fir in firs]))
+    y = table.convolve_host(x, _default_mode if mode is None else mode)       # (n, F*C)
+    return y.reshape(x.shape[0], len(firs), num_channels).transpose(1, 0, 2)
 
 
 # ----------------------------------------------------------------------------
@@ -484,11 +511,22 @@ class VelvetNoise(Decorrelator):
         GPU convolution, then the host epilogue - side-channel encode (MS mode),
         width, normaliser."""
         input_signal = to_float32(input_signal)
+        mono = None
         if input_signal.ndim == 1:
+            # the device reads the one channel for both outputs (fan-out) instead of a copy
+            if self.num_outs == 2 and input_signal.shape[0] > 0:
+                mono = np.ascontiguousarray(input_signal, dtype=np.float32)[:, None]
             input_signal = mono_to_stereo(input_signal)
         if _device_epilogue and self._device_epilogue_applies(input_signal):
-            return self._decorrelate_on_device(input_signal)
-        output_signal = self.convolve(input_signal)
+            return self._decorrelate_on_device(input_signal if mono is None else mono)
+        if mono is not None:
+            output_signal = self._device_table().convolve_host(mono, _default_mode)
+        else:
+            output_signal = self.convolve(input_signal)
+        return self._host_epilogue(input_signal, output_signal)
+
+    def _host_epilogue(self, input_signal: NDArray, output_signal: NDArray) -> NDArray:
+        """decorrelation.py:433-440, in place on ``output_signal`` (NumPy: bit-identical)."""
         if self.mode == LayoutMode.MS:
             encode_signal_to_side_channel(input_signal, output_signal)
         if self.width is not None:
@@ -507,9 +545,9 @@ class VelvetNoise(Decorrelator):
 
     def _decorrelate_on_device(self, x: NDArray) -> NDArray:
         stereo_steps = self.mode == LayoutMode.MS or self.width is not None
-        if stereo_steps and x.shape[-1] != 2:
+        if stereo_steps and self.num_outs != 2:
             raise ValueError('Input shape invalid: Expected shape (num samples, 2), '
-                             f'but got shape {x.shape}.')
+                             f'but got shape {x.shape[:-1] + (self.num_outs,)}.')
         table = self._device_table()
         return table.decorrelate_host(np.ascontiguousarray(x, dtype=np.float32), _default_mode,
                                       ms_encode=self.mode == LayoutMode.MS, width=self.width,
@@ -521,9 +559,45 @@ class VelvetNoise(Decorrelator):
         x = to_float32(np.asarray(input_signals))
         if x.ndim != 3:
             raise ValueError(f'expected (batch, n, channels), got shape {x.shape}')
+        if x.shape[-1] == 1 and self.num_outs == 2 and x.shape[1] > 0 and \
+                (self.normalizer is None or self.normalizer is rms_normalize):
+            return self._decorrelate_on_device(x)           # mono signals, fanned out on the device
         if not self._device_epilogue_applies(x):
             return np.stack([self.decorrelate(sig) for sig in x]) if len(x) else np.zeros(x.shape, np.float32)
         return self._decorrelate_on_device(x)
+
+
+def decorrelate_bank(input_signal: NDArray, decorrelators: Sequence[VelvetNoise]) -> List[NDArray]:
+    """``[d.decorrelate(input_signal) for d in decorrelators]`` with the F convolutions in ONE
+    device launch (the tables concatenated channel-wise, the signal fanned out to them) and
+    each decorrelator's own epilogue on the host afterwards - the shape of the reference
+    optimiser's candidate scan (optimization.py:71, :107-117).  Bit-identical to the loop
+    in the exact mode."""
+    decorrelators = list(decorrelators)
+    if not decorrelators:
+        return []
+    num_outs = decorrelators[0].num_outs
+    if any(d.num_outs != num_outs for d in decorrelators):
+        raise ValueError('all decorrelators of a bank must have the same num_outs')
+    input_signal = to_float32(input_signal)
+    if input_signal.ndim == 1:
+        input_signal = mono_to_stereo(input_signal)
+    if input_signal.ndim != 2:
+        raise IndexError('too many indices for array: decorrelate expects a (n,) or (n, channels) signal')
+    x = np.ascontiguousarray(input_signal[:, :num_outs], dtype=np.float32)
+    if x.shape[1] != num_outs:
+        raise IndexError(f'index {num_outs - 1} is out of bounds for axis 1 with size {input_signal.shape[1]}')
+    if x.shape[0] == 0:
+        return [d.decorrelate(input_signal) for d in decorrelators]
+    arrays = concat_tap_arrays([d._tap_arrays() for d in decorrelators])
+    table = _native.TapTable.create(_native.default_context(), arrays.tap_offsets, arrays.tap_index,
+                                    arrays.tap_weight, **arrays.kwargs())
+    try:
+        y = table.convolve_host(x, _default_mode)                           # (n, F * num_outs)
+    finally:
+        table.close()
+    return [d._host_epilogue(input_signal, np.ascontiguousarray(y[:, f * num_outs:(f + 1) * num_outs]))
+            for f, d in enumerate(decorrelators)]
 
 
 # ----------------------------------------------------------------------------

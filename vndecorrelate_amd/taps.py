@@ -142,3 +142,42 @@ def class_path_arrays(channels: Sequence, envelope: Sequence[float], apply_gain:
                      np.asarray(w, np.float32), np.asarray(seg_offsets, np.int32),
                      np.asarray(seg_end, np.int32), np.asarray(seg_gain, np.float32),
                      np.asarray(flags, np.uint8), bool(apply_gain))
+
+
+def concat_tap_arrays(tables: Sequence[TapArrays]) -> TapArrays:
+    """Channel-wise concatenation: a bank of F tables of C channels each becomes one table
+    of F*C channels (table f owns channels ``f*C .. f*C+C-1``), the shape the fan-out
+    launch wants (``vnd_convolve_fanout_*``: output channel c reads input channel c % C).
+    All tables must be of the same kind (function path, or class path with segments).
+    A class-path bank applies gains as soon as one member does; the others carry gain 1.0,
+    and multiplying by 1.0 is exact."""
+    tables = list(tables)
+    if not tables:
+        raise ValueError('empty filter bank')
+    with_seg = [t.seg_offsets is not None for t in tables]
+    if any(with_seg) and not all(with_seg):
+        raise ValueError('cannot mix function-path and class-path tables in one bank')
+    tap_offsets, idx, w = [np.zeros(1, np.int32)], [], []
+    seg_offsets, seg_end, seg_gain, flags = [np.zeros(1, np.int32)], [], [], []
+    tap_base = seg_base = 0
+    for t in tables:
+        tap_offsets.append(t.tap_offsets[1:].astype(np.int64) + tap_base)
+        idx.append(t.tap_index)
+        w.append(t.tap_weight)
+        if with_seg[0]:
+            seg_offsets.append(t.seg_offsets[1:].astype(np.int64) + seg_base)
+            seg_end.append(t.seg_end.astype(np.int64) + tap_base)
+            seg_gain.append(t.seg_gain)
+            seg_base += len(t.seg_end)
+        flags.append(t.chan_flags if t.chan_flags is not None else np.zeros(t.num_channels, np.uint8))
+        tap_base += len(t.tap_index)
+    out = TapArrays(np.concatenate(tap_offsets).astype(np.int32), np.concatenate(idx).astype(np.int32),
+                    np.concatenate(w).astype(np.float32))
+    if with_seg[0]:
+        out.seg_offsets = np.concatenate(seg_offsets).astype(np.int32)
+        out.seg_end = np.concatenate(seg_end).astype(np.int32)
+        out.seg_gain = np.concatenate(seg_gain).astype(np.float32)
+        out.apply_gain = any(t.apply_gain for t in tables)
+    if any(t.chan_flags is not None for t in tables):
+        out.chan_flags = np.concatenate(flags).astype(np.uint8)
+    return out
