@@ -153,6 +153,27 @@ vnd_status vnd_decorrelate_fanout_f32_host(vnd_ctx *ctx, const vnd_taps *taps, c
                                            int32_t mode, int32_t ms_encode, int32_t use_width, double width,
                                            int32_t normalize, float eps);
 
+/* ---- candidate scan: many filters, one signal, scores instead of signals -------
+ * Replaces the loop of optimization.py:107-117 (grid_scan) over
+ * symmetry_aware_objective (:46-105): the bank's F stereo pairs are convolved in one
+ * fan-out launch and reduced on the device to VND_MOMENTS doubles per pair,
+ *   {sum r, sum r*theta, sum r*theta^2, sum r*theta^3, max|theta|, sum L*R, sum L^2, sum R^2}
+ * with r, theta the polar samples of utils/dsp.py:374-422 (MS angle, folded, radii not
+ * normalised); the objective's terms are quotients of these.  float32 element maths as
+ * NumPy, float64 sums: scores agree with the reference to ~1e-7 relative.
+ * vnd_polar_moments_f32_dev reduces an existing device array y[n_frames][2*n_pairs];
+ * vnd_scan_bank_f32_host runs the whole scan from a host signal (in_channels 1 or 2; the
+ * bank table has 2*n_pairs channels) and returns moments[n_pairs][VND_MOMENTS].  The
+ * candidates' convolution only (no side-channel encode / width / normaliser), which is
+ * what optimize_velvet_noise builds (optimization.py:259-271: mode LR, normalizer None). */
+#define VND_MOMENTS 8
+vnd_status vnd_polar_moments_workspace_bytes(int64_t n_frames, int32_t n_pairs, int64_t *bytes);
+vnd_status vnd_polar_moments_f32_dev(vnd_ctx *ctx, const float *y_dev, int64_t n_frames, int32_t n_pairs,
+                                     double *moments_dev, void *workspace_dev, int64_t workspace_bytes,
+                                     void *hip_stream);
+vnd_status vnd_scan_bank_f32_host(vnd_ctx *ctx, const vnd_taps *bank, const float *x, int64_t n_frames,
+                                  int32_t in_channels, int32_t mode, double *moments);
+
 /* ---- measurement helpers (used by bench.py; not on the data path) ---------- */
 /* Launches the convolve `iters` times back to back on `hip_stream`, cycling
  * through `n_buffers` (x,y) pairs laid out at x_dev + i*stride_elems, and

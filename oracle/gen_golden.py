@@ -67,7 +67,8 @@ def load_reference():
     dsp = load('vndecorrelate.utils.dsp', src / 'utils' / 'dsp.py')
     dec = load('vndecorrelate.decorrelation', src / 'decorrelation.py',
                lambda t: t.replace('type _LazyDecorrelator = ', '_LazyDecorrelator = '))
-    return dsp, dec
+    opt = load('vndecorrelate.optimization', src / 'optimization.py')
+    return dsp, dec, opt
 
 
 def sha(a: np.ndarray) -> str:
@@ -243,11 +244,11 @@ def ref_taps_to_nested(vn):
 
 
 def main():
-    dsp, dec = load_reference()
+    dsp, dec, opt = load_reference()
     OUT.mkdir(parents=True, exist_ok=True)
     manifest = {'reference': 'ckonst/VNDecorrelate v1.1.0', 'numpy': np.__version__,
                 'slice': SLICE, 'generators': {}, 'fn': {}, 'cls_convolve': {},
-                'cls_decorrelate': {}, 'class_taps': {}, 'known_answers': {}, 'audio': {}}
+                'cls_decorrelate': {}, 'class_taps': {}, 'known_answers': {}, 'audio': {}, 'objective': {}}
     arrays = {}
 
     # ---- a2/a3/a4: generator ------------------------------------------------
@@ -411,6 +412,55 @@ def main():
          O.decorrelate(excerpt.copy(), **oracle_class_kwargs(CLS['v44k_20ms'])), 'viola excerpt')
     manifest['audio']['viola_excerpt'] = {'fs': int(fs), 'start_frame': start, 'class': 'v44k_20ms',
                                           'generator': 'g44k_20ms'}
+
+    # ---- f3: the optimiser's candidate scan (optimization.py:46-117, :230-310) ---------------
+    # the candidates of optimize_velvet_noise (:259-271) on a small kappa grid
+    OBJ_KW = dict(angle_limit=float(np.pi / 4), lambda_mean=5.0, lambda_skew=2.0, lambda_correlation=15.0,
+                  lambda_penalty=1e3)
+    obj_inputs = {'viola_excerpt': excerpt,
+                  'uniform_stereo': make_input(dict(seed=31, shape=[30000, 2])),
+                  'uniform_mono': make_input(dict(seed=32, shape=[20000]))}
+    for iname, sig in obj_inputs.items():
+        fs_obj = 44100 if iname == 'viola_excerpt' else 48000
+        kappas = np.linspace(0.0, 1.0, 9)
+        cands = [dict(sample_rate_hz=fs_obj, duration_seconds=0.03, num_impulses=30,
+                      log_distribution_strength=float(k), normalizer=None, filtered_channels=(0,),
+                      mode='LR', seed=1) for k in kappas]
+        scores, terms = [], []
+        for kw in cands:
+            vn = dec.VelvetNoise(**kw)
+            ref_score = opt.symmetry_aware_objective(sig, vn, **OBJ_KW)
+            out = vn.decorrelate(sig)
+            mine = O.symmetry_aware_objective(out, **OBJ_KW)
+            if ref_score != mine:
+                raise SystemExit(f'ORACLE MISMATCH in objective[{iname}]: {ref_score!r} vs {mine!r}')
+            _, th, wt = dsp.polar_coordinates(out[:, 0], out[:, 1], normalize=False)
+            sp = opt.angular_variance(th, wt)
+            ref_terms = (sp, opt.centroid(th, wt), opt.polar_skewness(th, wt, sp),
+                         float(opt.left_right_correlation(out)), opt.max_angular_exceedance(th, OBJ_KW['angle_limit']))
+            if ref_terms != tuple(float(v) for v in O.objective_terms(out, angle_limit=OBJ_KW['angle_limit'])):
+                raise SystemExit(f'ORACLE MISMATCH in objective terms[{iname}]')
+            scores.append(ref_score)
+            terms.append(ref_terms)
+        scan = opt.grid_scan(sig, [dec.VelvetNoise(**kw) for kw in cands], **OBJ_KW)
+        assert np.array_equal(scan, np.array(scores))
+        minima = opt.get_local_minima(scan, len(kappas))
+        assert minima == O.local_minima(scan, len(kappas))
+        arrays[f'obj_{iname}_scores'] = np.array(scores, np.float64)
+        arrays[f'obj_{iname}_terms'] = np.array(terms, np.float64)
+        manifest['objective'][iname] = {'sample_rate_hz': fs_obj, 'kappas': kappas.tolist(), 'kwargs': OBJ_KW,
+                                        'local_minima': [int(i) for i in minima],
+                                        'input': ('viola_excerpt_in' if iname == 'viola_excerpt' else
+                                                  dict(seed=31, shape=[30000, 2]) if iname == 'uniform_stereo'
+                                                  else dict(seed=32, shape=[20000]))}
+        print(f'obj  {iname:14s} scores {np.array2string(np.array(scores), precision=4)} minima {minima}')
+    # the whole optimiser on the excerpt, small grid (scipy's bounded Brent on the same objective)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        kappa_opt = opt.optimize_velvet_noise(input_signal=excerpt, sample_rate_hz=44100, duration_seconds=0.03,
+                                              num_impulses=30, seed=1, grid_size=9)
+    manifest['objective']['viola_excerpt']['optimize_velvet_noise_grid9'] = float(kappa_opt)
+    print(f'obj  optimize_velvet_noise(grid 9) on the excerpt -> kappa {kappa_opt:.6f}')
 
     np.savez_compressed(OUT / 'golden.npz', **arrays)
     (OUT / 'manifest.json').write_text(json.dumps(manifest, indent=1, sort_keys=True) + '\n')

@@ -316,3 +316,47 @@ def haas_delay_lr(x, *, sample_rate_hz, delay_time_seconds, delayed_channel):
     y[:n, :] = x if x.ndim == 2 else np.column_stack((x, x))
     y[:, delayed_channel] = np.roll(y[:, delayed_channel], d, axis=0)
     return y
+
+
+# ---- f3: the optimiser's objective (optimization.py:11-105, utils/dsp.py:374-422) ------------
+EPSILON = 1e-10
+
+
+def polar_coordinates(left, right, *, mode='MS', semicircular=True, normalize=True):
+    """utils/dsp.py:374-422: ``(radii, thetas, weights)`` of a stereo signal's samples."""
+    thetas = np.arctan2(left - right, left + right) if mode == 'MS' else np.arctan2(left, right)
+    if semicircular:
+        thetas = np.where(thetas < -np.pi / 2, thetas + np.pi,
+                          np.where(thetas > np.pi / 2, thetas - np.pi, thetas))
+    radii = np.sqrt(left**2 + right**2)
+    if normalize:
+        radii /= radii.max() + EPSILON
+    weights = radii / (radii.sum() + EPSILON)
+    return radii, thetas, weights
+
+
+def objective_terms(output_signal, *, angle_limit):
+    """The five scalars the objective is built from (optimization.py:11-44, :73-99)."""
+    _, thetas, weights = polar_coordinates(output_signal[:, 0], output_signal[:, 1], normalize=False)
+    spread = float(np.sum(weights * thetas**2))
+    mean_theta = float(np.sum(weights * thetas))
+    skew = float(np.sum(weights * thetas**3)) / (max(spread, EPSILON) ** 1.5)
+    norm_left = np.linalg.norm(output_signal[:, 0]) + EPSILON          # (sic) both channels by ||L||, :14-17
+    corr = np.dot(output_signal[:, 0] / norm_left, output_signal[:, 1] / norm_left)
+    exceed = max(0.0, float(np.max(np.abs(thetas)) - angle_limit))
+    return spread, mean_theta, skew, corr, exceed
+
+
+def symmetry_aware_objective(output_signal, *, angle_limit, lambda_mean, lambda_skew,
+                             lambda_correlation, lambda_penalty):
+    """optimization.py:46-105 on an already decorrelated signal; returns the value to minimise."""
+    spread, mean_theta, skew, corr, exceed = objective_terms(output_signal, angle_limit=angle_limit)
+    objective = (spread - lambda_mean * mean_theta ** 2 - lambda_skew * skew ** 2
+                 - lambda_correlation * corr ** 2 - lambda_penalty * exceed ** 2)
+    return -objective
+
+
+def local_minima(scores, grid_size):
+    """optimization.py:120-128"""
+    found = [i for i in range(1, grid_size - 1) if scores[i] < scores[i - 1] and scores[i] < scores[i + 1]]
+    return found if found else [int(np.argmin(scores))]

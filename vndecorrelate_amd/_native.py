@@ -18,6 +18,7 @@ ABI_VERSION = 1
 MODE_EXACT = 0   # acc = f32(acc + f32(x*w)) : bit-identical to the reference's NumPy paths
 MODE_FMA = 1     # acc = fma(x, w, acc), table order
 MODE_FAST = 2    # fma, free summation order, gains folded into weights: the throughput mode
+MOMENTS = 8      # VND_MOMENTS: doubles per candidate returned by the scan
 
 _PKG = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get('VND_AMD_LIBRARY', _PKG / 'libvnd_amd.so'))   # override: tuning builds only
@@ -79,6 +80,12 @@ SIGNATURES = {
     'vnd_describe_fanout_launch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                                   ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                                   ctypes.c_char_p, ctypes.c_int32]),
+    'vnd_polar_moments_workspace_bytes': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32,
+                                                         ctypes.POINTER(ctypes.c_int64)]),
+    'vnd_polar_moments_f32_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    'vnd_scan_bank_f32_host': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_f32p, ctypes.c_int64,
+                                              ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]),
     'vnd_time_convolve_f32_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                  ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
@@ -335,6 +342,17 @@ class TapTable:
         _check(fn(self.ctx.handle, self.handle, ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr),
                   batch, n, channels, int(mode), ctypes.c_void_p(stream)), name)
 
+    def scan_host(self, x: np.ndarray, mode: int = MODE_EXACT) -> np.ndarray:
+        """Candidate scan: this table is a bank of F stereo pairs, ``x`` a ``(n, 1)`` or
+        ``(n, 2)`` float32 signal; returns ``(F, 8)`` float64 polar moments (``vnd_amd.h``)."""
+        if x.dtype != np.float32 or not x.flags.c_contiguous or x.ndim != 2:
+            raise ValueError('scan_host wants a C-contiguous float32 (n, channels) array')
+        out = np.zeros((self.num_channels // 2, MOMENTS), np.float64)
+        _check(self._lib.vnd_scan_bank_f32_host(self.ctx.handle, self.handle, _ptr(x, ctypes.c_float), x.shape[0],
+                                                x.shape[1], int(mode), _ptr(out, ctypes.c_double)),
+               'vnd_scan_bank_f32_host')
+        return out
+
     def time_device(self, x_ptr: int, y_ptr: int, batch: int, n: int, channels: int, *, mode: int,
                     n_buffers: int, stride_elems: int, iters: int, stream: int = 0) -> float:
         """Average milliseconds per launch between two hipEvents on ``stream``."""
@@ -359,6 +377,22 @@ def decorrelate_workspace_bytes(batch: int, n: int, channels: int) -> int:
     _check(load_library().vnd_decorrelate_workspace_bytes(batch, n, channels, ctypes.byref(need)),
            'vnd_decorrelate_workspace_bytes')
     return need.value
+
+
+def polar_moments_workspace_bytes(n: int, pairs: int) -> int:
+    need = ctypes.c_int64()
+    _check(load_library().vnd_polar_moments_workspace_bytes(n, pairs, ctypes.byref(need)),
+           'vnd_polar_moments_workspace_bytes')
+    return need.value
+
+
+def polar_moments_device(ctx: 'Context', y_ptr: int, n: int, pairs: int, moments_ptr: int, workspace_ptr: int,
+                         workspace_bytes: int, stream: int = 0):
+    """Reduce a device array ``y[n][2*pairs]`` to ``moments[pairs][8]`` (device doubles) on ``stream``."""
+    _check(ctx._lib.vnd_polar_moments_f32_dev(ctx.handle, ctypes.c_void_p(y_ptr), n, pairs,
+                                              ctypes.c_void_p(moments_ptr), ctypes.c_void_p(workspace_ptr),
+                                              workspace_bytes, ctypes.c_void_p(stream)),
+           'vnd_polar_moments_f32_dev')
 
 
 def device_count() -> int:

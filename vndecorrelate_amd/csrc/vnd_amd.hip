@@ -2,6 +2,7 @@
 // Host-side only decides launch geometry; all arithmetic lives in vnd_kernels.hpp.
 #include "vnd_kernels.hpp"
 #include "vnd_epilogue.hpp"
+#include "vnd_moments.hpp"
 #include "../../include/vnd_amd.h"
 
 #include <algorithm>
@@ -900,6 +901,84 @@ vnd_status vnd_decorrelate_fanout_f32_host(vnd_ctx *ctx, const vnd_taps *t, cons
     if (in_channels <= 0) return fail(VND_ERR_INVALID, "in_channels must be positive");
     return decorrelate_host(ctx, t, x, y, batch, n, in_channels, t->C, mode, ms_encode, use_width, width,
                             normalize, eps);
+}
+
+// ------------------------------------------------------------------------------
+// candidate scan
+// ------------------------------------------------------------------------------
+static int64_t mom_chunks(int64_t n) { return std::max<int64_t>((n + kMomFrames - 1) / kMomFrames, 1); }
+
+vnd_status vnd_polar_moments_workspace_bytes(int64_t n, int32_t n_pairs, int64_t *bytes)
+{
+    if (!bytes || n < 0 || n_pairs <= 0) return fail(VND_ERR_INVALID, "bad workspace query");
+    *bytes = mom_chunks(n) * n_pairs * kMoments * (int64_t)sizeof(double);
+    return VND_OK;
+}
+
+vnd_status vnd_polar_moments_f32_dev(vnd_ctx *ctx, const float *y, int64_t n, int32_t n_pairs, double *moments,
+                                     void *workspace, int64_t workspace_bytes, void *stream_)
+{
+    if (!ctx) return fail(VND_ERR_INVALID, "null context");
+    if (n < 0 || n_pairs <= 0) return fail(VND_ERR_INVALID, "bad frame or pair count");
+    if (!moments || (n > 0 && !y)) return fail(VND_ERR_INVALID, "null pointer");
+    int64_t need = 0;
+    vnd_polar_moments_workspace_bytes(n, n_pairs, &need);
+    if (!workspace || workspace_bytes < need)
+        return fail(VND_ERR_INVALID, "workspace too small: need %lld bytes", (long long)need);
+    const int64_t chunks = mom_chunks(n);
+    if (chunks > 0x7fffffffLL || n_pairs > 65535 * kMomThreads)
+        return fail(VND_ERR_UNSUPPORTED, "scan too large; split it");
+    hipStream_t stream = (hipStream_t)stream_;
+    MArgs a{};
+    a.y = y; a.partials = (double *)workspace; a.moments = moments; a.n = n; a.F = n_pairs; a.chunks = (int32_t)chunks;
+    if (n_pairs >= 64) {
+        const dim3 grid((unsigned)chunks, (unsigned)((n_pairs + kMomThreads - 1) / kMomThreads));
+        hipLaunchKernelGGL(moments_by_candidate_kernel, grid, dim3(kMomThreads), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(moments_by_frame_kernel, dim3((unsigned)chunks, (unsigned)n_pairs), dim3(kMomThreads), 0,
+                           stream, a);
+    }
+    const unsigned rblocks = (unsigned)(((int64_t)n_pairs * kMoments + kMomThreads - 1) / kMomThreads);
+    hipLaunchKernelGGL(moments_reduce_kernel, dim3(rblocks), dim3(kMomThreads), 0, stream, a);
+    HIP_TRY(hipGetLastError());
+    return VND_OK;
+}
+
+vnd_status vnd_scan_bank_f32_host(vnd_ctx *ctx, const vnd_taps *t, const float *x, int64_t n, int32_t in_channels,
+                                  int32_t mode, double *moments)
+{
+    if (!ctx || !t) return fail(VND_ERR_INVALID, "null context or tap table");
+    if (t->C % 2 != 0) return fail(VND_ERR_INVALID, "a scan needs stereo pairs: the bank has %d channels", t->C);
+    if (in_channels != 1 && in_channels != 2)
+        return fail(VND_ERR_INVALID, "a scan takes a mono or stereo signal, got %d channels", in_channels);
+    vnd_status st = check_shape(ctx, t, 1, n, t->C, mode, in_channels);
+    if (st != VND_OK) return st;
+    if (!moments || (n > 0 && !x)) return fail(VND_ERR_INVALID, "null pointer");
+    const int32_t pairs = t->C / 2;
+    HIP_TRY(hipSetDevice(ctx->device));
+    st = ensure_scratch(ctx, (size_t)std::max<int64_t>(n, 1) * t->C);
+    if (st != VND_OK) return st;
+    int64_t ws = 0;
+    vnd_polar_moments_workspace_bytes(n, pairs, &ws);
+    const size_t out_bytes = (size_t)pairs * kMoments * sizeof(double);
+    char *work = nullptr;
+    HIP_TRY(hipMalloc((void **)&work, (size_t)ws + out_bytes));
+    hipError_t he = hipSuccess;
+    if (n > 0) he = hipMemcpyAsync(ctx->scratch_x, x, (size_t)n * in_channels * sizeof(float), hipMemcpyHostToDevice,
+                                   ctx->stream);
+    if (he == hipSuccess) {
+        st = launch(ctx, t, ctx->scratch_x, ctx->scratch_y, 1, n, t->C, mode, ctx->stream, nullptr, in_channels);
+        if (st == VND_OK)
+            st = vnd_polar_moments_f32_dev(ctx, ctx->scratch_y, n, pairs, (double *)(work + ws), work, ws, ctx->stream);
+        if (st == VND_OK) {
+            he = hipMemcpyAsync(moments, work + ws, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+        }
+    }
+    (void)hipFree(work);
+    if (st != VND_OK) return st;
+    if (he != hipSuccess) return fail(VND_ERR_HIP, "scan: %s", hipGetErrorString(he));
+    return VND_OK;
 }
 
 #ifdef VND_STAMPS

@@ -6,8 +6,9 @@ citations are ``file:line`` in ckonst/VNDecorrelate v1.1.0.  These are O(N)
 pointwise NumPy steps or O(K) tap-placement maths; the O(N*K) tap sum itself
 never runs here - it lives in the HIP extension.
 
-The analysis/plot helpers of the reference (correlograms, sweeps, polar
-coordinates) are out of scope.
+``polar_coordinates`` is here for the optimiser's objective; the
+other analysis/plot helpers of the reference (correlograms, sweeps) are out of scope
+(SURVEY.md §2 rows 9-10).
 """
 from __future__ import annotations
 
@@ -145,3 +146,24 @@ def apply_log_distribution(randoms: NDArray, log_distribution: NDArray,
 def uniform_density(randoms: NDArray, impulse_indexes: NDArray,
                     impulse_interval: float) -> NDArray[np.int32]:
     return np.round(impulse_indexes * impulse_interval + randoms * (impulse_interval - 1)).astype(np.int32)
+
+
+# ---- polar samples of a stereo signal (utils/dsp.py:374-422) -------------------------
+def polar_coordinates(left: NDArray, right: NDArray, mode: LayoutMode = LayoutMode.MS, semicircular: bool = True,
+                      normalize: bool = True, compute_weights: bool = True):
+    """``(radii, thetas[, weights])`` per sample.  MS mode measures the angle of
+    (L - R, L + R); ``semicircular`` folds the inverted-mono half of the circle onto
+    [-pi/2, pi/2]; weights are the radii over their sum."""
+    if mode == LayoutMode.MS:
+        thetas = np.arctan2(left - right, left + right)
+    else:
+        thetas = np.arctan2(left, right)
+    if semicircular:
+        below, above = thetas < -np.pi / 2, thetas > np.pi / 2
+        thetas = np.where(below, thetas + np.pi, np.where(above, thetas - np.pi, thetas))
+    radii = np.sqrt(left**2 + right**2)
+    if normalize:
+        radii /= radii.max() + EPSILON
+    if not compute_weights:
+        return radii, thetas
+    return radii, thetas, radii / (radii.sum() + EPSILON)
