@@ -57,6 +57,7 @@ struct vnd_taps {
     vnd_ctx *ctx = nullptr;
     int32_t C = 0, total = 0, total_segs = 0, max_index = 0, apply_gain = 0;
     bool has_seg = false, has_flags = false;
+    bool unit_weights = false;    // every weight is +-1: x*w is exact, so fma(x, w, acc) == acc + x*w bit for bit
     std::vector<int32_t> tap_off, idx, seg_off, seg_end;
     std::vector<float> w, seg_gain;
     std::vector<uint8_t> flags;
@@ -191,6 +192,14 @@ static kern_t ordered_bc_by_r(int r)
     case 8: return conv_ordered_kernel<kOrderedThreads, 2, 8, MODE, true>;
     default: return nullptr;
     }
+}
+
+// VND_MODE_EXACT on a table of +-1 weights (every class-path table) runs the fma kernels: the
+// product is exact, so the single rounding of fma(x, +-1, acc) is the rounding of acc +- x, and
+// the segment gain and segment add stay separate operations in both instantiations.
+static int arithmetic_of(const vnd_taps *t, int mode)
+{
+    return (mode == VND_MODE_EXACT && t->unit_weights) ? VND_MODE_FMA : mode;
 }
 
 static kern_t pick_kernel(const Plan &p, int mode)
@@ -329,14 +338,14 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
     a.nblocks = p.nblocks;
     if (p.direct) {
         a.tiles = (int32_t)batch; a.groups = 1; a.W = 0;
-        kern_t k = mode == VND_MODE_EXACT ? conv_direct_kernel<0> : conv_direct_kernel<1>;
+        kern_t k = arithmetic_of(t, mode) == VND_MODE_EXACT ? conv_direct_kernel<0> : conv_direct_kernel<1>;
         if (mode == VND_MODE_FAST) a.taps = t->d_taps;      // direct kernel keeps the table's association
         hipLaunchKernelGGL(k, dim3(p.nblocks), dim3(kDirectThreads), 0, stream, a);
     } else {
         if ((int64_t)batch * p.tiles * p.groups > 0x7fffffffLL)
             return fail(VND_ERR_UNSUPPORTED, "grid too large; split the batch");
         a.tiles = p.tiles; a.groups = p.groups; a.W = p.W;
-        kern_t k = epi ? fast_epi_kernel(p) : pick_kernel(p, mode);
+        kern_t k = epi ? fast_epi_kernel(p) : pick_kernel(p, arithmetic_of(t, mode));
         if (!k) return fail(VND_ERR_UNSUPPORTED, "no kernel for this tile shape");
         if (epi) {
             a.epi_partials = epi->partials; a.epi_ms_encode = epi->ms_encode; a.epi_use_width = epi->use_width;
@@ -496,6 +505,8 @@ vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, 
     vnd_taps *t = new (std::nothrow) vnd_taps;
     if (!t) return fail(VND_ERR_NOMEM, "out of host memory");
     t->ctx = ctx; t->C = C; t->total = total; t->max_index = max_index;
+    t->unit_weights = true;
+    for (int32_t k = 0; k < total; ++k) t->unit_weights &= (tap_weight[k] == 1.0f || tap_weight[k] == -1.0f);
     t->apply_gain = apply_gain ? 1 : 0; t->has_seg = has_seg; t->total_segs = total_segs;
     t->tap_off.assign(tap_offsets, tap_offsets + C + 1);
     if (total) { t->idx.assign(tap_index, tap_index + total); t->w.assign(tap_weight, tap_weight + total); }

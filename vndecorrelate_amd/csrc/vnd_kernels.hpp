@@ -367,6 +367,38 @@ __device__ __forceinline__ void issue_reads(v2f (&buf)[R], unsigned addr)
     issue_reads_seq<NT, R>(buf, addr, std::make_integer_sequence<int, R>{});
 }
 
+template <int NT, int J, int BYTES>
+__device__ __forceinline__ float ds_read_dword(unsigned addr)
+{
+    static_assert(J * 2 * NT * 4 + BYTES <= 65535, "ds offset field is 16 bits");
+    float r;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(J * 2 * NT * 4 + BYTES));
+    return r;
+}
+
+template <int NT, int R, int BYTES, int... Js>
+__device__ __forceinline__ void issue_dwords_seq(float (&buf)[R], unsigned addr, std::integer_sequence<int, Js...>)
+{
+    ((buf[Js] = ds_read_dword<NT, Js, BYTES>(addr)), ...);
+}
+
+// the dword BYTES past each of the lane's R pair addresses
+template <int NT, int R, int BYTES>
+__device__ __forceinline__ void issue_dwords(float (&buf)[R], unsigned addr)
+{
+    issue_dwords_seq<NT, R, BYTES>(buf, addr, std::make_integer_sequence<int, R>{});
+}
+
+template <int R>
+__device__ __forceinline__ void wait_dwords(float (&a)[R], float (&b)[R])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]));
+#pragma unroll
+    for (int j = 1; j < R; ++j) asm volatile("" : "+v"(a[j]));
+#pragma unroll
+    for (int j = 0; j < R; ++j) asm volatile("" : "+v"(b[j]));
+}
+
 template <int N, int R>
 __device__ __forceinline__ void wait_reads(v2f (&buf)[R])
 {
@@ -701,24 +733,27 @@ __device__ __forceinline__ void ordered_consume(v2f (&sb)[R], const v2f (&v)[R],
     }
 }
 
+// The parity branch only fetches the tap's R pairs; the accumulators are updated after the
+// arms have joined, in straight-line code - updated inside the arms they become phi nodes
+// and hipcc copies all 2R accumulator registers after every tap.
 template <int NT, int R, int MODE>
 __device__ __forceinline__ void ordered_tap(const FastTap &t, unsigned lane_addr, v2f (&sb)[R])
 {
+    v2f val[R];
     if ((t.off & 4) == 0) {
-        v2f b0[R];
-        issue_reads<NT, R>(b0, lane_addr + (unsigned)t.off);
-        wait_reads<0, R>(b0);
-        ordered_consume<MODE, R>(sb, b0, t.w);
+        issue_reads<NT, R>(val, lane_addr + (unsigned)t.off);
+        wait_reads<0, R>(val);
     } else {
-        v2f lo[R], hi[R], mid[R];
-        issue_reads<NT, R>(lo, lane_addr + (unsigned)t.off - 4u);
-        issue_reads<NT, R>(hi, lane_addr + (unsigned)t.off + 4u);
-        wait_reads<0, R>(lo);
-        wait_reads<0, R>(hi);
+        // an odd offset is 4-byte-misaligned for a b64 pair: its two dwords come as two b32
+        // reads (2 LDS cycles each, like a b64) straight into the halves of the pair
+        float a[R], b[R];
+        issue_dwords<NT, R, 0>(a, lane_addr + (unsigned)t.off);
+        issue_dwords<NT, R, 4>(b, lane_addr + (unsigned)t.off);
+        wait_dwords<R>(a, b);
 #pragma unroll
-        for (int j = 0; j < R; ++j) mid[j] = v2f{lo[j].y, hi[j].x};
-        ordered_consume<MODE, R>(sb, mid, t.w);
+        for (int j = 0; j < R; ++j) val[j] = v2f{a[j], b[j]};
     }
+    ordered_consume<MODE, R>(sb, val, t.w);
 }
 
 template <int NT, int CG, int R, int MODE, bool BC = false>
