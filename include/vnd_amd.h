@@ -174,6 +174,22 @@ vnd_status vnd_polar_moments_f32_dev(vnd_ctx *ctx, const float *y_dev, int64_t n
 vnd_status vnd_scan_bank_f32_host(vnd_ctx *ctx, const vnd_taps *bank, const float *x, int64_t n_frames,
                                   int32_t in_channels, int32_t mode, double *moments);
 
+/* ---- HaasEffect on the device: the stage either side of the path in a chain ----
+ * Replaces HaasEffect.decorrelate after its float32 cast (decorrelation.py:192-230):
+ * x is float32 [batch][n_frames][in_channels] (1 = mono, duplicated; 2 = stereo), y is
+ * FLOAT64 [batch][n_frames + delay_frames][2] as upstream (:206).  Column
+ * `delayed_channel` - of the L/R pair, or of the mid/side pair when ms_mode - is delayed
+ * by delay_frames = round(delay_time_seconds * fs) >= 0 with np.roll's wrap of the zero
+ * tail (:220-222); use_width applies apply_stereo_width (utils/dsp.py:21-37).  float64
+ * arithmetic in NumPy's operation order: bit-identical to the reference.           */
+vnd_status vnd_haas_f64_dev(vnd_ctx *ctx, const float *x_dev, double *y_dev, int64_t batch,
+                            int64_t n_frames, int32_t in_channels, int32_t delay_frames,
+                            int32_t delayed_channel, int32_t ms_mode, int32_t use_width, double width,
+                            void *hip_stream);
+vnd_status vnd_haas_f64_host(vnd_ctx *ctx, const float *x, double *y, int64_t batch, int64_t n_frames,
+                             int32_t in_channels, int32_t delay_frames, int32_t delayed_channel,
+                             int32_t ms_mode, int32_t use_width, double width);
+
 /* ---- measurement helpers (used by bench.py; not on the data path) ---------- */
 /* Launches the convolve `iters` times back to back on `hip_stream`, cycling
  * through `n_buffers` (x,y) pairs laid out at x_dev + i*stride_elems, and

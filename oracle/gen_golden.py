@@ -248,7 +248,7 @@ def main():
     OUT.mkdir(parents=True, exist_ok=True)
     manifest = {'reference': 'ckonst/VNDecorrelate v1.1.0', 'numpy': np.__version__,
                 'slice': SLICE, 'generators': {}, 'fn': {}, 'cls_convolve': {},
-                'cls_decorrelate': {}, 'class_taps': {}, 'known_answers': {}, 'audio': {}, 'objective': {}}
+                'cls_decorrelate': {}, 'class_taps': {}, 'known_answers': {}, 'audio': {}, 'objective': {}, 'haas': {}}
     arrays = {}
 
     # ---- a2/a3/a4: generator ------------------------------------------------
@@ -461,6 +461,32 @@ def main():
                                               num_impulses=30, seed=1, grid_size=9)
     manifest['objective']['viola_excerpt']['optimize_velvet_noise_grid9'] = float(kappa_opt)
     print(f'obj  optimize_velvet_noise(grid 9) on the excerpt -> kappa {kappa_opt:.6f}')
+
+    # ---- f4: HaasEffect, every mode (decorrelation.py:163-230) ---------------------------------
+    HAAS = {
+        'haas_lr_ch0': (dict(sample_rate_hz=48000, delay_time_seconds=0.01, delayed_channel=0, mode='LR'), [1500, 2]),
+        'haas_lr_ch1_width': (dict(sample_rate_hz=44100, delay_time_seconds=0.02, delayed_channel=1, mode='LR',
+                                   width=0.3), [1500, 2]),
+        'haas_ms_mid': (dict(sample_rate_hz=48000, delay_time_seconds=0.005, delayed_channel=0, mode='MS'), [1500, 2]),
+        'haas_ms_side_width': (dict(sample_rate_hz=48000, delay_time_seconds=0.0125, delayed_channel=1, mode='MS',
+                                    width=0.7), [1500, 2]),
+        'haas_mono_lr': (dict(sample_rate_hz=48000, delay_time_seconds=0.003, delayed_channel=1, mode='LR'), [1500]),
+        'haas_mono_ms': (dict(sample_rate_hz=48000, delay_time_seconds=0.003, delayed_channel=1, mode='MS',
+                              width=0.5), [1500]),
+        'haas_zero_delay': (dict(sample_rate_hz=48000, delay_time_seconds=0.0, delayed_channel=0, mode='MS'), [100, 2]),
+        'haas_longer_than_signal': (dict(sample_rate_hz=48000, delay_time_seconds=0.01, delayed_channel=0,
+                                         mode='LR'), [100, 2]),
+    }
+    for name, (kw, shape) in HAAS.items():
+        spec = dict(seed=50, shape=shape)
+        x = make_input(spec)
+        ref = dec.HaasEffect(**kw).decorrelate(x)
+        mine = O.haas_effect(x, **kw)
+        same(ref, mine, f'HaasEffect[{name}]')
+        assert ref.dtype == np.float64
+        arrays[f'{name}_out'] = ref
+        manifest['haas'][name] = {'kwargs': kw, 'input': spec, 'out_shape': list(ref.shape), 'out_sha256': sha(ref)}
+        print(f'haas {name:24s} x {x.shape} -> {ref.shape} {ref.dtype}')
 
     np.savez_compressed(OUT / 'golden.npz', **arrays)
     (OUT / 'manifest.json').write_text(json.dumps(manifest, indent=1, sort_keys=True) + '\n')

@@ -360,3 +360,25 @@ def local_minima(scores, grid_size):
     """optimization.py:120-128"""
     found = [i for i in range(1, grid_size - 1) if scores[i] < scores[i - 1] and scores[i] < scores[i + 1]]
     return found if found else [int(np.argmin(scores))]
+
+
+# ---- f4: HaasEffect (decorrelation.py:192-230), every mode --------------------------------
+def haas_effect(x, *, sample_rate_hz, delay_time_seconds=0.02, delayed_channel=0, mode='LR', width=None):
+    """float64 ``(n + delay, 2)``: one channel (or the mid / side channel) delayed; the tail of the
+    zero-padded buffer wraps to the front (np.roll), i.e. the first ``delay`` samples are silent."""
+    d = round(delay_time_seconds * sample_rate_hz)
+    x = x.astype(np.float32, copy=False)
+    n = len(x)
+    mono = x.ndim == 1
+    y = np.zeros((n + d, 2))
+    y[:n, :] = np.column_stack((x, x)) if mono else x
+    if mode == 'MS' and not mono:
+        lr_to_ms(y)
+    y[:, delayed_channel] = np.roll(y[:, delayed_channel], d, axis=0)
+    if mode == 'MS':
+        ms_to_lr(y)
+        if mono:
+            y *= 0.5
+    if width is not None:
+        apply_stereo_width(y, width)
+    return y

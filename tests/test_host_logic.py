@@ -243,3 +243,18 @@ def test_concat_tap_arrays_against_the_oracle(golden):
         concat_tap_arrays([function_path_arrays(firs[0]), members[0]])
     with pytest.raises(ValueError):
         concat_tap_arrays([])
+
+
+# ---- f4: HaasEffect (NumPy stage) against the reference's outputs -------------------
+def test_haas_effect_matches_reference(golden):
+    import hashlib
+    from conftest import make_input
+    from oracle import vnd_oracle as O
+    for name, meta in golden.manifest['haas'].items():
+        x = make_input(meta['input'])
+        want = golden.arrays[f'{name}_out']
+        got = vnd.HaasEffect(**_kw(meta['kwargs'])).decorrelate(x)
+        assert got.dtype == np.float64 and list(got.shape) == meta['out_shape'], name
+        assert np.array_equal(got, want), name
+        assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest() == meta['out_sha256'], name
+        assert np.array_equal(O.haas_effect(x, **meta['kwargs']), want), name

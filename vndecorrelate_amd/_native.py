@@ -86,6 +86,12 @@ SIGNATURES = {
                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     'vnd_scan_bank_f32_host': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_f32p, ctypes.c_int64,
                                               ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]),
+    'vnd_haas_f64_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                        ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_void_p]),
+    'vnd_haas_f64_host': (ctypes.c_int, [ctypes.c_void_p, _c_f32p, ctypes.POINTER(ctypes.c_double), ctypes.c_int64,
+                                         ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                         ctypes.c_int32, ctypes.c_int32, ctypes.c_double]),
     'vnd_time_convolve_f32_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                  ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
@@ -377,6 +383,27 @@ def decorrelate_workspace_bytes(batch: int, n: int, channels: int) -> int:
     _check(load_library().vnd_decorrelate_workspace_bytes(batch, n, channels, ctypes.byref(need)),
            'vnd_decorrelate_workspace_bytes')
     return need.value
+
+
+def haas_host(ctx: 'Context', x: np.ndarray, *, delay: int, delayed_channel: int, ms_mode: bool, width) -> np.ndarray:
+    """HaasEffect on the device from host memory: x float32 ``(n, 1|2)`` or ``(batch, n, 1|2)``;
+    returns float64 ``(..., n + delay, 2)``."""
+    if x.dtype != np.float32 or not x.flags.c_contiguous or x.ndim not in (2, 3):
+        raise ValueError('haas_host wants a C-contiguous float32 (n, C) or (batch, n, C) array')
+    batch = 1 if x.ndim == 2 else x.shape[0]
+    n, c = x.shape[-2:]
+    y = np.empty(x.shape[:-2] + (n + int(delay), 2), np.float64)
+    _check(ctx._lib.vnd_haas_f64_host(ctx.handle, _ptr(x, ctypes.c_float), _ptr(y, ctypes.c_double), batch, n, c,
+                                      int(delay), int(delayed_channel), int(bool(ms_mode)), int(width is not None),
+                                      float(width or 0.0)), 'vnd_haas_f64_host')
+    return y
+
+
+def haas_device(ctx: 'Context', x_ptr: int, y_ptr: int, batch: int, n: int, channels: int, *, delay: int,
+                delayed_channel: int, ms_mode: bool, width, stream: int = 0):
+    _check(ctx._lib.vnd_haas_f64_dev(ctx.handle, ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr), batch, n, channels,
+                                     int(delay), int(delayed_channel), int(bool(ms_mode)), int(width is not None),
+                                     float(width or 0.0), ctypes.c_void_p(stream)), 'vnd_haas_f64_dev')
 
 
 def polar_moments_workspace_bytes(n: int, pairs: int) -> int:

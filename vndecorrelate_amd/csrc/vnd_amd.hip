@@ -3,6 +3,7 @@
 #include "vnd_kernels.hpp"
 #include "vnd_epilogue.hpp"
 #include "vnd_moments.hpp"
+#include "vnd_haas.hpp"
 #include "../../include/vnd_amd.h"
 
 #include <algorithm>
@@ -989,6 +990,70 @@ vnd_status vnd_scan_bank_f32_host(vnd_ctx *ctx, const vnd_taps *t, const float *
     (void)hipFree(work);
     if (st != VND_OK) return st;
     if (he != hipSuccess) return fail(VND_ERR_HIP, "scan: %s", hipGetErrorString(he));
+    return VND_OK;
+}
+
+// ------------------------------------------------------------------------------
+// HaasEffect on the device
+// ------------------------------------------------------------------------------
+static vnd_status haas_check(const vnd_ctx *ctx, int64_t batch, int64_t n, int32_t in_channels, int32_t delay,
+                             int32_t delayed_channel)
+{
+    if (!ctx) return fail(VND_ERR_INVALID, "null context");
+    if (batch < 0 || n < 0 || delay < 0) return fail(VND_ERR_INVALID, "negative batch, frame count or delay");
+    if (in_channels != 1 && in_channels != 2)
+        return fail(VND_ERR_INVALID, "HaasEffect takes a mono or stereo signal, got %d channels", in_channels);
+    if (delayed_channel != 0 && delayed_channel != 1)
+        return fail(VND_ERR_INVALID, "delayed_channel must be 0 or 1, got %d", delayed_channel);
+    if (batch > 65535) return fail(VND_ERR_UNSUPPORTED, "more than 65535 streams per call: split the batch");
+    return VND_OK;
+}
+
+vnd_status vnd_haas_f64_dev(vnd_ctx *ctx, const float *x, double *y, int64_t batch, int64_t n, int32_t in_channels,
+                            int32_t delay, int32_t delayed_channel, int32_t ms_mode, int32_t use_width,
+                            double width, void *stream)
+{
+    vnd_status st = haas_check(ctx, batch, n, in_channels, delay, delayed_channel);
+    if (st != VND_OK) return st;
+    const int64_t total = n + delay;
+    if (batch == 0 || total == 0) return VND_OK;
+    if (!y || (n > 0 && !x)) return fail(VND_ERR_INVALID, "null signal pointer");
+    HArgs a{};
+    a.x = x; a.y = y; a.n = n; a.Cx = in_channels; a.delay = delay; a.delayed_channel = delayed_channel;
+    a.ms = ms_mode ? 1 : 0; a.use_width = use_width ? 1 : 0; a.w_mid = 1.0 - width; a.w_side = width;
+    const dim3 grid((unsigned)((total + kHaasThreads - 1) / kHaasThreads), (unsigned)batch);
+    hipLaunchKernelGGL(haas_kernel, grid, dim3(kHaasThreads), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return VND_OK;
+}
+
+vnd_status vnd_haas_f64_host(vnd_ctx *ctx, const float *x, double *y, int64_t batch, int64_t n, int32_t in_channels,
+                             int32_t delay, int32_t delayed_channel, int32_t ms_mode, int32_t use_width,
+                             double width)
+{
+    vnd_status st = haas_check(ctx, batch, n, in_channels, delay, delayed_channel);
+    if (st != VND_OK) return st;
+    const int64_t total = n + delay;
+    if (batch == 0 || total == 0) return VND_OK;
+    if (!y || (n > 0 && !x)) return fail(VND_ERR_INVALID, "null signal pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t in_bytes = (size_t)batch * n * in_channels * sizeof(float);
+    const size_t out_bytes = (size_t)batch * total * 2 * sizeof(double);
+    char *buf = nullptr;
+    HIP_TRY(hipMalloc((void **)&buf, out_bytes + std::max<size_t>(in_bytes, 16)));
+    hipError_t he = hipSuccess;
+    if (in_bytes) he = hipMemcpyAsync(buf + out_bytes, x, in_bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (he == hipSuccess) {
+        st = vnd_haas_f64_dev(ctx, (const float *)(buf + out_bytes), (double *)buf, batch, n, in_channels, delay,
+                              delayed_channel, ms_mode, use_width, width, ctx->stream);
+        if (st == VND_OK) {
+            he = hipMemcpyAsync(y, buf, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+        }
+    }
+    (void)hipFree(buf);
+    if (st != VND_OK) return st;
+    if (he != hipSuccess) return fail(VND_ERR_HIP, "haas: %s", hipGetErrorString(he));
     return VND_OK;
 }
 

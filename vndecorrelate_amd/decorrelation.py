@@ -677,10 +677,11 @@ class WhiteNoise(Decorrelator):
 # ----------------------------------------------------------------------------
 class SignalChain:
     """Fluent, lazily-instantiated cascade of stages; ``chain(x)`` feeds each
-    stage the previous stage's output."""
+    stage the previous stage's output.  ``device_resident=True`` (an extension) keeps the
+    signal in HBM between stages that have a device form (``resident.py``)."""
 
     def __init__(self, *, sample_rate_hz: int, num_outs: int = 2, lazy: bool = True,
-                 _hot: bool = False, _decorrelators=None):
+                 device_resident: bool = False, _hot: bool = False, _decorrelators=None):
         if _decorrelators is not None:
             raise TypeError(
                 'Cannot supply decorrelators directly, use ``SignalChain.velvet_noise``,'
@@ -688,6 +689,7 @@ class SignalChain:
         self.sample_rate_hz = sample_rate_hz
         self.num_outs = num_outs
         self.lazy = lazy
+        self.device_resident = bool(device_resident)
         self._hot = bool(_hot) or not lazy
         self._decorrelators: list = []
 
@@ -736,6 +738,9 @@ class SignalChain:
 
     def __call__(self, input_signal: NDArray) -> NDArray:
         self._init_decorrelators()
+        if self.device_resident:
+            from . import resident
+            return resident.run(self._decorrelators, input_signal)
         signal = input_signal
         for stage in self._decorrelators:
             signal = stage(signal)
