@@ -50,6 +50,8 @@ struct vnd_ctx {
     hipStream_t stream = nullptr; // used by the *_host entry points
     float *scratch_x = nullptr, *scratch_y = nullptr;
     size_t scratch_elems = 0;
+    char *work = nullptr;         // grow-only workspace of the *_host entry points
+    size_t work_bytes = 0;
     int variant = -1;
     int variant_nofuse = 0;       // tuning: 1 = keep the decorrelate epilogue as separate passes
 };
@@ -449,6 +451,7 @@ vnd_status vnd_ctx_destroy(vnd_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->scratch_x) (void)hipFree(c->scratch_x);
     if (c->scratch_y) (void)hipFree(c->scratch_y);
+    if (c->work) (void)hipFree(c->work);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return VND_OK;
@@ -648,6 +651,17 @@ static vnd_status ensure_scratch(vnd_ctx *ctx, size_t elems)
     HIP_TRY(hipMalloc((void **)&ctx->scratch_x, elems * sizeof(float)));
     HIP_TRY(hipMalloc((void **)&ctx->scratch_y, elems * sizeof(float)));
     ctx->scratch_elems = elems;
+    return VND_OK;
+}
+
+static vnd_status ensure_work(vnd_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->work_bytes) return VND_OK;
+    if (ctx->work) (void)hipFree(ctx->work);
+    ctx->work = nullptr;
+    ctx->work_bytes = 0;
+    HIP_TRY(hipMalloc((void **)&ctx->work, bytes));
+    ctx->work_bytes = bytes;
     return VND_OK;
 }
 
@@ -859,22 +873,15 @@ static vnd_status decorrelate_host(vnd_ctx *ctx, const vnd_taps *t, const float 
     if (st != VND_OK) return st;
     int64_t ws = 0;
     vnd_decorrelate_workspace_bytes(batch, n, C, &ws);
-    void *workspace = nullptr;
-    HIP_TRY(hipMalloc(&workspace, (size_t)ws));
-    hipError_t he = hipMemcpyAsync(ctx->scratch_x, x, in_elems * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-    if (he != hipSuccess) {
-        (void)hipFree(workspace);
-        return fail(VND_ERR_HIP, "copy in: %s", hipGetErrorString(he));
-    }
+    st = ensure_work(ctx, (size_t)ws);
+    if (st != VND_OK) return st;
+    HIP_TRY(hipMemcpyAsync(ctx->scratch_x, x, in_elems * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     st = decorrelate_dev(ctx, t, ctx->scratch_x, ctx->scratch_y, batch, n, Cx, C, mode, ms_encode, use_width,
-                         width, normalize, eps, workspace, ws, ctx->stream);
-    if (st == VND_OK) {
-        hipError_t e = hipMemcpyAsync(y, ctx->scratch_y, out_elems * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) st = fail(VND_ERR_HIP, "copy back: %s", hipGetErrorString(e));
-    }
-    (void)hipFree(workspace);
-    return st;
+                         width, normalize, eps, ctx->work, ws, ctx->stream);
+    if (st != VND_OK) return st;
+    HIP_TRY(hipMemcpyAsync(y, ctx->scratch_y, out_elems * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VND_OK;
 }
 
 vnd_status vnd_decorrelate_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
@@ -973,23 +980,18 @@ vnd_status vnd_scan_bank_f32_host(vnd_ctx *ctx, const vnd_taps *t, const float *
     int64_t ws = 0;
     vnd_polar_moments_workspace_bytes(n, pairs, &ws);
     const size_t out_bytes = (size_t)pairs * kMoments * sizeof(double);
-    char *work = nullptr;
-    HIP_TRY(hipMalloc((void **)&work, (size_t)ws + out_bytes));
-    hipError_t he = hipSuccess;
-    if (n > 0) he = hipMemcpyAsync(ctx->scratch_x, x, (size_t)n * in_channels * sizeof(float), hipMemcpyHostToDevice,
-                                   ctx->stream);
-    if (he == hipSuccess) {
-        st = launch(ctx, t, ctx->scratch_x, ctx->scratch_y, 1, n, t->C, mode, ctx->stream, nullptr, in_channels);
-        if (st == VND_OK)
-            st = vnd_polar_moments_f32_dev(ctx, ctx->scratch_y, n, pairs, (double *)(work + ws), work, ws, ctx->stream);
-        if (st == VND_OK) {
-            he = hipMemcpyAsync(moments, work + ws, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
-            if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
-        }
-    }
-    (void)hipFree(work);
+    st = ensure_work(ctx, (size_t)ws + out_bytes);
     if (st != VND_OK) return st;
-    if (he != hipSuccess) return fail(VND_ERR_HIP, "scan: %s", hipGetErrorString(he));
+    char *work = ctx->work;
+    if (n > 0)
+        HIP_TRY(hipMemcpyAsync(ctx->scratch_x, x, (size_t)n * in_channels * sizeof(float), hipMemcpyHostToDevice,
+                               ctx->stream));
+    st = launch(ctx, t, ctx->scratch_x, ctx->scratch_y, 1, n, t->C, mode, ctx->stream, nullptr, in_channels);
+    if (st != VND_OK) return st;
+    st = vnd_polar_moments_f32_dev(ctx, ctx->scratch_y, n, pairs, (double *)(work + ws), work, ws, ctx->stream);
+    if (st != VND_OK) return st;
+    HIP_TRY(hipMemcpyAsync(moments, work + ws, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return VND_OK;
 }
 
@@ -1039,21 +1041,15 @@ vnd_status vnd_haas_f64_host(vnd_ctx *ctx, const float *x, double *y, int64_t ba
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t in_bytes = (size_t)batch * n * in_channels * sizeof(float);
     const size_t out_bytes = (size_t)batch * total * 2 * sizeof(double);
-    char *buf = nullptr;
-    HIP_TRY(hipMalloc((void **)&buf, out_bytes + std::max<size_t>(in_bytes, 16)));
-    hipError_t he = hipSuccess;
-    if (in_bytes) he = hipMemcpyAsync(buf + out_bytes, x, in_bytes, hipMemcpyHostToDevice, ctx->stream);
-    if (he == hipSuccess) {
-        st = vnd_haas_f64_dev(ctx, (const float *)(buf + out_bytes), (double *)buf, batch, n, in_channels, delay,
-                              delayed_channel, ms_mode, use_width, width, ctx->stream);
-        if (st == VND_OK) {
-            he = hipMemcpyAsync(y, buf, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
-            if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
-        }
-    }
-    (void)hipFree(buf);
+    st = ensure_work(ctx, out_bytes + std::max<size_t>(in_bytes, 16));
     if (st != VND_OK) return st;
-    if (he != hipSuccess) return fail(VND_ERR_HIP, "haas: %s", hipGetErrorString(he));
+    char *buf = ctx->work;
+    if (in_bytes) HIP_TRY(hipMemcpyAsync(buf + out_bytes, x, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    st = vnd_haas_f64_dev(ctx, (const float *)(buf + out_bytes), (double *)buf, batch, n, in_channels, delay,
+                          delayed_channel, ms_mode, use_width, width, ctx->stream);
+    if (st != VND_OK) return st;
+    HIP_TRY(hipMemcpyAsync(y, buf, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return VND_OK;
 }
 
