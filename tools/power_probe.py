@@ -10,7 +10,9 @@ import vndecorrelate_amd.decorrelation as vnd
 from vndecorrelate_amd import _native
 from vndecorrelate_amd.taps import function_path_arrays
 
-mode = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+mode = sys.argv[1] if len(sys.argv) > 1 else '2'          # 0 | 1 | 2 = kernel arithmetic, 'copy' = plain device copy
+copy_only = mode == 'copy'
+mode = 2 if copy_only else int(mode)
 seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
 
 
@@ -55,8 +57,16 @@ time.sleep(1.0)
 t_start = time.perf_counter()
 rates = []
 while time.perf_counter() - t_start < seconds:
-    ms = table.time_device(x.data_ptr(), y.data_ptr(), pool, n, 2, mode=mode, n_buffers=1, stride_elems=0,
-                           iters=200, stream=stream)
+    if copy_only:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            y.copy_(x)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 200
+    else:
+        ms = table.time_device(x.data_ptr(), y.data_ptr(), pool, n, 2, mode=mode, n_buffers=1, stride_elems=0,
+                               iters=200, stream=stream)
     rates.append((time.perf_counter() - t_start, ms))
 t_end = time.perf_counter()
 time.sleep(1.0)
