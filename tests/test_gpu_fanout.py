@@ -27,7 +27,7 @@ def vnd():
     yield d
     ctx.set_variant(-1)
     d.set_default_mode(d.MODE_EXACT)
-    d.set_device_epilogue(False)
+    d.set_device_epilogue(None)
 
 
 def _table(fir):
@@ -164,7 +164,7 @@ def test_mono_device_epilogue(vnd, mode):
         want = vn.decorrelate(_replicate(x[0], 2))
         assert (np.array_equal(got, want) if mode == 'exact' else _close(got, want.astype(np.float64)) <= 2e-6)
     finally:
-        vnd.set_device_epilogue(False)
+        vnd.set_device_epilogue(None)
         vnd.set_default_mode(vnd.MODE_EXACT)
 
 

@@ -108,11 +108,18 @@ def test_class_convolve(vnd, golden, name):
 
 
 # ---- a8: VelvetNoise.decorrelate / SignalChain ----------------------------------
+@pytest.mark.parametrize('epilogue', ['default', 'host'])
 @pytest.mark.parametrize('name', sorted(MANIFEST['cls_decorrelate']))
-def test_class_decorrelate(vnd, golden, name):
+def test_class_decorrelate(vnd, golden, name, epilogue):
+    """default: the epilogue runs on the device in exact mode (bit-identical, normaliser included);
+    host: the NumPy epilogue behind the device convolution.  Both must reproduce the reference."""
     meta = golden.manifest['cls_decorrelate'][name]
     kw = _kw(golden.manifest['class_taps'][meta['class']]['kwargs'])
-    y = vnd.VelvetNoise(**kw).decorrelate(make_input(meta['input']))
+    vnd.set_device_epilogue(False if epilogue == 'host' else None)
+    try:
+        y = vnd.VelvetNoise(**kw).decorrelate(make_input(meta['input']))
+    finally:
+        vnd.set_device_epilogue(None)
     golden.expect(name, y, exact=True)
 
 
@@ -359,7 +366,7 @@ def test_device_epilogue(vnd, golden, name, mode):
     try:
         y = vnd.VelvetNoise(**kw).decorrelate(x.copy())
     finally:
-        vnd.set_device_epilogue(False)
+        vnd.set_device_epilogue(None)
         vnd.set_default_mode(vnd.MODE_EXACT)
     ref_meta = meta['out']
     assert list(y.shape) == ref_meta['shape'] and y.dtype == np.float32
@@ -367,6 +374,10 @@ def test_device_epilogue(vnd, golden, name, mode):
     if kw.get('normalizer', 'default') is None:
         # pointwise steps are bit-identical; the fast convolution stays within 1e-6 of peak
         golden.expect(name, y, exact=mode == 'exact', rtol_peak=TOL_PEAK)
+    elif mode == 'exact' and y.shape[-1] >= 2:
+        # exact mode sums the squares in the reference's own order (sequential float32): the whole
+        # stage, normaliser included, is bit-identical
+        golden.expect(name, y, exact=True)
     else:
         golden.expect(name, y, exact=False, rtol_peak=5e-4)      # vs the reference's sequential float32 RMS
         want = _exact_scale_oracle(x, kw)                        # vs exact arithmetic: float32 rounding only
@@ -401,13 +412,15 @@ def test_device_epilogue_batched(vnd, golden):
     for b in range(9):
         want = _exact_scale_oracle(x[b], kw)
         assert np.max(np.abs(y[b].astype(np.float64) - want)) <= 2e-6 * np.max(np.abs(want)), b
+        # exact mode: the batch is the loop of the (bit-identical) host-epilogue stage
+        assert np.array_equal(y[b], vn.decorrelate(x[b])), b
     with pytest.raises(ValueError):
         vnd.set_device_epilogue(True)
         try:
             vnd.VelvetNoise(sample_rate_hz=96000, seed=1, num_impulses=64, num_outs=8,
                             filtered_channels=tuple(range(8))).decorrelate(np.zeros((100, 8), np.float32))
         finally:
-            vnd.set_device_epilogue(False)
+            vnd.set_device_epilogue(None)
 
 
 def test_velvet_noise_regeneration_refreshes_device_table(vnd):

@@ -80,8 +80,9 @@ def test_resident_chain_equals_stage_by_stage(vnd, shape):
 
 
 def test_resident_example_chain_with_normaliser(vnd, golden):
-    """tests/test_example.py's chain on the viola excerpt.  The device epilogue's RMS is the exactly
-    rounded one where NumPy's float32 sum is sequential: 5e-4 of peak."""
+    """tests/test_example.py's chain on the viola excerpt.  Exact mode sums the squares in the
+    reference's order, so the resident chain is bit-identical normaliser and all; the fast mode's RMS is
+    the exactly rounded one where NumPy's float32 sum is sequential: 5e-4 of peak."""
     x = golden.arrays['viola_excerpt_in']
     fs = golden.manifest['audio']['viola_excerpt']['fs']
 
@@ -93,10 +94,10 @@ def test_resident_example_chain_with_normaliser(vnd, golden):
     want, got = build()(x), build(device_resident=True)(x)
     assert got.shape == want.shape and got.dtype == np.float64
     peak = np.max(np.abs(want))
-    assert np.max(np.abs(got - want)) <= 5e-4 * peak
+    assert np.array_equal(got, want)
     vnd.set_default_mode(vnd.MODE_FAST)
     try:
         fast = build(device_resident=True)(x)
     finally:
         vnd.set_default_mode(vnd.MODE_EXACT)
-    assert np.max(np.abs(fast - got)) <= 3e-6 * peak
+    assert np.max(np.abs(fast - want)) <= 5e-4 * peak

@@ -62,19 +62,28 @@ MODE_FAST = _native.MODE_FAST
 _default_mode = MODE_EXACT
 
 
-_device_epilogue = False
+_device_epilogue: Optional[bool] = None
 
 
-def set_device_epilogue(enabled: bool) -> None:
-    """Run ``VelvetNoise.decorrelate``'s epilogue (side-channel encode, width, RMS
-    normalise) on the GPU behind the convolution instead of in NumPy on the host.
+def set_device_epilogue(enabled: Optional[bool]) -> None:
+    """Where ``VelvetNoise.decorrelate``'s epilogue (side-channel encode, width, RMS
+    normalise) runs: ``True`` on the GPU behind the convolution, ``False`` in NumPy on the
+    host, ``None`` (default) on the GPU exactly when that is bit-identical to the reference.
 
-    Off by default: the host epilogue repeats NumPy's own float32 operations and
-    is bit-identical to the reference; the device epilogue is bit-identical up to
-    the normaliser and uses a correctly rounded RMS where NumPy's float32
-    axis-0 sum is sequential (a ~1e-4 relative difference on long signals)."""
+    The pointwise steps repeat NumPy's float32 operations on the device.  In MODE_EXACT
+    the normaliser also repeats NumPy's own sum of squares - a sequential float32 recurrence
+    for ``(n, C >= 2)`` arrays - so the whole stage is bit-identical and the device is the
+    default.  In the other modes the device RMS is the correctly rounded one (~1e-4
+    relative from NumPy's on long signals), so it is opt-in there."""
     global _device_epilogue
-    _device_epilogue = bool(enabled)
+    _device_epilogue = None if enabled is None else bool(enabled)
+
+
+def _use_device_epilogue(num_outs: int, has_normalizer: bool) -> bool:
+    if _device_epilogue is not None:
+        return _device_epilogue
+    # single-channel sums are pairwise in NumPy: only the host repeats them
+    return _default_mode == MODE_EXACT and (num_outs >= 2 or not has_normalizer)
 
 
 def set_default_mode(mode: int) -> None:
@@ -517,7 +526,8 @@ class VelvetNoise(Decorrelator):
             if self.num_outs == 2 and input_signal.shape[0] > 0:
                 mono = np.ascontiguousarray(input_signal, dtype=np.float32)[:, None]
             input_signal = mono_to_stereo(input_signal)
-        if _device_epilogue and self._device_epilogue_applies(input_signal):
+        if _use_device_epilogue(self.num_outs, self.normalizer is not None) and \
+                self._device_epilogue_applies(input_signal):
             return self._decorrelate_on_device(input_signal if mono is None else mono)
         if mono is not None:
             output_signal = self._device_table().convolve_host(mono, _default_mode)
