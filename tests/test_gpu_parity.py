@@ -458,3 +458,61 @@ def test_integration_stub_runs(vnd, golden):
     assert np.array_equal(ns['convolve_velvet_noise'](x, fir), O.convolve_velvet_noise(x, fir))
     with pytest.raises(ValueError):
         ns['convolve_velvet_noise'](x, golden.fir('g96k_k64_c8'))
+
+
+# ---- f1 exact mode: the sequential float32 sum of squares, settled in integers -------------------
+def _seq_sums(a):
+    """NumPy's axis-0 float32 reduction for (n, C >= 2): a sequential recurrence per channel."""
+    sq = np.square(a)
+    return np.cumsum(sq, axis=0, dtype=np.float32)[-1] if len(a) else np.zeros(a.shape[1], np.float32)
+
+
+def _adversarial_signals():
+    rng = np.random.default_rng(77)
+    n = 70001
+    yield 'int16_valued', rng.integers(-32768, 32767, (n, 2)).astype(np.float32)          # integer squares: ties galore
+    yield 'small_integers', rng.integers(0, 4, (n, 2)).astype(np.float32) * (rng.random((n, 2)) < 0.3)
+    late = np.zeros((n, 2), np.float32)
+    late[9000:] = rng.uniform(-1, 1, (n - 9000, 2))
+    yield 'silent_start', late
+    yield 'powers_of_two', np.ldexp(1.0, rng.integers(-8, 5, (n, 2))).astype(np.float32)
+    yield 'denormal_squares', (rng.uniform(-1, 1, (n, 2)) * 1e-21).astype(np.float32)
+    big = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+    big[40000, 0] = 3e19                                                                  # square overflows to inf
+    big[50000, 1] = np.nan
+    yield 'inf_and_nan', big
+    yield 'uniform_long', rng.uniform(-1, 1, (480000, 2)).astype(np.float32)
+    yield 'audio_like', (np.sin(np.arange(200000)[:, None] * np.array([0.01, 0.013])) * 0.2).astype(np.float32)
+    yield 'three_channels', rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    yield 'eight_channels_int', rng.integers(-500, 500, (n, 8)).astype(np.float32)
+    yield 'shorter_than_a_group', rng.uniform(-1, 1, (100, 2)).astype(np.float32)
+    yield 'one_frame', np.array([[0.5, -0.25]], np.float32)
+
+
+@pytest.mark.parametrize('name,x', list(_adversarial_signals()), ids=lambda v: v if isinstance(v, str) else '')
+def test_exact_rms_sums_are_numpys(vnd, name, x):
+    """vnd_decorrelate in exact mode must reproduce NumPy's sequential float32 sums bit for bit - on
+    data built to hit the integer fast path's exits (ties, binade crossings, zeros, non-finite)."""
+    import torch
+    from vndecorrelate_amd import _native
+    from vndecorrelate_amd.utils.dsp import rms_normalize
+    ctx = _native.default_context()
+    n, channels = x.shape
+    offsets = np.arange(channels + 1, dtype=np.int32)
+    table = _native.TapTable.create(ctx, offsets, np.zeros(channels, np.int32), np.ones(channels, np.float32))
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.empty_like(xd)
+    ws_bytes = _native.decorrelate_workspace_bytes(1, n, channels)
+    ws = torch.zeros(ws_bytes // 8 + 1, dtype=torch.float64, device='cuda')
+    table.decorrelate_device(xd.data_ptr(), yd.data_ptr(), 1, n, channels, mode=vnd.MODE_EXACT, ms_encode=False,
+                             width=None, normalize=True, workspace_ptr=ws.data_ptr(), workspace_bytes=ws_bytes,
+                             stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got_sums = ws[:2 * channels].cpu().numpy()             # exact mode: one row of 2C float32 sums (as doubles)
+    want = _seq_sums(x)
+    assert np.array_equal(got_sums[:channels].astype(np.float32), want, equal_nan=True), (name, got_sums, want)
+    assert np.array_equal(got_sums[channels:].astype(np.float32), want, equal_nan=True), name      # y == x here
+    ref = x.copy()
+    with np.errstate(all='ignore'):
+        rms_normalize(x, ref)
+    assert np.array_equal(yd.cpu().numpy(), ref, equal_nan=True), name

@@ -850,8 +850,9 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
         if (st != VND_OK || !any) return st;
         // VND_MODE_EXACT, C >= 2: the scale comes from the reference's own sequential float32 sums
         // (bit-identical stage); C == 1 is summed pairwise by NumPy and keeps the float64 sums.
-        const bool seq = mode == VND_MODE_EXACT && normalize && C >= 2 && n * 8 < (int64_t)0x7fffffff &&
-                         2 * C <= kSeqLanes && (size_t)2 * C * kSeqFrames * sizeof(float) <= (size_t)ctx->lds_limit;
+        const bool seq = mode == VND_MODE_EXACT && normalize && C >= 2 && 2 * C <= 64 &&
+                         n * C * 4 < (int64_t)0x7fffffff &&
+                         (size_t)2 * C * (C == 2 ? kSeqFramesStereo : kSeqFrames) * sizeof(float) <= (size_t)ctx->lds_limit;
         e.rows = seq ? 1 : (int32_t)epi_chunks(n);
         e.exact_rms = seq ? 1 : 0;
         if (seq) e.normalize = 0;                          // pointwise pass without its partial sums
@@ -859,12 +860,13 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
             hipLaunchKernelGGL(epilogue_pointwise_kernel, grid, dim3(kEpiThreads), 0, stream, e);
         if (seq) {
             e.normalize = 1;
-            const size_t lds = (size_t)2 * C * kSeqFrames * sizeof(float);
-            auto k = C != 2 ? epilogue_rms_seq_kernel
-                            : (Cx == 1 ? epilogue_rms_seq_stereo_kernel<true> : epilogue_rms_seq_stereo_kernel<false>);
+            const size_t lds = (size_t)2 * C * (C == 2 ? kSeqFramesStereo : kSeqFrames) * sizeof(float);
+            const int waves = C == 2 ? 4 : std::min(2 * C, kSeqMaxWaves);
+            auto k = C != 2 ? epilogue_rms_seq_kernel<false, false>
+                            : (Cx == 1 ? epilogue_rms_seq_kernel<true, true> : epilogue_rms_seq_kernel<true, false>);
             if (lds > 65536) HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                           ctx->lds_limit));
-            hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(kSeqLanes), lds, stream, e);
+            hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(64 * waves), lds, stream, e);
         }
     }
     if (normalize) {

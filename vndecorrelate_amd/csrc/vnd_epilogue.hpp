@@ -146,135 +146,185 @@ __global__ __launch_bounds__(kEpiThreads) void epilogue_reduce_kernel(const EArg
 // ---- the reference's own sum of squares, bit for bit (VND_MODE_EXACT, C >= 2) -----------------
 // np.mean(np.square(a), axis=0) on a C-contiguous float32 (n, C >= 2) array adds the rows one
 // after the other in float32 - acc[c] = f32(acc[c] + f32(a[i,c]^2)) - with no pairwise
-// splitting (measured against np.cumsum for n up to 2.9e6).  That recurrence
-// cannot be parallelised without changing its roundings, so ONE lane walks each
-// (stream, array, channel) chain while the whole wave keeps it fed: all 64 lanes load the next
-// block of frames and square it into LDS (chain-major), the 2C chain lanes then add their row of
-// the block, 64 squares per LDS burst.  The cost is the dependent-add latency, ~6 cycles per
-// frame whatever the batch (one wave per stream, up to a thousand streams side by side):
-// ~1.3 ms for 10 s of 48 kHz audio.  Writes one row of 2C sums per stream (as doubles, exact).
-constexpr int kSeqFrames = 2048;     // frames per block: its adds (~7 us) cover the next block's HBM latency
-constexpr int kSeqLanes = 64;
+// splitting (measured against np.cumsum for n up to 2.9e6).  The recurrence
+// cannot be re-associated in floating point, but it can be settled in INTEGERS a group at a
+// time: while acc = A * ulp stays inside one binade (A in [2^23, 2^24), ulp = 2^(e-23)), adding
+// s >= 0 gives  f32(acc + s) = (A + q + [r > ulp/2]) * ulp  with q = floor(s/ulp), r = s - q*ulp,
+// unless r == ulp/2 exactly (a tie, which rounds on the parity of the running sum).  So for a
+// group of 256 squares a wave computes every lane's q + [r > ulp/2] from the bit patterns (four
+// squares per lane), adds them across the wave, and if no lane saw a tie, a square as large as
+// acc, or anything non-finite, and A + Q < 2^24, then acc <- (A + Q) * ulp is exactly what 256
+// sequential float additions would have produced.  Otherwise (a few dozen groups per 10 s signal:
+// one per binade the sum climbs through, the tie-prone start, the rare later tie) the group is
+// added one square after the other.  A staged block of 2048 squares is first tried as a whole.  One wave per (stream, array, channel) chain, the chains of
+// a stream in one workgroup that stages blocks of 2048 frames into LDS, next block in flight.
+constexpr int kSeqFrames = 2048;     // frames per staged block (generic channel counts)
+constexpr int kSeqFramesStereo = 2048;   // stereo (4096 measured slower: a block with one tie costs twice as much)
+constexpr int kSeqGroup = 256;       // squares a wave settles at once (4 per lane)
+constexpr int kSeqMaxWaves = 16;
 
-// the chain lanes' part of one block: 64 squares per LDS burst, the next burst in flight while the
-// current one is added (the adds are a dependent chain, ~6.6 cycles each: nothing else to overlap)
-__device__ __forceinline__ float seq_add64(const float4 (&v)[16], float acc)
+// sum over the wave's 64 lanes by DPP row shifts and row broadcasts (a few cycles each; the
+// ds_bpermute ladder of __shfl_xor costs an LDS round trip per step)
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x)
 {
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        acc = acc + v[u].x;
-        acc = acc + v[u].y;
-        acc = acc + v[u].z;
-        acc = acc + v[u].w;
-    }
-    return acc;
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);    // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);    // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);    // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);    // row_shr:8: lane 15 of a row = row total
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, true);    // row_bcast:15 into rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, true);    // row_bcast:31 into rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }
 
-__device__ __forceinline__ float seq_add_block(const float *row_base, float acc)
+struct SeqTally {                 // one lane's view of some squares against acc's binade
+    uint32_t q_sum = 0, any_bits = 0;
+    bool bad = false;
+};
+
+__device__ __forceinline__ void seq_tally(SeqTally &t, const float4 &v4, int eb)
 {
-    static_assert(kSeqFrames % 128 == 0, "two bursts of 64 squares per iteration");
-    const float4 *__restrict__ row = (const float4 *)row_base;
-    float4 va[16], vb[16];
+    // s / ulp = s * 2^(150 - eb): a power-of-two scaling, exact (a result that underflows is far
+    // below 1/2 and rounds away either way); its floor is q, its fraction decides the rounding
+    const int k = 150 - eb;
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-    for (int u = 0; u < 16; ++u) va[u] = row[u];
+    for (int i = 0; i < 4; ++i) {
+        t.any_bits |= __float_as_uint(v[i]);
+        const float scaled = ldexpf(v[i], k);
+        const float whole = floorf(scaled);
+        const float frac = scaled - whole;                       // exact
+        t.bad |= !(scaled < 16777216.0f) || frac == 0.5f;        // a square as large as acc, inf, NaN; or a tie
+        t.q_sum += (uint32_t)whole + (frac > 0.5f ? 1u : 0u);
+    }
+}
+
+// true: acc has been advanced over the tallied squares (or they were all +0 on a zero acc)
+__device__ __forceinline__ bool seq_settle(const SeqTally &t, float &acc, int eb)
+{
+    const uint32_t ab = __float_as_uint(acc);
+    const bool bad = t.bad || eb <= 0 || eb >= 255 || t.q_sum >= (1u << 24);   // zero / denormal / non-finite acc
+    const uint32_t grown = ((ab & 0x7fffffu) | 0x800000u) + wave_sum_u32(t.q_sum);
+    if (__ballot(bad) == 0 && grown < (1u << 24)) {
+        acc = __uint_as_float(((uint32_t)eb << 23) | (grown & 0x7fffffu));
+        return true;
+    }
+    return ab == 0 && __ballot(t.any_bits != 0) == 0;               // +0 + +0 ... : still +0
+}
+
+__device__ __forceinline__ float seq_sum_group(const float *row, float acc, int lane)
+{
+    const int eb = (int)(__float_as_uint(acc) >> 23);   // acc is a sum of squares: sign 0 (a NaN may set it: eb > 255)
+    SeqTally t;
+    seq_tally(t, *(const float4 *)(row + 4 * lane), eb);
+    if (seq_settle(t, acc, eb)) return acc;
+    // one after the other; every lane does the same adds on the same (broadcast) LDS words
 #pragma unroll 1
-    for (int i = 0; i < kSeqFrames / 4; i += 32) {
+    for (int i = 0; i < kSeqGroup; i += 16) {
+        float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) vb[u] = row[i + 16 + u];
-        acc = seq_add64(va, acc);
-        const int next = i + 32 < kSeqFrames / 4 ? i + 32 : i;       // the last prefetch re-reads: harmless
+        for (int u = 0; u < 4; ++u) v[u] = *(const float4 *)(row + i + 4 * u);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) va[u] = row[next + u];
-        acc = seq_add64(vb, acc);
+        for (int u = 0; u < 4; ++u) {
+            acc = acc + v[u].x;
+            acc = acc + v[u].y;
+            acc = acc + v[u].z;
+            acc = acc + v[u].w;
+        }
     }
     return acc;
 }
 
-// Stereo: branch-free staging.  Each lane takes 4 consecutive frames per 256-frame round through
-// range-checked buffer loads (frames past the end read 0 and add +0: exact) and writes one float4
-// per chain; the NEXT block's loads are issued before the chain lanes start adding the current
-// one.  (A first version with per-frame bounds branches spent more time staging than adding: one
-// wave alone on its SIMD pays ~20 cycles per scalar branch.)
-template <bool MONO>
-__global__ __launch_bounds__(kSeqLanes) void epilogue_rms_seq_stereo_kernel(const EArgs a)
+// A whole staged block at once when nothing in it needs care (one reduction per 2048 squares),
+// else group by group.
+template <int FRAMES>
+__device__ __forceinline__ float seq_sum_block(const float *row, float acc, int lane)
 {
-    extern __shared__ __attribute__((aligned(16))) float sq[];      // [4][kSeqFrames]
-    constexpr int ROUND = 4 * kSeqLanes;                             // frames per round
-    constexpr int PER = kSeqFrames / ROUND;
-    const int lane = threadIdx.x;
+    const int eb = (int)(__float_as_uint(acc) >> 23);
+    SeqTally t;
+#pragma unroll
+    for (int g = 0; g < FRAMES; g += kSeqGroup) seq_tally(t, *(const float4 *)(row + g + 4 * lane), eb);
+    if (seq_settle(t, acc, eb)) return acc;
+#pragma unroll 1
+    for (int g = 0; g < FRAMES; g += kSeqGroup) acc = seq_sum_group(row + g, acc, lane);
+    return acc;
+}
+
+// blockDim.x = 64 * W, W = min(2C, 16) waves; wave w owns chains w, w + W, ...
+// STEREO: C == 2, branch-free vector staging (range-checked buffer loads: frames past the end
+// read 0 and add +0, exact); MONO: x has one channel, fanned out.
+template <bool STEREO, bool MONO>
+__global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(const EArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float sq[];      // [2C][BF]
+    constexpr int BF = STEREO ? kSeqFramesStereo : kSeqFrames;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, waves = blockDim.x >> 6;
+    const int C = STEREO ? 2 : a.C, Cx = a.Cx, chains = 2 * C;
     const int64_t b = blockIdx.x;
-    const v4i rx = make_rsrc(a.x + b * a.n * (MONO ? 1 : 2), a.n * (MONO ? 4 : 8));
-    const v4i ry = make_rsrc(a.y + b * a.n * 2, a.n * 8);
+    const int n = (int)a.n;                                // the host keeps 4 n C below 2^31
+    const float *__restrict__ xs = a.x + b * a.n * Cx;
+    const float *__restrict__ ys = a.y + b * a.n * C;
+    const v4i rx = make_rsrc(xs, a.n * Cx * 4);
+    const v4i ry = make_rsrc(ys, a.n * C * 4);
+    constexpr int PER = BF / 1024;                         // stereo: rounds of 4 frames per thread (256 threads)
     v2f xr[PER][4], yr[PER][4];
     auto fetch = [&](int f0) {
+        if constexpr (STEREO) {
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
+            for (int u = 0; u < PER; ++u) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int fr = f0 + u * ROUND + 4 * lane + k;
-                yr[u][k] = buf_load2(ry, fr * 8, 0, 0);
-                if constexpr (MONO) {
-                    const float v = buf_load1(rx, fr * 4, 0, 0);
-                    xr[u][k] = v2f{v, v};
-                } else {
-                    xr[u][k] = buf_load2(rx, fr * 8, 0, 0);
+                for (int k = 0; k < 4; ++k) {
+                    const int fr = f0 + u * (BF / PER) + 4 * tid + k;
+                    yr[u][k] = buf_load2(ry, fr * 8, 0, 0);
+                    if constexpr (MONO) {
+                        const float v = buf_load1(rx, fr * 4, 0, 0);
+                        xr[u][k] = v2f{v, v};
+                    } else {
+                        xr[u][k] = buf_load2(rx, fr * 8, 0, 0);
+                    }
                 }
             }
         }
     };
-    float acc = 0.0f;
-    const int n = (int)a.n;                                // the host keeps 8 n below 2^31
-    fetch(0);
-    for (int f0 = 0; f0 < n; f0 += kSeqFrames) {
-        __syncthreads();                                   // the chain lanes are done with the previous block
+    auto stage = [&](int f0) {
+        if constexpr (STEREO) {
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            float4 *dst = (float4 *)(sq + u * ROUND + 4 * lane);
-            dst[0 * kSeqFrames / 4] = make_float4(xr[u][0].x * xr[u][0].x, xr[u][1].x * xr[u][1].x,
-                                                  xr[u][2].x * xr[u][2].x, xr[u][3].x * xr[u][3].x);
-            dst[1 * kSeqFrames / 4] = make_float4(xr[u][0].y * xr[u][0].y, xr[u][1].y * xr[u][1].y,
-                                                  xr[u][2].y * xr[u][2].y, xr[u][3].y * xr[u][3].y);
-            dst[2 * kSeqFrames / 4] = make_float4(yr[u][0].x * yr[u][0].x, yr[u][1].x * yr[u][1].x,
-                                                  yr[u][2].x * yr[u][2].x, yr[u][3].x * yr[u][3].x);
-            dst[3 * kSeqFrames / 4] = make_float4(yr[u][0].y * yr[u][0].y, yr[u][1].y * yr[u][1].y,
-                                                  yr[u][2].y * yr[u][2].y, yr[u][3].y * yr[u][3].y);
+            for (int u = 0; u < PER; ++u) {
+                float4 *dst = (float4 *)(sq + u * (BF / PER) + 4 * tid);
+                dst[0 * BF / 4] = make_float4(xr[u][0].x * xr[u][0].x, xr[u][1].x * xr[u][1].x,
+                                                      xr[u][2].x * xr[u][2].x, xr[u][3].x * xr[u][3].x);
+                dst[1 * BF / 4] = make_float4(xr[u][0].y * xr[u][0].y, xr[u][1].y * xr[u][1].y,
+                                                      xr[u][2].y * xr[u][2].y, xr[u][3].y * xr[u][3].y);
+                dst[2 * BF / 4] = make_float4(yr[u][0].x * yr[u][0].x, yr[u][1].x * yr[u][1].x,
+                                                      yr[u][2].x * yr[u][2].x, yr[u][3].x * yr[u][3].x);
+                dst[3 * BF / 4] = make_float4(yr[u][0].y * yr[u][0].y, yr[u][1].y * yr[u][1].y,
+                                                      yr[u][2].y * yr[u][2].y, yr[u][3].y * yr[u][3].y);
+            }
+        } else {
+            for (int e = tid; e < BF * C; e += blockDim.x) {
+                const int f = e / C, c = e - f * C;
+                const int fr = f0 + f;
+                const float xv = buf_load1(rx, (fr * Cx + c % Cx) * 4, 0, 0);
+                const float yv = buf_load1(ry, (fr * C + c) * 4, 0, 0);
+                sq[c * BF + f] = fr < n ? xv * xv : 0.f;     // (fr*Cx+c%Cx may land in range past the last frame)
+                sq[(C + c) * BF + f] = yv * yv;
+            }
         }
+    };
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};                  // chains wave, wave + W, ... (2C <= 64 => at most 4 each)
+    fetch(0);
+    for (int f0 = 0; f0 < n; f0 += BF) {
+        __syncthreads();                                   // every wave is done with the previous block
+        stage(f0);
         __syncthreads();
-#if !(defined(VND_SEQ_ABLATE) && VND_SEQ_ABLATE == 2)
-        if (f0 + kSeqFrames < n) fetch(f0 + kSeqFrames);
-#endif
-#if !(defined(VND_SEQ_ABLATE) && VND_SEQ_ABLATE == 1)
-        if (lane < 4) acc = seq_add_block(sq + lane * kSeqFrames, acc);
-#endif
-    }
-    if (lane < 4) a.partials[b * a.rows * 4 + lane] = (double)acc;
-}
-
-// Any channel count >= 2 (plain loop, no prefetch).
-__global__ __launch_bounds__(kSeqLanes) void epilogue_rms_seq_kernel(const EArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) float sq[];      // [2C][kSeqFrames]
-    const int lane = threadIdx.x;
-    const int C = a.C, Cx = a.Cx;
-    const int64_t b = blockIdx.x;
-    const float *__restrict__ xs = a.x + b * a.n * Cx;
-    const float *__restrict__ ys = a.y + b * a.n * C;
-    const int chains = 2 * C;
-    float acc = 0.0f;
-    for (int64_t f0 = 0; f0 < a.n; f0 += kSeqFrames) {
-        __syncthreads();
-        for (int e = lane; e < kSeqFrames * C; e += kSeqLanes) {
-            const int f = e / C, c = e - f * C;
-            const int64_t fr = f0 + f;
-            const float xv = fr < a.n ? xs[fr * Cx + c % Cx] : 0.f;
-            const float yv = fr < a.n ? ys[fr * C + c] : 0.f;
-            sq[c * kSeqFrames + f] = xv * xv;
-            sq[(C + c) * kSeqFrames + f] = yv * yv;
+        if (f0 + BF < n) fetch(f0 + BF);
+        int slot = 0;
+        for (int ch = wave; ch < chains; ch += waves, ++slot) {
+            acc[slot] = seq_sum_block<BF>(sq + ch * BF, acc[slot], lane);
         }
-        __syncthreads();
-        if (lane < chains) acc = seq_add_block(sq + lane * kSeqFrames, acc);
     }
-    if (lane < chains) a.partials[b * a.rows * 2 * C + lane] = (double)acc;
+    int slot = 0;
+    for (int ch = wave; ch < chains; ch += waves, ++slot)
+        if (lane == 0) a.partials[b * a.rows * chains + ch] = (double)acc[slot];
 }
 
 // Pass 2: y[:, c] *= scale[c]
