@@ -205,6 +205,27 @@ static int arithmetic_of(const vnd_taps *t, int mode)
     return (mode == VND_MODE_EXACT && t->unit_weights) ? VND_MODE_FMA : mode;
 }
 
+// ordered kernel with the pointwise epilogue applied before the store (two channels per workgroup)
+template <int MODE, bool BC>
+static kern_t ordered_epi_by_r(int r)
+{
+    switch (r) {
+    case 1: return conv_ordered_kernel<kOrderedThreads, 2, 1, MODE, BC, true>;
+    case 2: return conv_ordered_kernel<kOrderedThreads, 2, 2, MODE, BC, true>;
+    case 4: return conv_ordered_kernel<kOrderedThreads, 2, 4, MODE, BC, true>;
+    case 8: return conv_ordered_kernel<kOrderedThreads, 2, 8, MODE, BC, true>;
+    default: return nullptr;
+    }
+}
+
+static kern_t ordered_epi_kernel(const Plan &p, int arithmetic)
+{
+    if (p.direct || p.cg != 2 || p.nt != kOrderedThreads) return nullptr;
+    const bool exact = arithmetic == VND_MODE_EXACT;
+    if (p.bc) return exact ? ordered_epi_by_r<0, true>(p.r) : ordered_epi_by_r<1, true>(p.r);
+    return exact ? ordered_epi_by_r<0, false>(p.r) : ordered_epi_by_r<1, false>(p.r);
+}
+
 static kern_t pick_kernel(const Plan &p, int mode)
 {
     if (p.bc)
@@ -348,7 +369,8 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
         if ((int64_t)batch * p.tiles * p.groups > 0x7fffffffLL)
             return fail(VND_ERR_UNSUPPORTED, "grid too large; split the batch");
         a.tiles = p.tiles; a.groups = p.groups; a.W = p.W;
-        kern_t k = epi ? fast_epi_kernel(p) : pick_kernel(p, arithmetic_of(t, mode));
+        kern_t k = !epi ? pick_kernel(p, arithmetic_of(t, mode))
+                 : (mode == VND_MODE_FAST ? fast_epi_kernel(p) : ordered_epi_kernel(p, arithmetic_of(t, mode)));
         if (!k) return fail(VND_ERR_UNSUPPORTED, "no kernel for this tile shape");
         if (epi) {
             a.epi_partials = epi->partials; a.epi_ms_encode = epi->ms_encode; a.epi_use_width = epi->use_width;
@@ -846,7 +868,18 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
         if (st != VND_OK) return st;
         e.rows = p.tiles;
     } else {
-        st = launch(ctx, t, x, y, batch, n, C, mode, stream, nullptr, Cx);
+        // table-order modes: the pointwise steps ride in the ordered kernel's store phase when the
+        // plan has both channels in one workgroup; the sums of squares follow as their own pass
+        const bool pointwise = ms_encode || use_width;
+        const bool in_kernel = pointwise && mode != VND_MODE_FAST && ctx->variant_nofuse == 0 &&
+                               ordered_epi_kernel(p, arithmetic_of(t, mode)) != nullptr;
+        if (in_kernel) {
+            EpiFuse f{nullptr, e.ms_encode, e.use_width, 0, e.w_mid, e.w_side};
+            st = launch(ctx, t, x, y, batch, n, C, mode, stream, &f, Cx);
+            e.ms_encode = e.use_width = 0;                 // done
+        } else {
+            st = launch(ctx, t, x, y, batch, n, C, mode, stream, nullptr, Cx);
+        }
         if (st != VND_OK || !any) return st;
         // VND_MODE_EXACT, C >= 2: the scale comes from the reference's own sequential float32 sums
         // (bit-identical stage); C == 1 is summed pairwise by NumPy and keeps the float64 sums.
@@ -856,7 +889,7 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
         e.rows = seq ? 1 : (int32_t)epi_chunks(n);
         e.exact_rms = seq ? 1 : 0;
         if (seq) e.normalize = 0;                          // pointwise pass without its partial sums
-        if (!seq || ms_encode || use_width)
+        if (e.ms_encode || e.use_width || (normalize && !seq))
             hipLaunchKernelGGL(epilogue_pointwise_kernel, grid, dim3(kEpiThreads), 0, stream, e);
         if (seq) {
             e.normalize = 1;

@@ -526,6 +526,31 @@ __device__ unsigned long long g_stamps[8 * 65536];
 #define VND_STAMP(slot) do { } while (0)
 #endif
 
+// The decorrelate epilogue's pointwise steps on one lane's stereo frame pair, in the reference's
+// float32 operation order (bit-identical to NumPy; the file is built with -ffp-contract=off).
+// v = {L0, R0, L1, R1} of the convolution, xin the same of the input.
+__device__ __forceinline__ void epi_pointwise(const KArgs &a, float (&v)[4], const float (&xin)[4])
+{
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {                    // the pair's two frames
+        float y0 = v[2 * f], y1 = v[2 * f + 1];
+        if (a.epi_ms_encode) {                       // utils/dsp.py:59-63
+            const float mid = xin[2 * f] + xin[2 * f + 1];
+            const float side = (y0 - y1) * 0.5f;
+            y0 = (mid + side) * 0.5f;
+            y1 = (mid - side) * 0.5f;
+        }
+        if (a.epi_use_width) {                       // utils/dsp.py:34-37
+            float m = (y0 + y1) * 0.5f, sd = (y0 - y1) * 0.5f;
+            m = m * a.epi_w_mid;
+            sd = sd * a.epi_w_side;
+            y0 = m + sd;
+            y1 = m - sd;
+        }
+        v[2 * f] = y0; v[2 * f + 1] = y1;
+    }
+}
+
 // EPI: the decorrelate epilogue's pointwise steps (side-channel encode, stereo width;
 // reference utils/dsp.py:21-63) are applied to the tile before it is stored, in the
 // reference's float32 operation order, and the tile's sums of x^2 and y^2 go to
@@ -647,26 +672,7 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
                 const float2 xp = *(const float2 *)(lds + (BC ? 0 : c * W) + 2 * q);
                 xin[c] = xp.x; xin[CG + c] = xp.y;
             }
-            if constexpr (CG == 2) {
-#pragma unroll
-                for (int f = 0; f < 2; ++f) {            // the pair's two frames
-                    float y0 = v[f * CG], y1 = v[f * CG + 1];
-                    if (a.epi_ms_encode) {               // utils/dsp.py:59-63
-                        const float mid = xin[f * CG] + xin[f * CG + 1];
-                        const float side = (y0 - y1) * 0.5f;
-                        y0 = (mid + side) * 0.5f;
-                        y1 = (mid - side) * 0.5f;
-                    }
-                    if (a.epi_use_width) {               // utils/dsp.py:34-37
-                        float m = (y0 + y1) * 0.5f, sd = (y0 - y1) * 0.5f;
-                        m = m * a.epi_w_mid;
-                        sd = sd * a.epi_w_side;
-                        y0 = m + sd;
-                        y1 = m - sd;
-                    }
-                    v[f * CG] = y0; v[f * CG + 1] = y1;
-                }
-            }
+            if constexpr (CG == 2) epi_pointwise(a, v, xin);
 #pragma unroll
             for (int c = 0; c < CG; ++c) {               // frames past the stream's end are zeros
                 sum_x[c] += xin[c] * xin[c] + xin[CG + c] * xin[CG + c];
@@ -757,7 +763,9 @@ __device__ __forceinline__ void ordered_tap(const FastTap &t, unsigned lane_addr
     ordered_consume<MODE, R>(sb, val, t.w);
 }
 
-template <int NT, int CG, int R, int MODE, bool BC = false>
+// EPI (CG == 2): the pointwise epilogue steps are applied before the store - the input planes are
+// still intact in LDS - which saves the separate read-modify-write pass over y in exact mode.
+template <int NT, int CG, int R, int MODE, bool BC = false, bool EPI = false>
 __global__ __launch_bounds__(NT) void conv_ordered_kernel(const KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -834,6 +842,12 @@ __global__ __launch_bounds__(NT) void conv_ordered_kernel(const KArgs a)
         float v[2 * CG];
 #pragma unroll
         for (int c = 0; c < CG; ++c) { v[c] = out[c][j].x; v[CG + c] = out[c][j].y; }
+        if constexpr (EPI && CG == 2) {
+            const int q = tid + NT * j;
+            const float2 x0 = *(const float2 *)(lds + 2 * q), x1 = *(const float2 *)(lds + (BC ? 0 : W) + 2 * q);
+            const float xin[4] = {x0.x, x1.x, x0.y, x1.y};
+            epi_pointwise(a, v, xin);
+        }
         store_result<CG>(rdst, shape, tid + NT * j, strideG, C, v);
     }
 }
