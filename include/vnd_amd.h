@@ -108,9 +108,16 @@ vnd_status vnd_convolve_f32_host(vnd_ctx *ctx, const vnd_taps *taps, const float
  *   ms_encode  encode_signal_to_side_channel(x, y)      utils/dsp.py:40-63   (2 channels)
  *   use_width  apply_stereo_width(y, width)             utils/dsp.py:21-37   (2 channels)
  *   normalize  rms_normalize(x, y), DUAL_MONO           utils/dsp.py:87-109  (eps = 1e-10 upstream)
- * The pointwise steps are bit-identical to NumPy; the RMS scale uses an exactly
- * rounded sum where NumPy's float32 reduction is sequential (see vnd_epilogue.hpp).
+ * The pointwise steps are bit-identical to NumPy.  The normaliser's sums of squares:
+ *   VND_MODE_EXACT, or normalize = VND_NORMALIZE_RMS_REFERENCE_ORDER in any mode (2+ channels):
+ *     NumPy's own sequential float32 recurrence, reproduced bit for bit - in exact mode the
+ *     whole stage is bit-identical to the reference;
+ *   otherwise (normalize = VND_NORMALIZE_RMS): exactly rounded float64 sums, fused into the
+ *     fast kernel - the fastest form, ~1e-4 relative from NumPy's RMS on long signals.
  * `workspace` is device memory of >= vnd_decorrelate_workspace_bytes().          */
+#define VND_NORMALIZE_OFF 0
+#define VND_NORMALIZE_RMS 1
+#define VND_NORMALIZE_RMS_REFERENCE_ORDER 2
 vnd_status vnd_decorrelate_workspace_bytes(int64_t batch, int64_t n_frames, int32_t n_channels,
                                            int64_t *bytes);
 vnd_status vnd_decorrelate_f32_dev(vnd_ctx *ctx, const vnd_taps *taps, const float *x_dev, float *y_dev,

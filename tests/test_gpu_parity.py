@@ -391,6 +391,7 @@ def test_fused_and_unfused_epilogue_agree(vnd, golden):
     x = make_input(dict(seed=14, shape=[5, 30011, 2]))
     outs = []
     vnd.set_default_mode(vnd.MODE_FAST)
+    vnd.set_device_epilogue(True)                        # the fused float64-sum form
     try:
         for variant in (-1, 1 << 24, 2, 8):              # auto (fused), unfused, fused at other tile sizes
             ctx.set_variant(variant)
@@ -399,9 +400,25 @@ def test_fused_and_unfused_epilogue_agree(vnd, golden):
     finally:
         ctx.set_variant(-1)
         vnd.set_default_mode(vnd.MODE_EXACT)
+        vnd.set_device_epilogue(None)
     peak = np.max(np.abs(outs[0]))
     for y in outs[1:]:
         assert np.max(np.abs(y - outs[0])) <= 2e-6 * peak
+
+
+@pytest.mark.parametrize('mode', ['fma', 'fast'])
+@pytest.mark.parametrize('name', sorted(MANIFEST['cls_decorrelate']))
+def test_default_epilogue_in_tolerance_modes(vnd, golden, name, mode):
+    """Default policy outside exact mode: device epilogue with the sums in NumPy's order, so the stage
+    differs from the reference only through the convolution's 1e-6 of peak."""
+    meta = golden.manifest['cls_decorrelate'][name]
+    kw = _kw(golden.manifest['class_taps'][meta['class']]['kwargs'])
+    vnd.set_default_mode(vnd.MODE_FMA if mode == 'fma' else vnd.MODE_FAST)
+    try:
+        y = vnd.VelvetNoise(**kw).decorrelate(make_input(meta['input']))
+    finally:
+        vnd.set_default_mode(vnd.MODE_EXACT)
+    golden.expect(name, y, exact=False, rtol_peak=3e-6)
 
 
 def test_device_epilogue_batched(vnd, golden):
@@ -463,8 +480,9 @@ def test_integration_stub_runs(vnd, golden):
 # ---- f1 exact mode: the sequential float32 sum of squares, settled in integers -------------------
 def _seq_sums(a):
     """NumPy's axis-0 float32 reduction for (n, C >= 2): a sequential recurrence per channel."""
-    sq = np.square(a)
-    return np.cumsum(sq, axis=0, dtype=np.float32)[-1] if len(a) else np.zeros(a.shape[1], np.float32)
+    with np.errstate(all='ignore'):
+        sq = np.square(a)
+        return np.cumsum(sq, axis=0, dtype=np.float32)[-1] if len(a) else np.zeros(a.shape[1], np.float32)
 
 
 def _adversarial_signals():

@@ -14,7 +14,7 @@ def build(**kw):
             .haas_effect(delay_time_seconds=0.02, delayed_channel=1, mode='LR'))
 
 
-for label, chain in (('stage by stage (NumPy epilogue + NumPy Haas)', build()),
+for label, chain in (('stage by stage (host arrays between stages)', build()),
                      ('device resident', build(device_resident=True))):
     for mode, name in ((vnd.MODE_EXACT, 'exact'), (vnd.MODE_FAST, 'fast')):
         vnd.set_default_mode(mode)

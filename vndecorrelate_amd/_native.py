@@ -19,6 +19,7 @@ MODE_EXACT = 0   # acc = f32(acc + f32(x*w)) : bit-identical to the reference's 
 MODE_FMA = 1     # acc = fma(x, w, acc), table order
 MODE_FAST = 2    # fma, free summation order, gains folded into weights: the throughput mode
 MOMENTS = 8      # VND_MOMENTS: doubles per candidate returned by the scan
+NORMALIZE_OFF, NORMALIZE_RMS, NORMALIZE_RMS_REFERENCE_ORDER = 0, 1, 2   # the `normalize` argument of the decorrelate calls
 
 _PKG = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get('VND_AMD_LIBRARY', _PKG / 'libvnd_amd.so'))   # override: tuning builds only
@@ -312,11 +313,12 @@ class TapTable:
         return y
 
     def decorrelate_host(self, x: np.ndarray, mode: int = MODE_EXACT, *, ms_encode: bool, width,
-                         normalize: bool, eps: float = 1e-10) -> np.ndarray:
-        """Convolution + decorrelate epilogue on the device; x as in ``convolve_host``."""
+                         normalize, eps: float = 1e-10) -> np.ndarray:
+        """Convolution + decorrelate epilogue on the device; x as in ``convolve_host``.
+        ``normalize``: False/True or one of the ``NORMALIZE_*`` values."""
         batch, n, c, y = self._host_shapes(x, 'decorrelate_host')
         tail = (int(mode), int(bool(ms_encode)), int(width is not None), float(width or 0.0),
-                int(bool(normalize)), float(eps))
+                int(normalize), float(eps))
         if c == self.num_channels:
             _check(self._lib.vnd_decorrelate_f32_host(
                 self.ctx.handle, self.handle, _ptr(x, ctypes.c_float), _ptr(y, ctypes.c_float), batch, n, c,
@@ -335,7 +337,7 @@ class TapTable:
                     if channels == self.num_channels else
                     (self._lib.vnd_decorrelate_fanout_f32_dev, 'vnd_decorrelate_fanout_f32_dev'))
         _check(fn(self.ctx.handle, self.handle, ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr), batch, n, channels,
-                  int(mode), int(bool(ms_encode)), int(width is not None), float(width or 0.0), int(bool(normalize)),
+                  int(mode), int(bool(ms_encode)), int(width is not None), float(width or 0.0), int(normalize),
                   float(eps), ctypes.c_void_p(workspace_ptr), workspace_bytes, ctypes.c_void_p(stream)), name)
 
     def convolve_device(self, x_ptr: int, y_ptr: int, batch: int, n: int, channels: int,

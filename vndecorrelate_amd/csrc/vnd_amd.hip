@@ -860,13 +860,21 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
 
     // Fused form: the fast kernel applies the pointwise steps and writes one row of sums per tile.
     const Plan p = make_plan(ctx, t, batch, n, C, mode, Cx);
+    // normalize == VND_NORMALIZE_RMS_REFERENCE_ORDER: the sums of squares in NumPy's own (sequential
+    // float32) order in every mode, so that the scale differs from the reference's only through y
+    const bool seq_ok = normalize && C >= 2 && 2 * C <= 64 && n * C * 4 < (int64_t)0x7fffffff &&
+                        (size_t)2 * C * (C == 2 ? kSeqFramesStereo : kSeqFrames) * sizeof(float) <= (size_t)ctx->lds_limit;
+    const bool want_seq = seq_ok && (mode == VND_MODE_EXACT || normalize == VND_NORMALIZE_RMS_REFERENCE_ORDER);
     const bool fused = any && mode == VND_MODE_FAST && ctx->variant_nofuse == 0 && fast_epi_kernel(p) != nullptr &&
-                       (!(ms_encode || use_width) || p.cg == 2);
+                       (!(ms_encode || use_width) || p.cg == 2) && !(want_seq && !(ms_encode || use_width));
+    bool sums_pending = false;                             // the sequential sums still have to run
     if (fused) {
-        EpiFuse f{(double *)workspace, e.ms_encode, e.use_width, e.normalize, e.w_mid, e.w_side};
+        // with reference-order sums the fused kernel only applies the pointwise steps
+        EpiFuse f{(double *)workspace, e.ms_encode, e.use_width, want_seq ? 0 : e.normalize, e.w_mid, e.w_side};
         st = launch(ctx, t, x, y, batch, n, C, mode, stream, &f, Cx);
         if (st != VND_OK) return st;
         e.rows = p.tiles;
+        sums_pending = want_seq;
     } else {
         // table-order modes: the pointwise steps ride in the ordered kernel's store phase when the
         // plan has both channels in one workgroup; the sums of squares follow as their own pass
@@ -881,26 +889,26 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
             st = launch(ctx, t, x, y, batch, n, C, mode, stream, nullptr, Cx);
         }
         if (st != VND_OK || !any) return st;
-        // VND_MODE_EXACT, C >= 2: the scale comes from the reference's own sequential float32 sums
-        // (bit-identical stage); C == 1 is summed pairwise by NumPy and keeps the float64 sums.
-        const bool seq = mode == VND_MODE_EXACT && normalize && C >= 2 && 2 * C <= 64 &&
-                         n * C * 4 < (int64_t)0x7fffffff &&
-                         (size_t)2 * C * (C == 2 ? kSeqFramesStereo : kSeqFrames) * sizeof(float) <= (size_t)ctx->lds_limit;
+        // reference-order sums (always in VND_MODE_EXACT, C >= 2: the bit-identical stage); C == 1 is
+        // summed pairwise by NumPy and keeps the float64 sums.
+        const bool seq = want_seq;
         e.rows = seq ? 1 : (int32_t)epi_chunks(n);
-        e.exact_rms = seq ? 1 : 0;
         if (seq) e.normalize = 0;                          // pointwise pass without its partial sums
         if (e.ms_encode || e.use_width || (normalize && !seq))
             hipLaunchKernelGGL(epilogue_pointwise_kernel, grid, dim3(kEpiThreads), 0, stream, e);
-        if (seq) {
-            e.normalize = 1;
-            const size_t lds = (size_t)2 * C * (C == 2 ? kSeqFramesStereo : kSeqFrames) * sizeof(float);
-            const int waves = C == 2 ? 4 : std::min(2 * C, kSeqMaxWaves);
-            auto k = C != 2 ? epilogue_rms_seq_kernel<false, false>
-                            : (Cx == 1 ? epilogue_rms_seq_kernel<true, true> : epilogue_rms_seq_kernel<true, false>);
-            if (lds > 65536) HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                          ctx->lds_limit));
-            hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(64 * waves), lds, stream, e);
-        }
+        sums_pending = seq;
+    }
+    if (sums_pending) {
+        e.rows = 1;
+        e.exact_rms = 1;
+        e.normalize = 1;
+        const size_t lds = (size_t)2 * C * (C == 2 ? kSeqFramesStereo : kSeqFrames) * sizeof(float);
+        const int waves = C == 2 ? 4 : std::min(2 * C, kSeqMaxWaves);
+        auto k = C != 2 ? epilogue_rms_seq_kernel<false, false>
+                        : (Cx == 1 ? epilogue_rms_seq_kernel<true, true> : epilogue_rms_seq_kernel<true, false>);
+        if (lds > 65536) HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      ctx->lds_limit));
+        hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(64 * waves), lds, stream, e);
     }
     if (normalize) {
         hipLaunchKernelGGL(epilogue_reduce_kernel, dim3((unsigned)batch), dim3(kEpiThreads), 0, stream, e);

@@ -67,14 +67,18 @@ _device_epilogue: Optional[bool] = None
 
 def set_device_epilogue(enabled: Optional[bool]) -> None:
     """Where ``VelvetNoise.decorrelate``'s epilogue (side-channel encode, width, RMS
-    normalise) runs: ``True`` on the GPU behind the convolution, ``False`` in NumPy on the
-    host, ``None`` (default) on the GPU exactly when that is bit-identical to the reference.
+    normalise) runs.
 
-    The pointwise steps repeat NumPy's float32 operations on the device.  In MODE_EXACT
-    the normaliser also repeats NumPy's own sum of squares - a sequential float32 recurrence
-    for ``(n, C >= 2)`` arrays - so the whole stage is bit-identical and the device is the
-    default.  In the other modes the device RMS is the correctly rounded one (~1e-4
-    relative from NumPy's on long signals), so it is opt-in there."""
+    ``None`` (default): on the GPU behind the convolution, with the normaliser's sums of
+    squares in NumPy's own order (a sequential float32 recurrence for ``(n, C >= 2)`` arrays,
+    reproduced bit for bit).  In MODE_EXACT the whole stage is then bit-identical to the
+    reference; in the other modes it differs from it only through the convolution
+    (~1e-6 of peak).  Single-channel tables, whose sums NumPy forms pairwise, and custom
+    normalisers keep the host epilogue.
+    ``True``: on the GPU in its fastest form - in MODE_FAST everything fused into the fast
+    kernel with exactly rounded float64 sums, which puts the normalised output ~1e-4
+    relative from the reference's on long signals (NumPy's sequential sum is that far off).
+    ``False``: in NumPy on the host, behind the device convolution."""
     global _device_epilogue
     _device_epilogue = None if enabled is None else bool(enabled)
 
@@ -82,8 +86,13 @@ def set_device_epilogue(enabled: Optional[bool]) -> None:
 def _use_device_epilogue(num_outs: int, has_normalizer: bool) -> bool:
     if _device_epilogue is not None:
         return _device_epilogue
-    # single-channel sums are pairwise in NumPy: only the host repeats them
-    return _default_mode == MODE_EXACT and (num_outs >= 2 or not has_normalizer)
+    return num_outs >= 2 or not has_normalizer
+
+
+def _normalize_flag(has_normalizer: bool) -> int:
+    if not has_normalizer:
+        return _native.NORMALIZE_OFF
+    return _native.NORMALIZE_RMS if _device_epilogue else _native.NORMALIZE_RMS_REFERENCE_ORDER
 
 
 def set_default_mode(mode: int) -> None:
@@ -561,7 +570,7 @@ class VelvetNoise(Decorrelator):
         table = self._device_table()
         return table.decorrelate_host(np.ascontiguousarray(x, dtype=np.float32), _default_mode,
                                       ms_encode=self.mode == LayoutMode.MS, width=self.width,
-                                      normalize=self.normalizer is not None)
+                                      normalize=_normalize_flag(self.normalizer is not None))
 
     def decorrelate_batched(self, input_signals: NDArray) -> NDArray:
         """``(B, n, num_outs)`` independent signals through the whole stage in one

@@ -55,7 +55,7 @@ def _velvet_on_device(stage, buf, torch, dec):
     work = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     stage._device_table().decorrelate_device(
         x.data_ptr(), y.data_ptr(), 1, n, channels, mode=dec._default_mode, ms_encode=stage.mode == LayoutMode.MS,
-        width=stage.width, normalize=stage.normalizer is not None, workspace_ptr=work.data_ptr(),
+        width=stage.width, normalize=dec._normalize_flag(stage.normalizer is not None), workspace_ptr=work.data_ptr(),
         workspace_bytes=ws_bytes, stream=torch.cuda.current_stream().cuda_stream)
     return y
 
