@@ -77,3 +77,94 @@ def test_class_path_tables(ctx, tab, n, seed, pairs):
                              seg_end=arr.seg_end, seg_gain=arr.seg_gain, chan_flags=arr.chan_flags,
                              apply_gain=arr.apply_gain)
     _check(ctx, arr, x, want, pairs)
+
+
+# ---- the rows beyond the plain convolution: whole stage, fan-out, Haas -----------------------------
+def _numpy_stage(x, y, ms_encode, width, normalize):
+    """The reference's epilogue (decorrelation.py:433-440) with its own NumPy helpers."""
+    from vndecorrelate_amd.utils import dsp
+    if ms_encode:
+        dsp.encode_signal_to_side_channel(x, y)
+    if width is not None:
+        dsp.apply_stereo_width(y, width)
+    if normalize:
+        with np.errstate(all='ignore'):
+            dsp.rms_normalize(x, y)
+    return y
+
+
+@SET
+@given(tab=class_table(), n=st.integers(1, 9000), seed=st.integers(0, 2**31 - 1), kind=st.sampled_from(['uniform', 'int16', 'sparse']),
+       ms_encode=st.booleans(), width=st.sampled_from([None, 0.0, 0.3, 1.0]), normalize=st.booleans(),
+       mono=st.booleans(), batch=st.integers(1, 3))
+def test_exact_stage_is_numpys(ctx, tab, n, seed, kind, ms_encode, width, normalize, mono, batch):
+    """vnd_decorrelate in exact mode == bit-exact convolution + the NumPy epilogue, for random class
+    tables, lengths, integer-valued and sparse signals (ties and zero runs in the sums), mono fan-out."""
+    from vndecorrelate_amd import _native
+    chans, env = tab
+    channels = len(chans)
+    stereo_steps = ms_encode or width is not None
+    if stereo_steps and channels != 2:
+        ms_encode, width = False, None
+    in_channels = 1 if (mono and channels == 2) else channels
+    rng = np.random.default_rng(seed)
+    if kind == 'uniform':
+        x = rng.uniform(-1, 1, (batch, n, in_channels))
+    elif kind == 'int16':
+        x = rng.integers(-32768, 32767, (batch, n, in_channels)).astype(np.float64)
+    else:
+        x = rng.integers(-3, 4, (batch, n, in_channels)) * (rng.random((batch, n, in_channels)) < 0.2)
+    x = np.ascontiguousarray(x, np.float32)
+    arr = class_path_arrays(chans, env, env != (1.0,))
+    table = _native.TapTable.create(ctx, arr.tap_offsets, arr.tap_index, arr.tap_weight, **arr.kwargs())
+    try:
+        got = table.decorrelate_host(x, 0, ms_encode=ms_encode, width=width, normalize=normalize)
+    finally:
+        table.close()
+    full = np.ascontiguousarray(np.tile(x, (1, 1, channels // in_channels)))
+    conv = c_oracle.convolve(full, arr.tap_offsets, arr.tap_index, arr.tap_weight, seg_off=arr.seg_offsets,
+                             seg_end=arr.seg_end, seg_gain=arr.seg_gain, chan_flags=arr.chan_flags,
+                             apply_gain=arr.apply_gain)
+    for b in range(batch):
+        want = _numpy_stage(full[b], conv[b].copy(), ms_encode, width, normalize and channels >= 2)
+        if normalize and channels == 1:
+            continue                                   # NumPy sums a single channel pairwise: tolerance only, elsewhere
+        assert np.array_equal(got[b], want, equal_nan=True), (b, channels, in_channels, kind)
+
+
+@SET
+@given(fir=sparse_fir(), n=st.integers(1, 5000), seed=st.integers(0, 2**31 - 1), fan=st.integers(1, 3),
+       pairs=st.sampled_from([0, 1, 4]))
+def test_fanout_equals_replicated_input(ctx, fir, n, seed, fan, pairs):
+    """A bank of `fan` copies of a random filter over one signal == the plain call on the tiled signal."""
+    from vndecorrelate_amd import _native
+    from vndecorrelate_amd.taps import concat_tap_arrays
+    in_channels = fir.shape[1]
+    x = np.random.default_rng(seed).uniform(-1, 1, (n, in_channels)).astype(np.float32)
+    bank = concat_tap_arrays([function_path_arrays(fir)] * fan)
+    table = _native.TapTable.create(ctx, bank.tap_offsets, bank.tap_index, bank.tap_weight)
+    want = c_oracle.convolve(np.ascontiguousarray(np.tile(x, (1, fan))), bank.tap_offsets, bank.tap_index,
+                             bank.tap_weight)
+    try:
+        ctx.set_variant(pairs)
+        assert np.array_equal(table.convolve_host(x, 0), want)
+        peak = max(float(np.max(np.abs(want))), 1e-30)
+        floor = 2.0 ** -24 * _term_scale(bank, x)
+        assert np.max(np.abs(table.convolve_host(x, 2).astype(np.float64) - want)) <= 1e-6 * peak + floor + 1e-30
+    finally:
+        ctx.set_variant(-1)
+        table.close()
+
+
+@SET
+@given(n=st.integers(0, 3000), delay=st.integers(0, 4000), channel=st.integers(0, 1), ms_mode=st.booleans(),
+       width=st.sampled_from([None, 0.0, 0.25, 0.9]), mono=st.booleans(), seed=st.integers(0, 2**31 - 1))
+def test_device_haas_is_the_oracles(ctx, n, delay, channel, ms_mode, width, mono, seed):
+    from oracle import vnd_oracle as O
+    from vndecorrelate_amd import _native
+    x = np.random.default_rng(seed).uniform(-1, 1, (n,) if mono else (n, 2)).astype(np.float32)
+    want = O.haas_effect(x, sample_rate_hz=1000, delay_time_seconds=delay / 1000, delayed_channel=channel,
+                         mode='MS' if ms_mode else 'LR', width=width)
+    got = _native.haas_host(ctx, np.ascontiguousarray(x[:, None] if mono else x), delay=delay, delayed_channel=channel,
+                            ms_mode=ms_mode, width=width)
+    assert got.shape == want.shape and np.array_equal(got, want)
