@@ -1016,8 +1016,7 @@ vnd_status vnd_polar_moments_f32_dev(vnd_ctx *ctx, const float *y, int64_t n, in
         hipLaunchKernelGGL(moments_by_frame_kernel, dim3((unsigned)chunks, (unsigned)n_pairs), dim3(kMomThreads), 0,
                            stream, a);
     }
-    const unsigned rblocks = (unsigned)(((int64_t)n_pairs * kMoments + kMomThreads - 1) / kMomThreads);
-    hipLaunchKernelGGL(moments_reduce_kernel, dim3(rblocks), dim3(kMomThreads), 0, stream, a);
+    hipLaunchKernelGGL(moments_reduce_kernel, dim3((unsigned)n_pairs), dim3(kMomThreads), 0, stream, a);
     HIP_TRY(hipGetLastError());
     return VND_OK;
 }

@@ -122,18 +122,39 @@ __global__ __launch_bounds__(kMomThreads) void moments_by_frame_kernel(const MAr
     }
 }
 
-// One thread per (candidate, moment) adds the chunks in order: deterministic.
+// One workgroup per candidate: threads stride over the chunks (each reads the chunk's 8 contiguous
+// doubles), then a fixed-order tree across the workgroup - the same order every run.
 __global__ __launch_bounds__(kMomThreads) void moments_reduce_kernel(const MArgs a)
 {
-    const int64_t e = (int64_t)blockIdx.x * kMomThreads + threadIdx.x;
-    if (e >= (int64_t)a.F * kMoments) return;
-    const int k = (int)(e % kMoments);
-    double t = 0.0;
-    for (int c = 0; c < a.chunks; ++c) {
-        const double v = a.partials[(int64_t)c * a.F * kMoments + e];
-        t = k == 4 ? fmax(t, v) : t + v;
+    __shared__ double red[kMomThreads / 64][kMoments];
+    const int f = blockIdx.x;
+    double v[kMoments];
+#pragma unroll
+    for (int k = 0; k < kMoments; ++k) v[k] = 0.0;
+    for (int c = threadIdx.x; c < a.chunks; c += kMomThreads) {
+        const double *p = a.partials + ((int64_t)c * a.F + f) * kMoments;
+#pragma unroll
+        for (int k = 0; k < kMoments; ++k) v[k] = k == 4 ? fmax(v[k], p[k]) : v[k] + p[k];
     }
-    a.moments[e] = t;
+#pragma unroll
+    for (int k = 0; k < kMoments; ++k) {
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) {
+            const double o = __shfl_xor(v[k], sh);
+            v[k] = k == 4 ? fmax(v[k], o) : v[k] + o;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < kMoments; ++k) red[threadIdx.x >> 6][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < kMoments) {
+        const int k = threadIdx.x;
+        double t = red[0][k];
+        for (int w = 1; w < kMomThreads / 64; ++w) t = k == 4 ? fmax(t, red[w][k]) : t + red[w][k];
+        a.moments[(int64_t)f * kMoments + k] = t;
+    }
 }
 
 }  // namespace vnd
