@@ -177,24 +177,33 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x)
 }
 
 struct SeqTally {                 // one lane's view of some squares against acc's binade
-    uint32_t q_sum = 0, any_bits = 0;
-    bool bad = false;
+    v2f q = {0.f, 0.f};           // sum of round(s / ulp): integers, exact in float while below 2^24
+    v2f smax = {0.f, 0.f};        // largest s / ulp seen
+    v2f rmax = {0.f, 0.f}, rmin = {0.f, 0.f};     // extreme rounding remainders: +-1/2 means a tie
+    uint32_t any_bits = 0;
 };
 
-__device__ __forceinline__ void seq_tally(SeqTally &t, const float4 &v4, int eb)
+// 2^(150 - eb) as a float: s / ulp = s * that.  eb in [23, 254] (smaller sums take the slow path).
+__device__ __forceinline__ float seq_scale(int eb) { return __uint_as_float((uint32_t)(277 - eb) << 23); }
+
+__device__ __forceinline__ void seq_tally(SeqTally &t, const float4 &v4, float scale)
 {
-    // s / ulp = s * 2^(150 - eb): a power-of-two scaling, exact (a result that underflows is far
-    // below 1/2 and rounds away either way); its floor is q, its fraction decides the rounding
-    const int k = 150 - eb;
-    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    // s / ulp by a power-of-two multiply (exact; a product that underflows is far below 1/2 and
+    // rounds away either way), rounded to the nearest integer with the 2^23 trick - packed, two
+    // squares per instruction, and no comparison inside the loop: what can go wrong is only
+    // tracked (largest scaled square, extreme remainders) and judged once per block in seq_settle.
+    const v2f sc = {scale, scale}, magic = {8388608.0f, 8388608.0f};
+    const v2f in[2] = {v2f{v4.x, v4.y}, v2f{v4.z, v4.w}};
+    t.any_bits |= __float_as_uint(v4.x) | __float_as_uint(v4.y) | __float_as_uint(v4.z) | __float_as_uint(v4.w);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        t.any_bits |= __float_as_uint(v[i]);
-        const float scaled = ldexpf(v[i], k);
-        const float whole = floorf(scaled);
-        const float frac = scaled - whole;                       // exact
-        t.bad |= !(scaled < 16777216.0f) || frac == 0.5f;        // a square as large as acc, inf, NaN; or a tie
-        t.q_sum += (uint32_t)whole + (frac > 0.5f ? 1u : 0u);
+    for (int i = 0; i < 2; ++i) {
+        const v2f scaled = in[i] * sc;
+        const v2f whole = (scaled + magic) - magic;
+        const v2f rem = scaled - whole;
+        t.q = t.q + whole;
+        t.smax = __builtin_elementwise_max(t.smax, scaled);
+        t.rmax = __builtin_elementwise_max(t.rmax, rem);
+        t.rmin = __builtin_elementwise_min(t.rmin, rem);
     }
 }
 
@@ -202,8 +211,13 @@ __device__ __forceinline__ void seq_tally(SeqTally &t, const float4 &v4, int eb)
 __device__ __forceinline__ bool seq_settle(const SeqTally &t, float &acc, int eb)
 {
     const uint32_t ab = __float_as_uint(acc);
-    const bool bad = t.bad || eb <= 0 || eb >= 255 || t.q_sum >= (1u << 24);   // zero / denormal / non-finite acc
-    const uint32_t grown = ((ab & 0x7fffffu) | 0x800000u) + wave_sum_u32(t.q_sum);
+    const float lane_total = t.q.x + t.q.y;                // NaN if any square was NaN
+    // a square within a factor 4 of acc (or inf) breaks the 2^23 trick's range; a remainder of
+    // exactly +-1/2 is a tie (the rounding would depend on the running sum's parity)
+    const bool bad = eb < 23 || eb >= 255 || !(lane_total < 16777216.0f) ||
+                     !(fmaxf(t.smax.x, t.smax.y) < 4194304.0f) ||
+                     fmaxf(t.rmax.x, t.rmax.y) == 0.5f || fminf(t.rmin.x, t.rmin.y) == -0.5f;
+    const uint32_t grown = ((ab & 0x7fffffu) | 0x800000u) + wave_sum_u32(bad ? 0u : (uint32_t)lane_total);
     if (__ballot(bad) == 0 && grown < (1u << 24)) {
         acc = __uint_as_float(((uint32_t)eb << 23) | (grown & 0x7fffffu));
         return true;
@@ -215,7 +229,7 @@ __device__ __forceinline__ float seq_sum_group(const float *row, float acc, int 
 {
     const int eb = (int)(__float_as_uint(acc) >> 23);   // acc is a sum of squares: sign 0 (a NaN may set it: eb > 255)
     SeqTally t;
-    seq_tally(t, *(const float4 *)(row + 4 * lane), eb);
+    seq_tally(t, *(const float4 *)(row + 4 * lane), seq_scale(eb));
     if (seq_settle(t, acc, eb)) return acc;
     // one after the other; every lane does the same adds on the same (broadcast) LDS words
 #pragma unroll 1
@@ -241,8 +255,9 @@ __device__ __forceinline__ float seq_sum_block(const float *row, float acc, int 
 {
     const int eb = (int)(__float_as_uint(acc) >> 23);
     SeqTally t;
+    const float scale = seq_scale(eb);
 #pragma unroll
-    for (int g = 0; g < FRAMES; g += kSeqGroup) seq_tally(t, *(const float4 *)(row + g + 4 * lane), eb);
+    for (int g = 0; g < FRAMES; g += kSeqGroup) seq_tally(t, *(const float4 *)(row + g + 4 * lane), scale);
     if (seq_settle(t, acc, eb)) return acc;
 #pragma unroll 1
     for (int g = 0; g < FRAMES; g += kSeqGroup) acc = seq_sum_group(row + g, acc, lane);
@@ -266,7 +281,7 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
     const v4i rx = make_rsrc(xs, a.n * Cx * 4);
     const v4i ry = make_rsrc(ys, a.n * C * 4);
     constexpr int PER = BF / 1024;                         // stereo: rounds of 4 frames per thread (256 threads)
-    v2f xr[PER][4], yr[PER][4];
+    v2f xr[PER][4], yr[PER][4];                            // this thread's frames of the next block
     auto fetch = [&](int f0) {
         if constexpr (STEREO) {
 #pragma unroll
@@ -291,13 +306,13 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
             for (int u = 0; u < PER; ++u) {
                 float4 *dst = (float4 *)(sq + u * (BF / PER) + 4 * tid);
                 dst[0 * BF / 4] = make_float4(xr[u][0].x * xr[u][0].x, xr[u][1].x * xr[u][1].x,
-                                                      xr[u][2].x * xr[u][2].x, xr[u][3].x * xr[u][3].x);
+                                              xr[u][2].x * xr[u][2].x, xr[u][3].x * xr[u][3].x);
                 dst[1 * BF / 4] = make_float4(xr[u][0].y * xr[u][0].y, xr[u][1].y * xr[u][1].y,
-                                                      xr[u][2].y * xr[u][2].y, xr[u][3].y * xr[u][3].y);
+                                              xr[u][2].y * xr[u][2].y, xr[u][3].y * xr[u][3].y);
                 dst[2 * BF / 4] = make_float4(yr[u][0].x * yr[u][0].x, yr[u][1].x * yr[u][1].x,
-                                                      yr[u][2].x * yr[u][2].x, yr[u][3].x * yr[u][3].x);
+                                              yr[u][2].x * yr[u][2].x, yr[u][3].x * yr[u][3].x);
                 dst[3 * BF / 4] = make_float4(yr[u][0].y * yr[u][0].y, yr[u][1].y * yr[u][1].y,
-                                                      yr[u][2].y * yr[u][2].y, yr[u][3].y * yr[u][3].y);
+                                              yr[u][2].y * yr[u][2].y, yr[u][3].y * yr[u][3].y);
             }
         } else {
             for (int e = tid; e < BF * C; e += blockDim.x) {
@@ -316,11 +331,10 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
         __syncthreads();                                   // every wave is done with the previous block
         stage(f0);
         __syncthreads();
-        if (f0 + BF < n) fetch(f0 + BF);
+        if (f0 + BF < n) fetch(f0 + BF);                   // (two blocks in flight measured no faster)
         int slot = 0;
-        for (int ch = wave; ch < chains; ch += waves, ++slot) {
+        for (int ch = wave; ch < chains; ch += waves, ++slot)
             acc[slot] = seq_sum_block<BF>(sq + ch * BF, acc[slot], lane);
-        }
     }
     int slot = 0;
     for (int ch = wave; ch < chains; ch += waves, ++slot)
