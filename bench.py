@@ -82,7 +82,24 @@ def cpu_baseline(budget_s: float) -> dict:
         best = min(best, dt)
         reps += 1
     mean = spent / reps
+    # the "fair CPU" line of SURVEY 8d: the C restatement (bit-identical too), one thread and many,
+    # on a batch of 16 such signals (OpenMP over streams x tiles); ~2 s, reported beside the headline
+    c_port = None
+    try:
+        from oracle import c_oracle
+        offs, idx, w = O.fir_to_taps(fir)
+        xb = np.ascontiguousarray(np.broadcast_to(x, (16,) + x.shape))
+        threads = max(1, min(os.cpu_count() or 1, 64))
+        c_port = {}
+        for label, nthreads, batch in (('threads_1', 1, xb[:2]), (f'threads_{threads}', threads, xb)):
+            c_oracle.convolve(batch, offs, idx, w, threads=nthreads)
+            t = time.perf_counter()
+            c_oracle.convolve(batch, offs, idx, w, threads=nthreads)
+            c_port[label] = round(batch.size / (time.perf_counter() - t) / 1e6, 1)
+    except Exception as exc:                            # the C oracle is optional test infrastructure
+        c_port = {'unavailable': repr(exc)}
     return {'value': round(x.size / mean / 1e6, 3), 'unit': 'Msamples/s', 'cores': 1, 'kind': 'port',
+            'c_restatement_Msamples_s': c_port,
             'sample': f'{reps} x one cfg2 signal ({x.shape[0]}x{x.shape[1]} f32, {TAPS} taps), '
                       f'NumPy restatement of convolve_velvet_noise, mean {mean * 1e3:.1f} ms, '
                       f'min {best * 1e3:.1f} ms, host cores available {os.cpu_count()}',
@@ -236,11 +253,13 @@ def main():
             'config': {'workload': f'cfg2: 48 kHz stereo float32, 10 s, 30 taps / 30 ms velvet FIR (seed 1); '
                                    f'{args.pool} distinct signals resident per GPU, one batched launch per step',
                        'pool_signals_per_gpu': args.pool, 'frames': n, 'channels': CHANNELS,
+                       'Mframes_per_s': round(value / CHANNELS, 1),
                        'arithmetic': args.mode, 'parity_vs_oracle_of_peak': (0.0 if mode == vnd.MODE_EXACT else parity),
                        'launch': table.describe(args.pool, n, CHANNELS, mode), 'exact_mode': exact_info,
                        'sharding': 'independent streams per rank; RCCL broadcast of the tap table only'},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'read_only_frac': round(achieved / 2 / HBM_PEAK_GBS, 4),
                          'kernel_ms': round(kernel_ms, 4), 'device_copy_GBs': round(copy_gbs, 1),
                          'limit': 'board power cap (1400 W; clock falls to ~1.83 GHz under this kernel), DESIGN.md 3.5',
                          'algorithmic_bytes_per_launch': ALGO_BYTES_PER_SAMPLE * samples_per_step},
