@@ -1,26 +1,28 @@
 """Host-side helpers (``dsp``) around the velvet-noise hot path."""
+import functools
+import statistics
 import time
-from functools import wraps
 
 
-def timed(repititions: int = 5):
-    """Decorator: run the function ``repititions`` times and print the mean wall
-    time in milliseconds (same knob name, typo included, as the reference's
-    ``utils/__init__.py:5-26``)."""
+class timed:
+    """``@timed(repititions=5)``: call the wrapped function that many times, report the mean
+    wall time, return the last result.  Same decorator name and (misspelt) knob as the
+    reference's timing helper (``utils/__init__.py:5-26``) so that scripts using it keep working."""
 
-    def decorator(func):
-        @wraps(func)
-        def wrapper(*args, **kwargs):
-            total = 0.0
-            result = None
-            for _ in range(repititions):
-                start = time.perf_counter()
-                result = func(*args, **kwargs)
-                total += time.perf_counter() - start
-            print(f"Function '{func.__name__}' executed {repititions} times averaging "
-                  f'{(total / repititions) * 1000:.4f} milliseconds.')
-            return result
+    def __init__(self, repititions: int = 5):
+        self.repititions = int(repititions)
 
-        return wrapper
+    def _one_run(self, func, args, kwargs):
+        began = time.perf_counter()
+        value = func(*args, **kwargs)
+        return time.perf_counter() - began, value
 
-    return decorator
+    def __call__(self, func):
+        @functools.wraps(func)
+        def measured(*args, **kwargs):
+            runs = [self._one_run(func, args, kwargs) for _ in range(self.repititions)]
+            mean_ms = 1e3 * statistics.fmean(seconds for seconds, _ in runs) if runs else 0.0
+            print(f"Function '{func.__name__}' executed {self.repititions} times "
+                  f'averaging {mean_ms:.4f} milliseconds.')
+            return runs[-1][1] if runs else None
+        return measured
