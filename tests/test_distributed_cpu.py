@@ -73,6 +73,23 @@ def _worker(rank, world, port, out_dir):
         assert y_local.shape == (count, 3000, 2)
         np.save(os.path.join(out_dir, f'y{rank}.npy'), y_local)
         np.save(os.path.join(out_dir, f'span{rank}.npy'), np.array([start, count]))
+
+        # the optimiser's scan sharded over candidates: 5 candidates -> 3 + 2, scores all-gathered
+        from vndecorrelate_amd.distributed import sharded_grid_scan
+        kw = dict(angle_limit=float(np.pi / 4), lambda_mean=5.0, lambda_skew=2.0, lambda_correlation=15.0,
+                  lambda_penalty=1e3)
+        kappas = [0.0, 0.25, 0.5, 0.75, 1.0]
+        sig = np.random.default_rng(3).uniform(-1, 1, (4000, 2)).astype(np.float32)
+
+        def checker_scorer(signal, candidates, **objective):          # the oracle's objective per candidate
+            return np.array([O.symmetry_aware_objective(
+                O.decorrelate(signal.copy(), sample_rate_hz=48000, log_distribution_strength=k,
+                              filtered_channels=(0,), mode='LR', normalize=False, seed=1), **objective)
+                for k in candidates])
+
+        scores = sharded_grid_scan(sig, kappas, scorer=checker_scorer, **kw)
+        assert scores.shape == (5,) and np.array_equal(scores, checker_scorer(sig, kappas, **kw))
+        assert sharded_grid_scan(sig, [], scorer=checker_scorer, **kw).shape == (0,)
         dist.barrier()
     finally:
         dist.destroy_process_group()

@@ -102,3 +102,40 @@ class ShardedDecorrelator:
         back only ITS block; stack blocks in rank order to rebuild the batch."""
         start, count = self.shard(x_all.shape[0])
         return self.convolve_local(x_all[start:start + count], mode)
+
+
+def all_gather_blocks(block: np.ndarray, total: int, group=None, device=None) -> np.ndarray:
+    """Concatenate the ranks' contiguous blocks (as cut by :func:`shard_range`) of a 1-D float64
+    vector of length ``total``: one all_gather of blocks padded to the largest block."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return np.asarray(block, np.float64)
+    world = dist.get_world_size(group)
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) \
+            if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+    widest = shard_range(total, world, 0)[1]
+    mine = torch.zeros(max(widest, 1), dtype=torch.float64, device=device)
+    mine[:len(block)] = torch.as_tensor(np.asarray(block, np.float64), device=device)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    return np.concatenate([parts[r][:shard_range(total, world, r)[1]].cpu().numpy() for r in range(world)])
+
+
+def sharded_grid_scan(input_signal: np.ndarray, decorrelators, *, group=None, device=None,
+                      scorer: Optional[Callable] = None, **objective) -> np.ndarray:
+    """The optimiser's candidate scan (``optimization.grid_scan``) over several GPUs: the
+    candidates are independent, so rank r scores a contiguous block of them on its own GPU
+    (every rank holds the signal) and one all_gather of the score blocks - RCCL with backend
+    ``nccl`` - gives every rank the full score vector.  ``scorer(signal, candidates, **objective)``
+    defaults to the device scan; CPU tests inject a checker."""
+    import torch.distributed as dist
+    decorrelators = list(decorrelators)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    start, count = shard_range(len(decorrelators), world, rank)
+    if scorer is None:
+        from .optimization import grid_scan as scorer
+    mine = scorer(input_signal, decorrelators[start:start + count], **objective) if count else np.zeros(0)
+    return all_gather_blocks(np.asarray(mine, np.float64), len(decorrelators), group=group, device=device)
