@@ -102,6 +102,16 @@ vnd_status vnd_convolve_f32_host(vnd_ctx *ctx, const vnd_taps *taps, const float
                                  float *y, int64_t batch, int64_t n_frames,
                                  int32_t n_channels, int32_t mode);
 
+/* The same call for the operand types NumPy promotes: a float64 signal, or any signal with
+ * a float64 filter (VelvetNoise.FIR, decorrelation.py:454-472) - there the reference forms
+ * each product in float64 and adds it to the float32 output in float64, rounding at every
+ * tap (decorrelation.py:656-658): acc = f32(f64(acc) + f64(x) * f64(w)).  Bit-identical to
+ * that; function-path table given inline (host arrays, float64 weights), host pointers,
+ * x float32 or float64 (x_is_f64), y float32.                                        */
+vnd_status vnd_convolve_promote_host(vnd_ctx *ctx, int32_t num_channels, const int32_t *tap_offsets,
+                                     const int32_t *tap_index, const double *tap_weight, const void *x,
+                                     int32_t x_is_f64, float *y, int64_t batch, int64_t n_frames);
+
 /* ---- the full stage: convolution + decorrelate epilogue on the device ----------
  * Replaces VelvetNoise.decorrelate after its float32 cast / mono->stereo
  * (decorrelation.py:431-440): convolve, then in place on y

@@ -59,14 +59,33 @@ def test_function_path_exact(vnd, golden, name):
             assert hashlib.sha256(y[b].tobytes()).hexdigest() == want
         return
     y = vnd.convolve_velvet_noise(x, fir, mode=vnd.MODE_EXACT)
-    # bit-identical whenever NumPy itself computes in float32: float32 input, and the integer types it
-    # promotes with a float32 weight to float32 (int16 audio); float64 input is promoted tap by tap upstream
-    float32_in = np.result_type(x.dtype, np.float32) == np.float32 and fir.dtype == np.float32
-    golden.expect(name, y, exact=float32_in, rtol_peak=TOL_PEAK)
-    if not float32_in and x.size:
-        # what the ABI computes is exact on the float32-rounded operands
-        offs, idx, w = O.fir_to_taps(fir.astype(np.float32))
-        assert np.array_equal(y, c_oracle.convolve(x.astype(np.float32), offs, idx, w))
+    # bit-identical for every operand type: float32 (and the integer types NumPy promotes with a float32
+    # weight to float32, e.g. int16 audio) through the float32 kernels, float64 signals or filters through
+    # the promoting kernel, which rounds to float32 at every tap as NumPy's  out += x * value  does
+    golden.expect(name, y, exact=True)
+
+
+def test_promoting_path_more_types(vnd, golden):
+    """int32 / int64 signals are multiplied in float64 by NumPy too; batched == loop; a float64 filter on a
+    float32 signal; and outside exact mode the float32 kernels stay within 1e-6 of peak."""
+    fir32 = golden.fir('g48k_k30')
+    fir64 = fir32.astype(np.float64) * 1.0000001
+    rng = np.random.default_rng(8)
+    cases = [(rng.integers(-2**20, 2**20, (5000, 2)).astype(np.int32), fir32),
+             (rng.integers(-2**40, 2**40, (3000, 2)), fir32),
+             (rng.uniform(-1, 1, (7001, 2)), fir32),
+             (rng.uniform(-1, 1, (7001, 2)).astype(np.float32), fir64),
+             (rng.uniform(-1, 1, (7001, 2)), fir64)]
+    for x, fir in cases:
+        want = O.convolve_velvet_noise(x, fir)
+        got = vnd.convolve_velvet_noise(x, fir)
+        assert got.dtype == np.float32 and np.array_equal(got, want), (x.dtype, fir.dtype)
+        fast = vnd.convolve_velvet_noise(x, fir, mode=vnd.MODE_FAST)
+        assert np.max(np.abs(fast.astype(np.float64) - want)) <= 2e-6 * np.max(np.abs(want)), (x.dtype, fir.dtype)
+    xb = rng.uniform(-1, 1, (3, 4001, 2))
+    yb = vnd.convolve_velvet_noise_batched(xb, fir32)
+    for b in range(3):
+        assert np.array_equal(yb[b], O.convolve_velvet_noise(xb[b], fir32))
 
 
 @pytest.mark.parametrize('mode', ['fma', 'fast'])

@@ -93,6 +93,9 @@ SIGNATURES = {
     'vnd_haas_f64_host': (ctypes.c_int, [ctypes.c_void_p, _c_f32p, ctypes.POINTER(ctypes.c_double), ctypes.c_int64,
                                          ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_double]),
+    'vnd_convolve_promote_host': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, _c_i32p, _c_i32p,
+                                                 ctypes.POINTER(ctypes.c_double), ctypes.c_void_p, ctypes.c_int32,
+                                                 _c_f32p, ctypes.c_int64, ctypes.c_int64]),
     'vnd_time_convolve_f32_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                  ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
@@ -385,6 +388,25 @@ def decorrelate_workspace_bytes(batch: int, n: int, channels: int) -> int:
     _check(load_library().vnd_decorrelate_workspace_bytes(batch, n, channels, ctypes.byref(need)),
            'vnd_decorrelate_workspace_bytes')
     return need.value
+
+
+def convolve_promote_host(ctx: 'Context', x: np.ndarray, tap_offsets: np.ndarray, tap_index: np.ndarray,
+                          tap_weight: np.ndarray) -> np.ndarray:
+    """The function path on operands NumPy promotes to float64 (``vnd_convolve_promote_host``):
+    x float32 or float64 ``(n, C)`` / ``(batch, n, C)``, float64 weights; float32 result."""
+    if x.dtype not in (np.float32, np.float64) or not x.flags.c_contiguous or x.ndim not in (2, 3):
+        raise ValueError('convolve_promote_host wants a C-contiguous float32/float64 (n, C) or (batch, n, C) array')
+    batch = 1 if x.ndim == 2 else x.shape[0]
+    n, c = x.shape[-2:]
+    offs = np.ascontiguousarray(tap_offsets, np.int32)
+    idx = np.ascontiguousarray(tap_index, np.int32)
+    w = np.ascontiguousarray(tap_weight, np.float64)
+    y = np.empty(x.shape, np.float32)
+    _check(ctx._lib.vnd_convolve_promote_host(ctx.handle, c, _ptr(offs, ctypes.c_int32), _ptr(idx, ctypes.c_int32),
+                                              _ptr(w, ctypes.c_double), ctypes.c_void_p(x.ctypes.data),
+                                              int(x.dtype == np.float64), _ptr(y, ctypes.c_float), batch, n),
+           'vnd_convolve_promote_host')
+    return y
 
 
 def haas_host(ctx: 'Context', x: np.ndarray, *, delay: int, delayed_channel: int, ms_mode: bool, width) -> np.ndarray:

@@ -981,6 +981,51 @@ vnd_status vnd_decorrelate_fanout_f32_host(vnd_ctx *ctx, const vnd_taps *t, cons
                             normalize, eps);
 }
 
+vnd_status vnd_convolve_promote_host(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, const int32_t *tap_index,
+                                     const double *tap_weight, const void *x, int32_t x_is_f64, float *y,
+                                     int64_t batch, int64_t n)
+{
+    if (!ctx) return fail(VND_ERR_INVALID, "null context");
+    if (C <= 0 || batch < 0 || n < 0) return fail(VND_ERR_INVALID, "bad channel, batch or frame count");
+    if (!tap_offsets || tap_offsets[0] != 0) return fail(VND_ERR_INVALID, "bad tap_offsets");
+    for (int c = 0; c < C; ++c)
+        if (tap_offsets[c + 1] < tap_offsets[c]) return fail(VND_ERR_INVALID, "tap_offsets not monotone");
+    const int32_t taps = tap_offsets[C];
+    if (taps > 0 && (!tap_index || !tap_weight)) return fail(VND_ERR_INVALID, "null tap arrays");
+    for (int32_t k = 0; k < taps; ++k)
+        if (tap_index[k] < 0) return fail(VND_ERR_INVALID, "negative tap index at %d", k);
+    const int64_t total = batch * n * C;
+    if (total == 0) return VND_OK;
+    if (!x || !y) return fail(VND_ERR_INVALID, "null signal pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t xb = (size_t)total * (x_is_f64 ? 8 : 4), yb = (size_t)total * 4;
+    const size_t wb = (size_t)taps * 8, ob = (size_t)(C + 1) * 4, ib = (size_t)taps * 4;
+    vnd_status st = ensure_work(ctx, up16(xb) + up16(yb) + up16(wb) + up16(ob) + up16(ib) + 16);
+    if (st != VND_OK) return st;
+    char *p = ctx->work;                                   // hipMalloc'ed: 256-byte aligned
+    PArgs a{};
+    a.x = p;
+    a.y = (float *)(p + up16(xb));
+    a.w = (const double *)((const char *)a.y + up16(yb));
+    a.tap_off = (const int32_t *)((const char *)a.w + up16(wb));
+    a.idx = (const int32_t *)((const char *)a.tap_off + up16(ob));
+    a.n = n; a.total = total; a.C = C; a.x_is_f64 = x_is_f64 ? 1 : 0;
+    HIP_TRY(hipMemcpyAsync(p, x, xb, hipMemcpyHostToDevice, ctx->stream));
+    if (taps) {
+        HIP_TRY(hipMemcpyAsync((void *)a.w, tap_weight, (size_t)taps * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync((void *)a.idx, tap_index, (size_t)taps * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(hipMemcpyAsync((void *)a.tap_off, tap_offsets, (size_t)(C + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    const int64_t blocks = std::min<int64_t>((total + kDirectThreads - 1) / kDirectThreads, (int64_t)cus * 32);
+    hipLaunchKernelGGL(conv_promote_kernel, dim3((unsigned)blocks), dim3(kDirectThreads), 0, ctx->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(y, a.y, yb, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return VND_OK;
+}
+
 // ------------------------------------------------------------------------------
 // candidate scan
 // ------------------------------------------------------------------------------

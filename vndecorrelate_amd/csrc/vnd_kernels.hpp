@@ -910,4 +910,44 @@ __global__ __launch_bounds__(kDirectThreads) void conv_direct_kernel(const KArgs
     }
 }
 
+// =====================================================================================
+// Promoting form of the function path.  NumPy multiplies a float64 signal (or any signal by
+// a float64 filter such as VelvetNoise.FIR) in float64 and adds that product to the float32
+// output in float64, rounding to float32 at every tap
+// (decorrelation.py:656-658: out[:N-i] += x[i:] * value):
+//     acc = f32( f64(acc) + f64(x) * f64(w) )
+// A plain gather, one lane per output sample, table order: this path exists for parity with
+// that corner of the reference, not for speed.
+// =====================================================================================
+struct PArgs {
+    const void *__restrict__ x;        // [batch][n][C] float32 or float64
+    float *__restrict__ y;
+    const int32_t *__restrict__ tap_off;
+    const int32_t *__restrict__ idx;
+    const double *__restrict__ w;
+    int64_t n, total;                  // total = batch * n * C
+    int32_t C, x_is_f64;
+};
+
+__global__ __launch_bounds__(kDirectThreads) void conv_promote_kernel(const PArgs a)
+{
+    const int64_t per_stream = a.n * a.C;
+    for (int64_t e = (int64_t)blockIdx.x * kDirectThreads + threadIdx.x; e < a.total;
+         e += (int64_t)gridDim.x * kDirectThreads) {
+        const int64_t b = e / per_stream, r = e - b * per_stream;
+        const int64_t n0 = r / a.C;
+        const int ch = (int)(r - n0 * a.C);
+        float acc = 0.0f;
+        for (int k = a.tap_off[ch]; k < a.tap_off[ch + 1]; ++k) {
+            const int64_t m = n0 + a.idx[k];
+            if (m >= a.n) continue;                                   // the slice does not reach this output
+            const int64_t at = b * per_stream + m * a.C + ch;
+            const double xv = a.x_is_f64 ? ((const double *)a.x)[at] : (double)((const float *)a.x)[at];
+            const double p = xv * a.w[k];
+            acc = (float)((double)acc + p);
+        }
+        a.y[e] = acc;
+    }
+}
+
 }  // namespace vnd

@@ -223,6 +223,25 @@ def _fir_key(fir: np.ndarray, channels: int):
             _native.default_context().device)
 
 
+def _promoted_convolve(x: NDArray, fir: NDArray, num_channels: int, mode: int) -> Optional[NDArray]:
+    """The operand types NumPy multiplies in float64 (a float64 or int32/int64 signal, or any
+    signal with a float64 filter such as ``VelvetNoise.FIR``): in the exact mode they take the
+    promoting kernel, which rounds to float32 at every tap exactly as ``out += x * value`` does
+    (decorrelation.py:656-658).  None when the float32 kernels apply."""
+    if mode != MODE_EXACT or np.result_type(x.dtype, fir.dtype) != np.float64 or x.size == 0:
+        return None
+    offsets = np.zeros(num_channels + 1, np.int32)
+    idx, weights = [], []
+    for c in range(num_channels):
+        nz = np.flatnonzero(fir[:, c] != 0.0)
+        idx.append(nz.astype(np.int32))
+        weights.append(fir[nz, c].astype(np.float64))
+        offsets[c + 1] = offsets[c] + len(nz)
+    xin = x if x.dtype in (np.float32, np.float64) else x.astype(np.float64)
+    return _native.convolve_promote_host(_native.default_context(), np.ascontiguousarray(xin), offsets,
+                                         np.concatenate(idx), np.concatenate(weights))
+
+
 def convolve_velvet_noise(input_signal: NDArray, velvet_noise_filters: NDArray, *,
                           mode: Optional[int] = None) -> NDArray:
     """Stateless sparse convolution ``y[n,c] = sum_k w[c,k] * x[n + i[c,k], c]``.
@@ -245,12 +264,17 @@ def convolve_velvet_noise(input_signal: NDArray, velvet_noise_filters: NDArray, 
     num_channels = input_signal.shape[1]
     if num_channels > 1:
         check_equal_length(input_signal, fir, dim=1)
+    mode = _default_mode if mode is None else mode
+    if num_channels:
+        promoted = _promoted_convolve(np.asarray(input_signal), fir, num_channels, mode)
+        if promoted is not None:
+            return promoted
     x = np.ascontiguousarray(input_signal, dtype=np.float32)
     if x.shape[0] == 0 or num_channels == 0:
         return np.zeros(x.shape, dtype=np.float32)
     table = _fir_tables.get(_fir_key(fir, num_channels),
                             lambda: function_path_arrays(fir, num_channels))
-    return table.convolve_host(x, _default_mode if mode is None else mode)
+    return table.convolve_host(x, mode)
 
 
 def convolve_velvet_noise_batched(input_signals: NDArray, velvet_noise_filters: NDArray, *,
@@ -266,12 +290,17 @@ def convolve_velvet_noise_batched(input_signals: NDArray, velvet_noise_filters: 
     if num_channels > 1 and fir.shape[1] != num_channels:
         raise ValueError('Input length mismatch: Expected signals of equal length, but got lengths '
                          f'{num_channels} and {fir.shape[1]} for dimension 1.')
+    mode = _default_mode if mode is None else mode
+    if num_channels:
+        promoted = _promoted_convolve(np.asarray(input_signals), fir, num_channels, mode)
+        if promoted is not None:
+            return promoted
     x = np.ascontiguousarray(input_signals, dtype=np.float32)
     if x.size == 0:
         return np.zeros(x.shape, dtype=np.float32)
     table = _fir_tables.get(_fir_key(fir, num_channels),
                             lambda: function_path_arrays(fir, num_channels))
-    return table.convolve_host(x, _default_mode if mode is None else mode)
+    return table.convolve_host(x, mode)
 
 
 def convolve_velvet_noise_bank(input_signal: NDArray, filter_bank: Sequence[NDArray], *,
