@@ -555,3 +555,20 @@ def test_exact_rms_sums_are_numpys(vnd, name, x):
     with np.errstate(all='ignore'):
         rms_normalize(x, ref)
     assert np.array_equal(yd.cpu().numpy(), ref, equal_nan=True), name
+
+
+def test_fortran_ordered_signal_keeps_numpys_sum_order(vnd, golden):
+    """NumPy sums a Fortran-ordered (n, 2) signal pairwise per column, not row by row: the default
+    policy must then leave the normaliser to NumPy - the result equals the host-epilogue stage."""
+    x = np.asfortranarray(make_input(dict(seed=61, shape=[50000, 2])))
+    assert not x.flags.c_contiguous
+    vn = vnd.VelvetNoise(sample_rate_hz=48000, seed=1)
+    got = vn.decorrelate(x)
+    vnd.set_device_epilogue(False)
+    try:
+        want = vn.decorrelate(x)
+    finally:
+        vnd.set_device_epilogue(None)
+    assert np.array_equal(got, want)
+    # and it genuinely differs from the C-ordered sum order
+    assert not np.array_equal(got, vn.decorrelate(np.ascontiguousarray(x)))

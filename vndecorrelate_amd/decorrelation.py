@@ -554,9 +554,9 @@ class VelvetNoise(Decorrelator):
         return table.convolve_host(x, _default_mode)
 
     def decorrelate(self, input_signal: NDArray) -> NDArray:
-        """Full stage (decorrelation.py:417-442): float32 cast, mono->stereo,
-        GPU convolution, then the host epilogue - side-channel encode (MS mode),
-        width, normaliser."""
+        """Full stage (decorrelation.py:417-442): float32 cast, mono->stereo, GPU convolution,
+        then the epilogue - side-channel encode (MS mode), width, normaliser - on the device
+        where that is faithful to the reference (see ``set_device_epilogue``), else in NumPy."""
         input_signal = to_float32(input_signal)
         mono = None
         if input_signal.ndim == 1:
@@ -564,7 +564,11 @@ class VelvetNoise(Decorrelator):
             if self.num_outs == 2 and input_signal.shape[0] > 0:
                 mono = np.ascontiguousarray(input_signal, dtype=np.float32)[:, None]
             input_signal = mono_to_stereo(input_signal)
-        if _use_device_epilogue(self.num_outs, self.normalizer is not None) and \
+        # NumPy's sum order follows the memory layout (a Fortran-ordered signal is summed pairwise,
+        # column by column): the device repeats the C-contiguous order only, so by default other
+        # layouts keep the host epilogue, which sees the caller's array as the reference does
+        layout_ok = _device_epilogue is not None or input_signal.flags.c_contiguous or self.normalizer is None
+        if layout_ok and _use_device_epilogue(self.num_outs, self.normalizer is not None) and \
                 self._device_epilogue_applies(input_signal):
             return self._decorrelate_on_device(input_signal if mono is None else mono)
         if mono is not None:
