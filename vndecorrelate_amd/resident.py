@@ -88,6 +88,9 @@ def run(stages: Sequence, input_signal: np.ndarray) -> np.ndarray:
     device = torch.device('cuda', _native.default_context().device)
     host = np.asarray(input_signal)
     buf = None                                             # the signal lives in exactly one of host / buf
+    # NumPy's sums follow the memory layout; the device repeats the C-contiguous order only, so a
+    # normalising first stage on, say, a Fortran-ordered signal stays with NumPy (as in decorrelate)
+    odd_layout = host.ndim == 2 and not host.flags.c_contiguous
 
     def to_device():
         nonlocal buf, host
@@ -107,7 +110,8 @@ def run(stages: Sequence, input_signal: np.ndarray) -> np.ndarray:
     for stage in stages:
         out = None
         if isinstance(stage, dec.VelvetNoise):
-            out = _velvet_on_device(stage, to_device(), torch, dec)
+            if not (odd_layout and stage.normalizer is not None):
+                out = _velvet_on_device(stage, to_device(), torch, dec)
         elif isinstance(stage, dec.HaasEffect):
             out = _haas_on_device(stage, to_device(), torch)
         if out is not None:
@@ -115,4 +119,5 @@ def run(stages: Sequence, input_signal: np.ndarray) -> np.ndarray:
         else:
             host = stage(to_host())
             buf = None
+        odd_layout = False                                 # every stage returns a C-ordered array
     return to_host()
