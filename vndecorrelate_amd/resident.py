@@ -116,8 +116,9 @@ def run(stages: Sequence, input_signal: np.ndarray) -> np.ndarray:
             out = _haas_on_device(stage, to_device(), torch)
         if out is not None:
             buf = out
+            odd_layout = False                             # device stages produce C-ordered arrays
         else:
-            host = stage(to_host())
+            host = np.asarray(stage(to_host()))
             buf = None
-        odd_layout = False                                 # every stage returns a C-ordered array
+            odd_layout = host.ndim == 2 and not host.flags.c_contiguous
     return to_host()
