@@ -359,6 +359,8 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
     a.seg_end = t->d_seg_end; a.seg_gain = t->d_seg_gain;
     a.chan_flags = t->has_flags ? t->d_flags : nullptr;
     a.n = n; a.C = C; a.Cx = Cx; a.apply_gain = t->apply_gain;
+    // an output beyond what the L2 + Infinity Cache could hand to a consumer is streamed past them
+    a.stream_out = (batch * n * C * (int64_t)sizeof(float) >= ((int64_t)64 << 20)) ? 1 : 0;
     a.nblocks = p.nblocks;
     if (p.direct) {
         a.tiles = (int32_t)batch; a.groups = 1; a.W = 0;

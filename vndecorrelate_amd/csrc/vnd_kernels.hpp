@@ -68,6 +68,7 @@ struct KArgs {
     int32_t tiles;             // tiles per stream
     int32_t W;                 // floats per LDS plane (tile + halo, even)
     int32_t apply_gain;
+    int32_t stream_out;        // 1: non-temporal stores (large outputs)
     uint32_t nblocks;
     // fused decorrelate epilogue (fast kernel, EPI instantiation; vnd_epilogue.hpp has the two-pass form)
     double *__restrict__ epi_partials;      // [batch][tiles][2*C]: sum x_c^2, then sum y_c^2, per tile
@@ -206,47 +207,47 @@ __device__ __forceinline__ void load_pair(v4i rsrc, int q, int strideG, int C, f
 }
 
 // out pair -> interleaved frames;  v[c] = frame 2q, v[CG + c] = frame 2q+1
-template <int CG, int SHAPE>
+template <int CG, int SHAPE, int AUX>
 __device__ __forceinline__ void store_pair(v4i rdst, int q, int strideG, int C, const float (&v)[2 * CG])
 {
     if constexpr (SHAPE == kPair) {
         const int off = q * (8 * CG);
         if constexpr (CG == 1) {
             v2f t; t.x = v[0]; t.y = v[1];
-            buf_store2(t, rdst, off, 0, kStoreAux);
+            buf_store2(t, rdst, off, 0, AUX);
         } else if constexpr (CG == 2) {
             v4f t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
-            buf_store4(t, rdst, off, 0, kStoreAux);
+            buf_store4(t, rdst, off, 0, AUX);
         } else {
             v4f t, u;
             t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
             u.x = v[4]; u.y = v[5]; u.z = v[6]; u.w = v[7];
-            buf_store4(t, rdst, off, 0, kStoreAux);
-            buf_store4(u, rdst, off + 16, 0, kStoreAux);
+            buf_store4(t, rdst, off, 0, AUX);
+            buf_store4(u, rdst, off + 16, 0, AUX);
         }
     } else if constexpr (SHAPE == kFrame) {
         const int off0 = (2 * q) * strideG * (4 * CG);
         const int off1 = (2 * q + 1) * strideG * (4 * CG);
         if constexpr (CG == 1) {
-            buf_store1(v[0], rdst, off0, 0, kStoreAux);
-            buf_store1(v[1], rdst, off1, 0, kStoreAux);
+            buf_store1(v[0], rdst, off0, 0, AUX);
+            buf_store1(v[1], rdst, off1, 0, AUX);
         } else if constexpr (CG == 2) {
             v2f t, u; t.x = v[0]; t.y = v[1]; u.x = v[2]; u.y = v[3];
-            buf_store2(t, rdst, off0, 0, kStoreAux);
-            buf_store2(u, rdst, off1, 0, kStoreAux);
+            buf_store2(t, rdst, off0, 0, AUX);
+            buf_store2(u, rdst, off1, 0, AUX);
         } else {
             v4f t, u;
             t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
             u.x = v[4]; u.y = v[5]; u.z = v[6]; u.w = v[7];
-            buf_store4(t, rdst, off0, 0, kStoreAux);
-            buf_store4(u, rdst, off1, 0, kStoreAux);
+            buf_store4(t, rdst, off0, 0, AUX);
+            buf_store4(u, rdst, off1, 0, AUX);
         }
     } else {
         const int off0 = (2 * q) * C * 4;
 #pragma unroll
         for (int c = 0; c < CG; ++c) {
-            buf_store1(v[c], rdst, off0 + 4 * c, 0, kStoreAux);
-            buf_store1(v[CG + c], rdst, off0 + C * 4 + 4 * c, 0, kStoreAux);
+            buf_store1(v[c], rdst, off0 + 4 * c, 0, AUX);
+            buf_store1(v[CG + c], rdst, off0 + C * 4 + 4 * c, 0, AUX);
         }
     }
 }
@@ -301,13 +302,24 @@ __device__ __forceinline__ void stage_window(float *plane, const float *src, int
 
 // One (frame pair, CG channels) result per lane and j: v[c] = frame 2q, v[CG+c] = frame 2q+1.
 // Range-checked buffer stores: frames past the end of the stream are dropped.
+// AUX = 2 marks the stores non-temporal: a large output is not read again before it has left
+// the caches, and streaming it past them measured +0.5...2 % on three boxes (it is a little less
+// energy per byte, and the kernel runs on the power cap).
+template <int CG, int AUX>
+__device__ __forceinline__ void store_result_aux(v4i rdst, int shape, int q, int strideG, int C,
+                                                 const float (&v)[2 * CG])
+{
+    if (shape == kPair)       store_pair<CG, kPair, AUX>(rdst, q, strideG, C, v);
+    else if (shape == kFrame) store_pair<CG, kFrame, AUX>(rdst, q, strideG, C, v);
+    else                      store_pair<CG, kDword, AUX>(rdst, q, strideG, C, v);
+}
+
 template <int CG>
-__device__ __forceinline__ void store_result(v4i rdst, int shape, int q, int strideG, int C,
+__device__ __forceinline__ void store_result(v4i rdst, int shape, int stream_out, int q, int strideG, int C,
                                              const float (&v)[2 * CG])
 {
-    if (shape == kPair)       store_pair<CG, kPair>(rdst, q, strideG, C, v);
-    else if (shape == kFrame) store_pair<CG, kFrame>(rdst, q, strideG, C, v);
-    else                      store_pair<CG, kDword>(rdst, q, strideG, C, v);
+    if (stream_out) store_result_aux<CG, 2>(rdst, shape, q, strideG, C, v);
+    else            store_result_aux<CG, kStoreAux>(rdst, shape, q, strideG, C, v);
 }
 
 // ---- LDS reads ---------------------------------------------------------------------
@@ -679,7 +691,7 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
                 sum_y[c] += v[c] * v[c] + v[CG + c] * v[CG + c];
             }
         }
-        store_result<CG>(rdst, shape, q, strideG, C, v);
+        store_result<CG>(rdst, shape, a.stream_out, q, strideG, C, v);
     }
     if constexpr (EPI) {
         if (a.epi_normalize) {
@@ -848,7 +860,7 @@ __global__ __launch_bounds__(NT) void conv_ordered_kernel(const KArgs a)
             const float xin[4] = {x0.x, x1.x, x0.y, x1.y};
             epi_pointwise(a, v, xin);
         }
-        store_result<CG>(rdst, shape, tid + NT * j, strideG, C, v);
+        store_result<CG>(rdst, shape, a.stream_out, tid + NT * j, strideG, C, v);
     }
 }
 
