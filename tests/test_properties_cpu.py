@@ -8,7 +8,7 @@ from oracle import vnd_oracle as O
 from vndecorrelate_amd.distributed import shard_range
 from vndecorrelate_amd.taps import TapArrays, class_path_arrays, function_path_arrays
 
-SET = settings(max_examples=40, deadline=None)
+SET = settings(max_examples=40, deadline=None, derandomize=True, database=None)
 
 
 @st.composite
