@@ -247,6 +247,36 @@ def test_long_fir_falls_back(vnd):
     assert np.array_equal(y, c_oracle.convolve(x, offs, idx, w, threads=4))
 
 
+@pytest.mark.parametrize('seconds', [0.1, 0.25, 0.4, 0.7])
+def test_mid_length_firs_stay_in_lds(vnd, seconds):
+    """FIRs of 0.1-0.7 s need windows of 40-140 KB: the tile shrinks, channels split, and the kernels opt
+    in to more than 64 KB of LDS - every mode, the decorrelate stage included."""
+    from vndecorrelate_amd import _native
+    from vndecorrelate_amd.taps import function_path_arrays
+    fir = vnd.generate_velvet_noise(duration_seconds=seconds, num_impulses=40, sample_rate_hz=48000, seed=6)
+    x = make_input(dict(seed=9, shape=[2, 90001, 2]))
+    arr = function_path_arrays(fir)
+    table = _native.TapTable.create(_native.default_context(), arr.tap_offsets, arr.tap_index, arr.tap_weight)
+    assert 'direct' not in table.describe(2, 90001, 2, vnd.MODE_FAST)
+    want = c_oracle.convolve(x, arr.tap_offsets, arr.tap_index, arr.tap_weight, threads=4)
+    assert np.array_equal(table.convolve_host(x, vnd.MODE_EXACT), want)
+    peak = np.max(np.abs(want))
+    for mode in (vnd.MODE_FMA, vnd.MODE_FAST):
+        assert np.max(np.abs(table.convolve_host(x, mode).astype(np.float64) - want)) <= 1e-6 * peak, mode
+    from vndecorrelate_amd.utils import dsp
+    for mode in (vnd.MODE_EXACT, vnd.MODE_FAST):
+        got = table.decorrelate_host(x, mode, ms_encode=True, width=0.4, normalize=_native.NORMALIZE_RMS_REFERENCE_ORDER)
+        for b in range(2):
+            ref = want[b].copy()
+            dsp.encode_signal_to_side_channel(x[b], ref)
+            dsp.apply_stereo_width(ref, 0.4)
+            dsp.rms_normalize(x[b], ref)
+            if mode == vnd.MODE_EXACT:
+                assert np.array_equal(got[b], ref), (seconds, b)
+            else:
+                assert np.max(np.abs(got[b] - ref)) <= 3e-6 * np.max(np.abs(ref)), (seconds, b)
+
+
 # ---- size-independent properties at BASELINE sizes ----------------------------------
 def test_linearity_and_shift_cfg2(vnd, golden):
     fir = golden.fir('g48k_k30')
@@ -524,6 +554,8 @@ def _adversarial_signals():
     yield 'audio_like', (np.sin(np.arange(200000)[:, None] * np.array([0.01, 0.013])) * 0.2).astype(np.float32)
     yield 'three_channels', rng.uniform(-1, 1, (n, 3)).astype(np.float32)
     yield 'eight_channels_int', rng.integers(-500, 500, (n, 8)).astype(np.float32)
+    yield 'sixteen_channels', rng.uniform(-1, 1, (20001, 16)).astype(np.float32)
+    yield 'thirty_two_channels_int', rng.integers(-300, 300, (9001, 32)).astype(np.float32)
     yield 'shorter_than_a_group', rng.uniform(-1, 1, (100, 2)).astype(np.float32)
     yield 'one_frame', np.array([[0.5, -0.25]], np.float32)
 
@@ -572,3 +604,19 @@ def test_fortran_ordered_signal_keeps_numpys_sum_order(vnd, golden):
     assert np.array_equal(got, want)
     # and it genuinely differs from the C-ordered sum order
     assert not np.array_equal(got, vn.decorrelate(np.ascontiguousarray(x)))
+
+
+@pytest.mark.parametrize('num_outs', [1, 3, 16, 40])
+def test_default_stage_for_any_channel_count(vnd, num_outs):
+    """LR tables of 1 to 40 channels: the default policy (device sums for 2-32 channels, NumPy's otherwise)
+    gives the host-epilogue result bit for bit."""
+    x = make_input(dict(seed=70 + num_outs, shape=[12001, num_outs]))
+    vn = vnd.VelvetNoise(sample_rate_hz=48000, seed=1, num_outs=num_outs, filtered_channels=tuple(range(num_outs)),
+                         mode='LR', num_impulses=12)
+    got = vn.decorrelate(x)
+    vnd.set_device_epilogue(False)
+    try:
+        want = vn.decorrelate(x)
+    finally:
+        vnd.set_device_epilogue(None)
+    assert got.shape == (12001, num_outs) and np.array_equal(got, want)

@@ -864,8 +864,11 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
     const Plan p = make_plan(ctx, t, batch, n, C, mode, Cx);
     // normalize == VND_NORMALIZE_RMS_REFERENCE_ORDER: the sums of squares in NumPy's own (sequential
     // float32) order in every mode, so that the scale differs from the reference's only through y
+    // frames per staged block of the sums kernel: as many as the 2C rows of squares leave room for
+    const int seq_frames = C == 2 ? kSeqFramesStereo
+                         : ((size_t)2 * C * kSeqFrames * sizeof(float) <= (size_t)ctx->lds_limit ? kSeqFrames : kSeqFramesWide);
     const bool seq_ok = normalize && C >= 2 && 2 * C <= 64 && n * C * 4 < (int64_t)0x7fffffff &&
-                        (size_t)2 * C * (C == 2 ? kSeqFramesStereo : kSeqFrames) * sizeof(float) <= (size_t)ctx->lds_limit;
+                        (size_t)2 * C * seq_frames * sizeof(float) <= (size_t)ctx->lds_limit;
     const bool want_seq = seq_ok && (mode == VND_MODE_EXACT || normalize == VND_NORMALIZE_RMS_REFERENCE_ORDER);
     const bool fused = any && mode == VND_MODE_FAST && ctx->variant_nofuse == 0 && fast_epi_kernel(p) != nullptr &&
                        (!(ms_encode || use_width) || p.cg == 2) && !(want_seq && !(ms_encode || use_width));
@@ -904,10 +907,11 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
         e.rows = 1;
         e.exact_rms = 1;
         e.normalize = 1;
-        const size_t lds = (size_t)2 * C * (C == 2 ? kSeqFramesStereo : kSeqFrames) * sizeof(float);
+        const size_t lds = (size_t)2 * C * seq_frames * sizeof(float);
         const int waves = C == 2 ? 4 : std::min(2 * C, kSeqMaxWaves);
-        auto k = C != 2 ? epilogue_rms_seq_kernel<false, false>
-                        : (Cx == 1 ? epilogue_rms_seq_kernel<true, true> : epilogue_rms_seq_kernel<true, false>);
+        auto k = C == 2 ? (Cx == 1 ? epilogue_rms_seq_kernel<true, true> : epilogue_rms_seq_kernel<true, false>)
+                        : (seq_frames == kSeqFrames ? epilogue_rms_seq_kernel<false, false, kSeqFrames>
+                                                    : epilogue_rms_seq_kernel<false, false, kSeqFramesWide>);
         if (lds > 65536) HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                       ctx->lds_limit));
         hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(64 * waves), lds, stream, e);

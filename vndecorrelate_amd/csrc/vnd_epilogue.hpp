@@ -160,6 +160,7 @@ __global__ __launch_bounds__(kEpiThreads) void epilogue_reduce_kernel(const EArg
 // a stream in one workgroup that stages blocks of 2048 frames into LDS, next block in flight.
 constexpr int kSeqFrames = 2048;     // frames per staged block (generic channel counts)
 constexpr int kSeqFramesStereo = 2048;   // stereo (4096 measured slower: a block with one tie costs twice as much)
+constexpr int kSeqFramesWide = 256;  // 11 to 32 channels: smaller blocks, so that the 2C rows still fit LDS
 constexpr int kSeqGroup = 256;       // squares a wave settles at once (4 per lane)
 constexpr int kSeqMaxWaves = 16;
 
@@ -267,11 +268,10 @@ __device__ __forceinline__ float seq_sum_block(const float *row, float acc, int 
 // blockDim.x = 64 * W, W = min(2C, 16) waves; wave w owns chains w, w + W, ...
 // STEREO: C == 2, branch-free vector staging (range-checked buffer loads: frames past the end
 // read 0 and add +0, exact); MONO: x has one channel, fanned out.
-template <bool STEREO, bool MONO>
+template <bool STEREO, bool MONO, int BF = (STEREO ? kSeqFramesStereo : kSeqFrames)>
 __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(const EArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float sq[];      // [2C][BF]
-    constexpr int BF = STEREO ? kSeqFramesStereo : kSeqFrames;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, waves = blockDim.x >> 6;
     const int C = STEREO ? 2 : a.C, Cx = a.Cx, chains = 2 * C;
     const int64_t b = blockIdx.x;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
     const float *__restrict__ ys = a.y + b * a.n * C;
     const v4i rx = make_rsrc(xs, a.n * Cx * 4);
     const v4i ry = make_rsrc(ys, a.n * C * 4);
-    constexpr int PER = BF / 1024;                         // stereo: rounds of 4 frames per thread (256 threads)
+    constexpr int PER = STEREO ? BF / 1024 : 1;            // stereo: rounds of 4 frames per thread (256 threads)
     v2f xr[PER][4], yr[PER][4];                            // this thread's frames of the next block
     auto fetch = [&](int f0) {
         if constexpr (STEREO) {

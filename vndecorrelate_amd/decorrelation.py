@@ -86,7 +86,9 @@ def set_device_epilogue(enabled: Optional[bool]) -> None:
 def _use_device_epilogue(num_outs: int, has_normalizer: bool) -> bool:
     if _device_epilogue is not None:
         return _device_epilogue
-    return num_outs >= 2 or not has_normalizer
+    # the device repeats NumPy's row-by-row sums for 2 to 32 channels; one channel is summed pairwise
+    # by NumPy, and wider tables than that are left to it as well
+    return 2 <= num_outs <= 32 or not has_normalizer
 
 
 def _normalize_flag(has_normalizer: bool) -> int:
