@@ -83,12 +83,16 @@ def set_device_epilogue(enabled: Optional[bool]) -> None:
     _device_epilogue = None if enabled is None else bool(enabled)
 
 
-def _use_device_epilogue(num_outs: int, has_normalizer: bool) -> bool:
+def _use_device_epilogue(num_outs: int, has_normalizer: bool, frames: int = 0, c_contiguous: bool = True) -> bool:
+    """The default policy: the device epilogue wherever it repeats what NumPy would do."""
     if _device_epilogue is not None:
         return _device_epilogue
-    # the device repeats NumPy's row-by-row sums for 2 to 32 channels; one channel is summed pairwise
-    # by NumPy, and wider tables than that are left to it as well
-    return 2 <= num_outs <= 32 or not has_normalizer
+    if not has_normalizer:
+        return True                                       # the pointwise steps are always NumPy's
+    # NumPy's row-by-row float32 sums are repeated on the device for 2 to 32 channels of a C-contiguous
+    # signal (a single channel, and other memory layouts, are summed pairwise by NumPy) whose streams
+    # stay below 2 GiB (the sums kernel's 32-bit offsets)
+    return 2 <= num_outs <= 32 and c_contiguous and frames * num_outs * 4 < 2**31
 
 
 def _normalize_flag(has_normalizer: bool) -> int:
@@ -569,9 +573,8 @@ class VelvetNoise(Decorrelator):
         # NumPy's sum order follows the memory layout (a Fortran-ordered signal is summed pairwise,
         # column by column): the device repeats the C-contiguous order only, so by default other
         # layouts keep the host epilogue, which sees the caller's array as the reference does
-        layout_ok = _device_epilogue is not None or input_signal.flags.c_contiguous or self.normalizer is None
-        if layout_ok and _use_device_epilogue(self.num_outs, self.normalizer is not None) and \
-                self._device_epilogue_applies(input_signal):
+        if _use_device_epilogue(self.num_outs, self.normalizer is not None, input_signal.shape[0],
+                                input_signal.flags.c_contiguous) and self._device_epilogue_applies(input_signal):
             return self._decorrelate_on_device(input_signal if mono is None else mono)
         if mono is not None:
             output_signal = self._device_table().convolve_host(mono, _default_mode)
@@ -613,6 +616,10 @@ class VelvetNoise(Decorrelator):
         x = to_float32(np.asarray(input_signals))
         if x.ndim != 3:
             raise ValueError(f'expected (batch, n, channels), got shape {x.shape}')
+        if _device_epilogue is None and not _use_device_epilogue(self.num_outs, self.normalizer is not None,
+                                                                  x.shape[1], True):
+            return np.stack([self.decorrelate(sig[:, 0] if x.shape[-1] == 1 else sig) for sig in x]) \
+                if len(x) else np.zeros(x.shape[:-1] + (self.num_outs,), np.float32)
         if x.shape[-1] == 1 and self.num_outs == 2 and x.shape[1] > 0 and \
                 (self.normalizer is None or self.normalizer is rms_normalize):
             return self._decorrelate_on_device(x)           # mono signals, fanned out on the device

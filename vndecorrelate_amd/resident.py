@@ -110,7 +110,8 @@ def run(stages: Sequence, input_signal: np.ndarray) -> np.ndarray:
     for stage in stages:
         out = None
         if isinstance(stage, dec.VelvetNoise):
-            if not (odd_layout and stage.normalizer is not None):
+            frames = host.shape[0] if buf is None else buf.shape[0]
+            if dec._use_device_epilogue(stage.num_outs, stage.normalizer is not None, frames, not odd_layout):
                 out = _velvet_on_device(stage, to_device(), torch, dec)
         elif isinstance(stage, dec.HaasEffect):
             out = _haas_on_device(stage, to_device(), torch)
