@@ -620,3 +620,20 @@ def test_default_stage_for_any_channel_count(vnd, num_outs):
     finally:
         vnd.set_device_epilogue(None)
     assert got.shape == (12001, num_outs) and np.array_equal(got, want)
+
+
+def test_denormal_range_signal_is_exact(vnd, golden):
+    """Products and sums in the float32 denormal range are kept (no flush to zero), as NumPy keeps them."""
+    fir = golden.fir('g48k_k30')
+    x = (make_input(dict(seed=81, shape=[30011, 2])).astype(np.float64) * 3e-38).astype(np.float32)
+    assert np.any((np.abs(x) < np.finfo(np.float32).tiny) & (x != 0))
+    want = O.convolve_velvet_noise(x, fir)
+    assert np.any((np.abs(want) < np.finfo(np.float32).tiny) & (want != 0))
+    assert np.array_equal(vnd.convolve_velvet_noise(x, fir), want)
+    vn = vnd.VelvetNoise(sample_rate_hz=48000, seed=1, normalizer=None)
+    got = vn.decorrelate(x)
+    vnd.set_device_epilogue(False)
+    try:
+        assert np.array_equal(got, vn.decorrelate(x))
+    finally:
+        vnd.set_device_epilogue(None)
