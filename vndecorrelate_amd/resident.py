@@ -56,7 +56,7 @@ def _velvet_on_device(stage, buf, torch, dec):
     stage._device_table().decorrelate_device(
         x.data_ptr(), y.data_ptr(), 1, n, channels, mode=dec._default_mode, ms_encode=stage.mode == LayoutMode.MS,
         width=stage.width, normalize=dec._normalize_flag(stage.normalizer is not None), workspace_ptr=work.data_ptr(),
-        workspace_bytes=ws_bytes, stream=torch.cuda.current_stream().cuda_stream)
+        workspace_bytes=ws_bytes, stream=torch.cuda.current_stream(x.device).cuda_stream)
     return y
 
 
@@ -77,7 +77,7 @@ def _haas_on_device(stage, buf, torch):
     if n + delay:
         _native.haas_device(_native.default_context(), x.data_ptr(), y.data_ptr(), 1, n, channels, delay=delay,
                             delayed_channel=stage.delayed_channel, ms_mode=stage.mode == LayoutMode.MS,
-                            width=stage.width, stream=torch.cuda.current_stream().cuda_stream)
+                            width=stage.width, stream=torch.cuda.current_stream(x.device).cuda_stream)
     return y
 
 
