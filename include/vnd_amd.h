@@ -50,7 +50,10 @@ typedef enum vnd_mode {
                             the throughput mode; <= 1e-6 of the output peak from the reference */
 } vnd_mode;
 
-typedef struct vnd_ctx vnd_ctx;     /* one per (process, device)                      */
+/* One per (process, device).  Every call runs on the context's device: the *_dev entry points
+ * switch to it for the launch and restore the caller's current device, the *_host ones leave it
+ * current.  Device pointers and streams passed in must belong to that device.            */
+typedef struct vnd_ctx vnd_ctx;
 typedef struct vnd_taps vnd_taps;   /* device-resident tap table, immutable            */
 
 /* ---- library / device ---------------------------------------------------- */

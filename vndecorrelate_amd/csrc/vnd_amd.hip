@@ -689,6 +689,20 @@ static vnd_status ensure_work(vnd_ctx *ctx, size_t bytes)
     return VND_OK;
 }
 
+// The *_dev entry points launch on the context's device whatever the caller's current device is,
+// and leave the caller's current device as they found it.
+struct DeviceScope {
+    int prev = -1;
+    explicit DeviceScope(int dev)
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess) prev = cur;
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+
 static bool overlaps(const float *x, int64_t x_elems, const float *y, int64_t y_elems)
 {
     return (x < y + y_elems) && (y < x + x_elems);
@@ -703,6 +717,7 @@ static vnd_status convolve_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, 
     if (batch == 0 || n == 0) return VND_OK;
     if (!x || !y) return fail(VND_ERR_INVALID, "null signal pointer");
     if (overlaps(x, batch * n * Cx, y, batch * n * C)) return fail(VND_ERR_INVALID, "x and y overlap");
+    DeviceScope on(ctx->device);
     return launch(ctx, t, x, y, batch, n, C, mode, (hipStream_t)stream, nullptr, Cx);
 }
 
@@ -760,6 +775,7 @@ vnd_status vnd_time_convolve_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const floa
     vnd_status st = check_shape(ctx, t, batch, n, C, mode);
     if (st != VND_OK) return st;
     if (!avg_ms || iters <= 0 || n_buffers <= 0) return fail(VND_ERR_INVALID, "bad timing arguments");
+    DeviceScope on(ctx->device);
     hipStream_t stream = (hipStream_t)stream_;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipError_t he = hipEventCreate(&e0);
@@ -849,6 +865,7 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
     if (normalize && (!workspace || workspace_bytes < need))
         return fail(VND_ERR_INVALID, "workspace too small: need %lld bytes", (long long)need);
     if (batch > 65535) return fail(VND_ERR_UNSUPPORTED, "more than 65535 streams per call: split the batch");
+    DeviceScope on(ctx->device);
     hipStream_t stream = (hipStream_t)stream_;
     const bool any = ms_encode || use_width || normalize;
 
@@ -1057,6 +1074,7 @@ vnd_status vnd_polar_moments_f32_dev(vnd_ctx *ctx, const float *y, int64_t n, in
     const int64_t chunks = mom_chunks(n);
     if (chunks > 0x7fffffffLL || n_pairs > 65535 * kMomThreads)
         return fail(VND_ERR_UNSUPPORTED, "scan too large; split it");
+    DeviceScope on(ctx->device);
     hipStream_t stream = (hipStream_t)stream_;
     MArgs a{};
     a.y = y; a.partials = (double *)workspace; a.moments = moments; a.n = n; a.F = n_pairs; a.chunks = (int32_t)chunks;
@@ -1129,6 +1147,7 @@ vnd_status vnd_haas_f64_dev(vnd_ctx *ctx, const float *x, double *y, int64_t bat
     const int64_t total = n + delay;
     if (batch == 0 || total == 0) return VND_OK;
     if (!y || (n > 0 && !x)) return fail(VND_ERR_INVALID, "null signal pointer");
+    DeviceScope on(ctx->device);
     HArgs a{};
     a.x = x; a.y = y; a.n = n; a.Cx = in_channels; a.delay = delay; a.delayed_channel = delayed_channel;
     a.ms = ms_mode ? 1 : 0; a.use_width = use_width ? 1 : 0; a.w_mid = 1.0 - width; a.w_side = width;
