@@ -509,6 +509,7 @@ vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, 
     int32_t max_index = 0;
     for (int32_t k = 0; k < total; ++k) {
         if (tap_index[k] < 0) return fail(VND_ERR_INVALID, "negative tap index at %d", k);
+        if (tap_index[k] > (1 << 30)) return fail(VND_ERR_UNSUPPORTED, "tap index %d at %d is beyond 2^30 frames", tap_index[k], k);
         max_index = std::max(max_index, tap_index[k]);
     }
     const bool has_seg = seg_offsets != nullptr;
