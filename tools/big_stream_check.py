@@ -28,4 +28,8 @@ peak = float(np.max(np.abs(want[:step])))
 print(f'exact: bit-identical over {n} frames; fast: max error {err:.2e} = {err / peak:.2e} of peak')
 assert err <= 1e-6 * peak
 vn = vnd.VelvetNoise(sample_rate_hz=48000, seed=1)
-t = time.perf_counter(); d = vn.decorrelate(x); print(f'decorrelate (default policy) {time.perf_counter() - t:.2f} s, finite: {bool(np.isfinite(d[::1000]).all())}')
+t = time.perf_counter(); d = vn.decorrelate(x); t_dev = time.perf_counter() - t
+vnd.set_device_epilogue(False)
+t = time.perf_counter(); h = vn.decorrelate(x); t_host = time.perf_counter() - t
+print(f'decorrelate: device epilogue {t_dev:.2f} s, NumPy epilogue {t_host:.2f} s, bit-identical: {bool(np.array_equal(d, h))}')
+assert np.array_equal(d, h)

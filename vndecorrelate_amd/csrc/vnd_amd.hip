@@ -885,7 +885,7 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
     // frames per staged block of the sums kernel: as many as the 2C rows of squares leave room for
     const int seq_frames = C == 2 ? kSeqFramesStereo
                          : ((size_t)2 * C * kSeqFrames * sizeof(float) <= (size_t)ctx->lds_limit ? kSeqFrames : kSeqFramesWide);
-    const bool seq_ok = normalize && C >= 2 && 2 * C <= 64 && n * C * 4 < (int64_t)0x7fffffff &&
+    const bool seq_ok = normalize && C >= 2 && 2 * C <= 64 &&
                         (size_t)2 * C * seq_frames * sizeof(float) <= (size_t)ctx->lds_limit;
     const bool want_seq = seq_ok && (mode == VND_MODE_EXACT || normalize == VND_NORMALIZE_RMS_REFERENCE_ORDER);
     const bool fused = any && mode == VND_MODE_FAST && ctx->variant_nofuse == 0 && fast_epi_kernel(p) != nullptr &&

@@ -275,20 +275,21 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, waves = blockDim.x >> 6;
     const int C = STEREO ? 2 : a.C, Cx = a.Cx, chains = 2 * C;
     const int64_t b = blockIdx.x;
-    const int n = (int)a.n;                                // the host keeps 4 n C below 2^31
+    const int64_t n = a.n;
     const float *__restrict__ xs = a.x + b * a.n * Cx;
     const float *__restrict__ ys = a.y + b * a.n * C;
-    const v4i rx = make_rsrc(xs, a.n * Cx * 4);
-    const v4i ry = make_rsrc(ys, a.n * C * 4);
     constexpr int PER = STEREO ? BF / 1024 : 1;            // stereo: rounds of 4 frames per thread (256 threads)
     v2f xr[PER][4], yr[PER][4];                            // this thread's frames of the next block
-    auto fetch = [&](int f0) {
+    // descriptors are re-based at every block (offsets stay small: streams beyond 2 GiB are fine)
+    auto fetch = [&](int64_t f0) {
         if constexpr (STEREO) {
+            const v4i rx = make_rsrc(xs + f0 * Cx, (n - f0) * Cx * 4);
+            const v4i ry = make_rsrc(ys + f0 * 2, (n - f0) * 8);
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int fr = f0 + u * (BF / PER) + 4 * tid + k;
+                    const int fr = u * (BF / PER) + 4 * tid + k;
                     yr[u][k] = buf_load2(ry, fr * 8, 0, 0);
                     if constexpr (MONO) {
                         const float v = buf_load1(rx, fr * 4, 0, 0);
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
             }
         }
     };
-    auto stage = [&](int f0) {
+    auto stage = [&](int64_t f0) {
         if constexpr (STEREO) {
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
@@ -315,19 +316,20 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
                                               yr[u][2].y * yr[u][2].y, yr[u][3].y * yr[u][3].y);
             }
         } else {
+            const v4i rx = make_rsrc(xs + f0 * Cx, (n - f0) * Cx * 4);
+            const v4i ry = make_rsrc(ys + f0 * C, (n - f0) * C * 4);
             for (int e = tid; e < BF * C; e += blockDim.x) {
                 const int f = e / C, c = e - f * C;
-                const int fr = f0 + f;
-                const float xv = buf_load1(rx, (fr * Cx + c % Cx) * 4, 0, 0);
-                const float yv = buf_load1(ry, (fr * C + c) * 4, 0, 0);
-                sq[c * BF + f] = fr < n ? xv * xv : 0.f;     // (fr*Cx+c%Cx may land in range past the last frame)
+                const float xv = buf_load1(rx, (f * Cx + c % Cx) * 4, 0, 0);
+                const float yv = buf_load1(ry, (f * C + c) * 4, 0, 0);
+                sq[c * BF + f] = xv * xv;                    // frames past the end read 0
                 sq[(C + c) * BF + f] = yv * yv;
             }
         }
     };
     float acc[4] = {0.f, 0.f, 0.f, 0.f};                  // chains wave, wave + W, ... (2C <= 64 => at most 4 each)
     fetch(0);
-    for (int f0 = 0; f0 < n; f0 += BF) {
+    for (int64_t f0 = 0; f0 < n; f0 += BF) {
         __syncthreads();                                   // every wave is done with the previous block
         stage(f0);
         __syncthreads();

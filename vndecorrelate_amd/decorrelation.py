@@ -90,9 +90,8 @@ def _use_device_epilogue(num_outs: int, has_normalizer: bool, frames: int = 0, c
     if not has_normalizer:
         return True                                       # the pointwise steps are always NumPy's
     # NumPy's row-by-row float32 sums are repeated on the device for 2 to 32 channels of a C-contiguous
-    # signal (a single channel, and other memory layouts, are summed pairwise by NumPy) whose streams
-    # stay below 2 GiB (the sums kernel's 32-bit offsets)
-    return 2 <= num_outs <= 32 and c_contiguous and frames * num_outs * 4 < 2**31
+    # signal (a single channel, and other memory layouts, are summed pairwise by NumPy)
+    return 2 <= num_outs <= 32 and c_contiguous
 
 
 def _normalize_flag(has_normalizer: bool) -> int:
