@@ -637,3 +637,26 @@ def test_denormal_range_signal_is_exact(vnd, golden):
         assert np.array_equal(got, vn.decorrelate(x))
     finally:
         vnd.set_device_epilogue(None)
+
+
+def test_many_short_streams(vnd, golden):
+    """3000 streams of 777 frames: shorter than a tile, one partial workgroup per stream and channel group;
+    the whole stage (one sums workgroup per stream) equals the loop."""
+    from vndecorrelate_amd.utils import dsp
+    fir = golden.fir('g48k_k30')
+    x = make_input(dict(seed=91, shape=[3000, 777, 2]))
+    offs, idx, w = O.fir_to_taps(fir)
+    want = c_oracle.convolve(x, offs, idx, w, threads=8)
+    assert np.array_equal(vnd.convolve_velvet_noise_batched(x, fir), want)
+    fast = vnd.convolve_velvet_noise_batched(x, fir, mode=vnd.MODE_FAST)
+    assert np.max(np.abs(fast.astype(np.float64) - want)) <= 1e-6 * np.max(np.abs(want))
+    vn = vnd.VelvetNoise(sample_rate_hz=48000, seed=1, width=0.25)
+    got = vn.decorrelate_batched(x)
+    for b in (0, 1, 1499, 2999):
+        assert np.array_equal(got[b], vn.decorrelate(x[b])), b
+    vnd.set_device_epilogue(False)
+    try:
+        for b in (7, 2998):
+            assert np.array_equal(got[b], vn.decorrelate(x[b])), b           # and the NumPy epilogue agrees
+    finally:
+        vnd.set_device_epilogue(None)
