@@ -660,3 +660,13 @@ def test_many_short_streams(vnd, golden):
             assert np.array_equal(got[b], vn.decorrelate(x[b])), b           # and the NumPy epilogue agrees
     finally:
         vnd.set_device_epilogue(None)
+
+
+def test_stage_batches_beyond_the_grid_limit(vnd):
+    """70 000 tiny streams: the host layer splits the batch for the epilogue kernels' 16-bit stream index."""
+    x = make_input(dict(seed=92, shape=[70000, 40, 2]))
+    vn = vnd.VelvetNoise(sample_rate_hz=48000, seed=1, duration_seconds=0.003, num_impulses=8)
+    got = vn.decorrelate_batched(x)
+    assert got.shape == x.shape
+    for b in (0, 32767, 32768, 65535, 65536, 69999):
+        assert np.array_equal(got[b], vn.decorrelate(x[b])), b

@@ -320,6 +320,11 @@ class TapTable:
         """Convolution + decorrelate epilogue on the device; x as in ``convolve_host``.
         ``normalize``: False/True or one of the ``NORMALIZE_*`` values."""
         batch, n, c, y = self._host_shapes(x, 'decorrelate_host')
+        if batch > 32768:                                   # the epilogue kernels index streams in 16 bits
+            for first in range(0, batch, 32768):
+                y[first:first + 32768] = self.decorrelate_host(x[first:first + 32768], mode, ms_encode=ms_encode,
+                                                               width=width, normalize=normalize, eps=eps)
+            return y
         tail = (int(mode), int(bool(ms_encode)), int(width is not None), float(width or 0.0),
                 int(normalize), float(eps))
         if c == self.num_channels:
