@@ -18,7 +18,15 @@
  *    functions take host pointers, copy H2D/D2H around the same kernels and
  *    return after the result is in `y` - the reference's synchronous semantics;
  *  - the caller owns every buffer it passes; handles own device memory;
- *  - a handle is used by one thread at a time; distinct handles are independent.
+ *  - threading: the reference's functions are pure and re-entrant
+ *    (decorrelation.py:630-660), and so are these.  A context owns one stream and
+ *    one set of staging buffers for its "*_host" entry points, which therefore hold
+ *    a per-context mutex from entry to return: concurrent host calls on one
+ *    context are serialised, never interleaved (use one context per thread to
+ *    overlap them).  "*_dev" calls only enqueue on the caller's stream and may run
+ *    concurrently.  A tap table is immutable and may be shared by threads; it must
+ *    outlive every call that uses it and must live on the context's device.
+ *    vnd_set_variant (tuning) is not synchronised.
  */
 #ifndef VND_AMD_H
 #define VND_AMD_H
@@ -78,7 +86,10 @@ vnd_status vnd_ctx_info(const vnd_ctx *ctx, char *name, int32_t len, int32_t *co
  * seg_gain[s] = segment_envelope[s]; weights are -1 (negatives first) / +1;
  * apply_gain = 0 reproduces the skipped multiply of the identity envelope (:411).
  * chan_flags[c] & 1 marks an unfiltered channel that is copied through (:399-400);
- * may be NULL.  All indices must be >= 0.  Arrays are HOST pointers, copied.   */
+ * may be NULL.  All indices must be >= 0 (and <= 2^30).  Arrays are HOST pointers, copied.
+ * A table with a non-finite weight keeps the reference's semantics (a term whose tap
+ * reaches past the end of the stream drops, decorrelation.py:656-658, instead of
+ * becoming 0 * inf) by running the index-testing gather kernel instead of the LDS ones. */
 vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t num_channels,
                            const int32_t *tap_offsets, const int32_t *tap_index,
                            const float *tap_weight,
@@ -128,6 +139,7 @@ vnd_status vnd_convolve_promote_host(vnd_ctx *ctx, int32_t num_channels, const i
  *   otherwise (normalize = VND_NORMALIZE_RMS): exactly rounded float64 sums, fused into the
  *     fast kernel - the fastest form, ~1e-4 relative from NumPy's RMS on long signals.
  * `workspace` is device memory of >= vnd_decorrelate_workspace_bytes().          */
+#define VND_MAX_STREAMS 65535   /* streams (batch) per decorrelate / Haas call: split larger batches */
 #define VND_NORMALIZE_OFF 0
 #define VND_NORMALIZE_RMS 1
 #define VND_NORMALIZE_RMS_REFERENCE_ORDER 2

@@ -19,3 +19,6 @@ build s2 -DVND_STORE_AUX=2
 build l2 -DVND_LOAD_AUX=2
 wait
 ls -la tools/ablate/*.so
+build ablate5 -DVND_ABLATE=5
+wait
+ls -la tools/ablate/*.so

@@ -19,6 +19,7 @@ MODE_EXACT = 0   # acc = f32(acc + f32(x*w)) : bit-identical to the reference's 
 MODE_FMA = 1     # acc = fma(x, w, acc), table order
 MODE_FAST = 2    # fma, free summation order, gains folded into weights: the throughput mode
 MOMENTS = 8      # VND_MOMENTS: doubles per candidate returned by the scan
+MAX_STREAMS_PER_CALL = 65535   # VND_MAX_STREAMS: the decorrelate / Haas kernels index streams by gridDim.y
 NORMALIZE_OFF, NORMALIZE_RMS, NORMALIZE_RMS_REFERENCE_ORDER = 0, 1, 2   # the `normalize` argument of the decorrelate calls
 
 _PKG = pathlib.Path(__file__).resolve().parent
@@ -178,7 +179,10 @@ def _ptr(a: Optional[np.ndarray], ctype):
 
 class Context:
     """One per (process, device): owns the stream and staging buffers of the
-    synchronous host-pointer calls."""
+    synchronous host-pointer calls.  Thread-safe: the library holds a per-context
+    mutex across every ``*_host`` entry point (ctypes drops the GIL during the call),
+    so concurrent callers are serialised, never interleaved; use one Context per
+    thread for host calls that should overlap."""
 
     def __init__(self, device: int = 0):
         lib = load_library()
@@ -320,10 +324,11 @@ class TapTable:
         """Convolution + decorrelate epilogue on the device; x as in ``convolve_host``.
         ``normalize``: False/True or one of the ``NORMALIZE_*`` values."""
         batch, n, c, y = self._host_shapes(x, 'decorrelate_host')
-        if batch > 32768:                                   # the epilogue kernels index streams in 16 bits
-            for first in range(0, batch, 32768):
-                y[first:first + 32768] = self.decorrelate_host(x[first:first + 32768], mode, ms_encode=ms_encode,
-                                                               width=width, normalize=normalize, eps=eps)
+        if batch > MAX_STREAMS_PER_CALL:
+            for first in range(0, batch, MAX_STREAMS_PER_CALL):
+                y[first:first + MAX_STREAMS_PER_CALL] = self.decorrelate_host(
+                    x[first:first + MAX_STREAMS_PER_CALL], mode, ms_encode=ms_encode, width=width,
+                    normalize=normalize, eps=eps)
             return y
         tail = (int(mode), int(bool(ms_encode)), int(width is not None), float(width or 0.0),
                 int(normalize), float(eps))
@@ -458,6 +463,7 @@ def device_count() -> int:
 
 
 _default_ctx: dict = {}
+_default_ctx_lock = threading.Lock()
 
 
 def default_context() -> Context:
@@ -466,7 +472,8 @@ def default_context() -> Context:
     n = device_count()
     if n > 0:
         dev %= n
-    ctx = _default_ctx.get(dev)
-    if ctx is None:
-        ctx = _default_ctx[dev] = Context(dev)
+    with _default_ctx_lock:
+        ctx = _default_ctx.get(dev)
+        if ctx is None:
+            ctx = _default_ctx[dev] = Context(dev)
     return ctx

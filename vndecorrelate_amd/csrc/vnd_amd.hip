@@ -10,6 +10,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cmath>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -54,13 +56,25 @@ struct vnd_ctx {
     size_t work_bytes = 0;
     int variant = -1;
     int variant_nofuse = 0;       // tuning: 1 = keep the decorrelate epilogue as separate passes
+    // One *_host call at a time per context: they share the stream, the staging buffers and the
+    // workspace.  The reference's functions are re-entrant (decorrelation.py:630-660), and ctypes /
+    // cgo / JNI callers run without a global lock, so the library serialises them itself.
+    std::mutex host_mutex;
+    // kernels already opted in to > 64 KiB of dynamic LDS on THIS context's device
+    // (hipFuncSetAttribute applies to the current device's copy of the function)
+    std::mutex raised_mutex;
+    std::vector<const void *> raised;
 };
+
+typedef std::lock_guard<std::mutex> HostLock;
 
 struct vnd_taps {
     vnd_ctx *ctx = nullptr;
     int32_t C = 0, total = 0, total_segs = 0, max_index = 0, apply_gain = 0;
     bool has_seg = false, has_flags = false;
     bool unit_weights = false;    // every weight is +-1: x*w is exact, so fma(x, w, acc) == acc + x*w bit for bit
+    bool nonfinite = false;       // an inf/NaN weight: only the direct kernel drops (rather than zero-fills) the tail terms
+    bool lds_images = true;       // false: indices too large for the LDS kernels' byte offsets (direct kernel only)
     std::vector<int32_t> tap_off, idx, seg_off, seg_end;
     std::vector<float> w, seg_gain;
     std::vector<uint8_t> flags;
@@ -258,7 +272,10 @@ static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int6
     const int v = ctx->variant;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     const bool fast = mode == VND_MODE_FAST;
-    const bool force_direct = v >= 0 && ((v >> 12) & 1);
+    // A term whose tap reaches past the end of the stream DROPS in the reference (decorrelation.py:656-658).
+    // The LDS kernels read such a sample as 0.0f, which is the same thing for a finite weight only
+    // (0 * inf = NaN), so a table with a non-finite weight takes the direct kernel, which tests the index.
+    const bool force_direct = (v >= 0 && ((v >> 12) & 1)) || t->nonfinite || !t->lds_images;
     int cg = (v >= 0 && ((v >> 8) & 15)) ? ((v >> 8) & 15) : 0;
     if (cg == 0) cg = (C % 2 == 0) ? 2 : 1;
     if (C % cg != 0 || (cg != 1 && cg != 2 && cg != 4)) cg = 1;
@@ -331,6 +348,9 @@ static vnd_status check_shape(const vnd_ctx *ctx, const vnd_taps *t, int64_t bat
     if (batch < 0 || n < 0) return fail(VND_ERR_INVALID, "negative batch or frame count");
     if (C != t->C)
         return fail(VND_ERR_INVALID, "signal has %d channels but the tap table has %d", C, t->C);
+    if (t->ctx != ctx && t->ctx->device != ctx->device)
+        return fail(VND_ERR_INVALID, "the tap table lives on device %d, the context on device %d", t->ctx->device,
+                    ctx->device);
     if (Cx != 0 && (Cx < 0 || C % Cx != 0))
         return fail(VND_ERR_INVALID, "%d input channels do not divide the tap table's %d channels", Cx, C);
     if (mode != VND_MODE_EXACT && mode != VND_MODE_FMA && mode != VND_MODE_FAST)
@@ -378,12 +398,12 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
             a.epi_partials = epi->partials; a.epi_ms_encode = epi->ms_encode; a.epi_use_width = epi->use_width;
             a.epi_normalize = epi->normalize; a.epi_w_mid = epi->w_mid; a.epi_w_side = epi->w_side;
         }
-        if (p.lds_bytes > 65536) {           // opt in to > 64 KiB of dynamic LDS, once per kernel
-            static thread_local std::vector<const void *> raised;
-            if (std::find(raised.begin(), raised.end(), (const void *)k) == raised.end()) {
+        if (p.lds_bytes > 65536) {           // opt in to > 64 KiB of dynamic LDS, once per (device, kernel)
+            std::lock_guard<std::mutex> g(ctx->raised_mutex);
+            if (std::find(ctx->raised.begin(), ctx->raised.end(), (const void *)k) == ctx->raised.end()) {
                 HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             ctx->lds_limit));
-                raised.push_back((const void *)k);
+                ctx->raised.push_back((const void *)k);
             }
         }
         hipLaunchKernelGGL(k, dim3(p.nblocks), dim3(p.nt), p.lds_bytes, stream, a);
@@ -535,7 +555,12 @@ vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, 
     if (!t) return fail(VND_ERR_NOMEM, "out of host memory");
     t->ctx = ctx; t->C = C; t->total = total; t->max_index = max_index;
     t->unit_weights = true;
-    for (int32_t k = 0; k < total; ++k) t->unit_weights &= (tap_weight[k] == 1.0f || tap_weight[k] == -1.0f);
+    for (int32_t k = 0; k < total; ++k) {
+        t->unit_weights &= (tap_weight[k] == 1.0f || tap_weight[k] == -1.0f);
+        t->nonfinite |= !std::isfinite(tap_weight[k]);
+    }
+    // the LDS kernels address taps by 32-bit byte offsets; a halo this long never fits LDS anyway
+    t->lds_images = max_index < (1 << 24);
     t->apply_gain = apply_gain ? 1 : 0; t->has_seg = has_seg; t->total_segs = total_segs;
     t->tap_off.assign(tap_offsets, tap_offsets + C + 1);
     if (total) { t->idx.assign(tap_index, tap_index + total); t->w.assign(tap_weight, tap_weight + total); }
@@ -566,7 +591,8 @@ vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, 
         for (int c = 0; c < C; ++c) {
             for (int parity = 0; parity < 2; ++parity) {
                 for (int32_t k = tap_offsets[c]; k < tap_offsets[c + 1]; ++k)
-                    if ((tap_index[k] & 1) == parity) fast.push_back(FastTap{eff[k], (tap_index[k] & ~1) * 4});
+                    if ((tap_index[k] & 1) == parity)
+                        fast.push_back(FastTap{eff[k], t->lds_images ? (tap_index[k] & ~1) * 4 : 0});
                 if (parity == 0) fast_even[c] = (int32_t)fast.size() - fast_off[c];
             }
             fast_off[c + 1] = (int32_t)fast.size();
@@ -576,7 +602,7 @@ vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, 
     if (e == hipSuccess) e = upload(&t->d_taps_fast, fast.data(), fast.size());
     {   // ordered image: table order, weight first (SGPR pair layout), byte offsets, padded
         std::vector<FastTap> ord((size_t)total + 16, FastTap{0.0f, 0});
-        for (int32_t k = 0; k < total; ++k) ord[k] = FastTap{tap_weight[k], tap_index[k] * 4};
+        for (int32_t k = 0; k < total; ++k) ord[k] = FastTap{tap_weight[k], t->lds_images ? tap_index[k] * 4 : 0};
         if (e == hipSuccess) e = upload(&t->d_taps_ord, ord.data(), ord.size());
     }
     if (e == hipSuccess) e = upload(&t->d_fast_off, fast_off.data(), fast_off.size());
@@ -729,6 +755,7 @@ static vnd_status convolve_host(vnd_ctx *ctx, const vnd_taps *t, const float *x,
     if (st != VND_OK) return st;
     if (batch == 0 || n == 0) return VND_OK;
     if (!x || !y) return fail(VND_ERR_INVALID, "null signal pointer");
+    HostLock lock(ctx->host_mutex);
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t in_elems = (size_t)batch * n * Cx, out_elems = (size_t)batch * n * C;
     st = ensure_scratch(ctx, out_elems);
@@ -865,7 +892,7 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
     vnd_decorrelate_workspace_bytes(batch, n, C, &need);
     if (normalize && (!workspace || workspace_bytes < need))
         return fail(VND_ERR_INVALID, "workspace too small: need %lld bytes", (long long)need);
-    if (batch > 65535) return fail(VND_ERR_UNSUPPORTED, "more than 65535 streams per call: split the batch");
+    if (batch > VND_MAX_STREAMS) return fail(VND_ERR_UNSUPPORTED, "more than %d streams per call: split the batch", VND_MAX_STREAMS);
     DeviceScope on(ctx->device);
     hipStream_t stream = (hipStream_t)stream_;
     const bool any = ms_encode || use_width || normalize;
@@ -950,6 +977,7 @@ static vnd_status decorrelate_host(vnd_ctx *ctx, const vnd_taps *t, const float 
     if (st != VND_OK) return st;
     if (batch == 0 || n == 0) return VND_OK;
     if (!x || !y) return fail(VND_ERR_INVALID, "null signal pointer");
+    HostLock lock(ctx->host_mutex);
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t in_elems = (size_t)batch * n * Cx, out_elems = (size_t)batch * n * C;
     st = ensure_scratch(ctx, out_elems);
@@ -1016,11 +1044,14 @@ vnd_status vnd_convolve_promote_host(vnd_ctx *ctx, int32_t C, const int32_t *tap
         if (tap_offsets[c + 1] < tap_offsets[c]) return fail(VND_ERR_INVALID, "tap_offsets not monotone");
     const int32_t taps = tap_offsets[C];
     if (taps > 0 && (!tap_index || !tap_weight)) return fail(VND_ERR_INVALID, "null tap arrays");
-    for (int32_t k = 0; k < taps; ++k)
+    for (int32_t k = 0; k < taps; ++k) {
         if (tap_index[k] < 0) return fail(VND_ERR_INVALID, "negative tap index at %d", k);
+        if (tap_index[k] > (1 << 30)) return fail(VND_ERR_UNSUPPORTED, "tap index %d at %d is beyond 2^30 frames", tap_index[k], k);
+    }
     const int64_t total = batch * n * C;
     if (total == 0) return VND_OK;
     if (!x || !y) return fail(VND_ERR_INVALID, "null signal pointer");
+    HostLock lock(ctx->host_mutex);
     HIP_TRY(hipSetDevice(ctx->device));
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t xb = (size_t)total * (x_is_f64 ? 8 : 4), yb = (size_t)total * 4;
@@ -1102,6 +1133,7 @@ vnd_status vnd_scan_bank_f32_host(vnd_ctx *ctx, const vnd_taps *t, const float *
     if (st != VND_OK) return st;
     if (!moments || (n > 0 && !x)) return fail(VND_ERR_INVALID, "null pointer");
     const int32_t pairs = t->C / 2;
+    HostLock lock(ctx->host_mutex);
     HIP_TRY(hipSetDevice(ctx->device));
     st = ensure_scratch(ctx, (size_t)std::max<int64_t>(n, 1) * t->C);
     if (st != VND_OK) return st;
@@ -1135,7 +1167,7 @@ static vnd_status haas_check(const vnd_ctx *ctx, int64_t batch, int64_t n, int32
         return fail(VND_ERR_INVALID, "HaasEffect takes a mono or stereo signal, got %d channels", in_channels);
     if (delayed_channel != 0 && delayed_channel != 1)
         return fail(VND_ERR_INVALID, "delayed_channel must be 0 or 1, got %d", delayed_channel);
-    if (batch > 65535) return fail(VND_ERR_UNSUPPORTED, "more than 65535 streams per call: split the batch");
+    if (batch > VND_MAX_STREAMS) return fail(VND_ERR_UNSUPPORTED, "more than %d streams per call: split the batch", VND_MAX_STREAMS);
     return VND_OK;
 }
 
@@ -1167,6 +1199,7 @@ vnd_status vnd_haas_f64_host(vnd_ctx *ctx, const float *x, double *y, int64_t ba
     const int64_t total = n + delay;
     if (batch == 0 || total == 0) return VND_OK;
     if (!y || (n > 0 && !x)) return fail(VND_ERR_INVALID, "null signal pointer");
+    HostLock lock(ctx->host_mutex);
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t in_bytes = (size_t)batch * n * in_channels * sizeof(float);
     const size_t out_bytes = (size_t)batch * total * 2 * sizeof(double);

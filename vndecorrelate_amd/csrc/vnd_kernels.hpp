@@ -428,6 +428,11 @@ __device__ __forceinline__ void consume(float2 (&acc)[R], const v2f (&buf)[R], f
     for (int j = 0; j < R; ++j) asm volatile("" ::"v"(buf[j]));
     return;
 #endif
+#if defined(VND_ABLATE) && VND_ABLATE == 5      // timing-only build: packed adds in place of the packed FMAs
+#pragma unroll
+    for (int j = 0; j < R; ++j) { acc[j].x += buf[j].x; acc[j].y += buf[j].y; }
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         acc[j].x = __builtin_fmaf(buf[j].x, w, acc[j].x);

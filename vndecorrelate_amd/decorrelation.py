@@ -12,20 +12,30 @@ reference                    here
 ``generate_velvet_noise``    :func:`generate_velvet_noise`  (host NumPy, O(K))
 ``VelvetNoise``              :class:`VelvetNoise` (``convolve`` on the GPU)
 ``SignalChain``              :class:`SignalChain`
-``HaasEffect``/``WhiteNoise`` NumPy-only chain stages (out of the GPU scope,
-                             SURVEY.md §2 rows 6-7; kept so chains stay drop-in)
+``HaasEffect``               :class:`HaasEffect` (device kernel ``vnd_haas_f64_*`` in a
+                             device-resident chain, NumPy otherwise)
+``WhiteNoise``               NumPy-only chain stage (out of the GPU scope, SURVEY.md §2
+                             row 7; kept so chains stay drop-in)
 ===========================  ==================================================
 
 There is no CPU implementation of the tap sum in this package: without the
 built extension or without a gfx950 device the calls raise ``RuntimeError``.
 
-Deliberate, documented deviations from the reference (DESIGN.md "Parity"):
-non-float32 inputs and float64 FIR weights are rounded to float32 before the
-GPU call (the reference promotes to float64 per tap, then rounds to float32).
+Operand types (DESIGN.md "Parity"): in the exact mode every dtype combination of
+the function path is bit-identical to the reference - float32 and the integer
+types NumPy promotes to float32 through the float32 kernels, float64 / int32 /
+int64 signals and float64 filters through ``vnd_convolve_promote_host``, which
+rounds to float32 at every tap as ``out += x * value`` does.  In the tolerance
+modes those operands are rounded to float32 first.
+
+Threading: the functions are re-entrant like the reference's; calls that share a
+context are serialised inside the library (one stream and one set of staging
+buffers per context).
 """
 from __future__ import annotations
 
 import hashlib
+import threading
 from abc import ABC, abstractmethod
 from collections import OrderedDict
 from dataclasses import dataclass, field
@@ -199,24 +209,29 @@ class _TableCache:
     def __init__(self, capacity: int = 16):
         self.capacity = capacity
         self._items: 'OrderedDict[tuple, _native.TapTable]' = OrderedDict()
+        self._lock = threading.Lock()
 
     def get(self, key, build: Callable[[], TapArrays]) -> _native.TapTable:
-        table = self._items.get(key)
-        if table is not None:
-            self._items.move_to_end(key)
-            return table
+        with self._lock:
+            table = self._items.get(key)
+            if table is not None:
+                self._items.move_to_end(key)
+                return table
         arrays = build()
         table = _native.TapTable.create(_native.default_context(), arrays.tap_offsets,
                                         arrays.tap_index, arrays.tap_weight, **arrays.kwargs())
-        self._items[key] = table
-        while len(self._items) > self.capacity:
-            self._items.popitem(last=False)[1].close()
+        with self._lock:
+            table = self._items.setdefault(key, table)      # another thread may have built it meanwhile
+            self._items.move_to_end(key)
+            # An evicted table is only dropped, never closed here: a thread still inside a call
+            # holds a reference, and the device memory goes when the last one does (TapTable.__del__).
+            while len(self._items) > self.capacity:
+                self._items.popitem(last=False)
         return table
 
     def clear(self):
-        for t in self._items.values():
-            t.close()
-        self._items.clear()
+        with self._lock:
+            self._items.clear()
 
 
 _fir_tables = _TableCache()
