@@ -3,26 +3,33 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], "cfg2"): synthetic 48 kHz stereo float32,
-10 s per signal, 30 taps over 30 ms (seed 1, the reference generator's
-defaults).  One cfg2 signal is only 3.84 MB, which lives in the 256 MiB
-Infinity Cache, so a *step* is one pass of the hot path over a resident pool of
-``--pool`` DISTINCT cfg2 signals in one batched launch (default 128 signals:
-491 MB read + 491 MB written per step, past the cache - SURVEY.md §8d).
+Headline workload (BASELINE.json configs[1], "cfg2"): synthetic 48 kHz stereo float32, 10 s per
+signal, 30 taps over 30 ms (seed 1, the reference generator's defaults).  One cfg2 signal is only
+3.84 MB, which lives in the 256 MiB Infinity Cache, so a *step* is one pass of the hot path over a
+resident pool of ``--pool`` DISTINCT cfg2 signals in ONE batched launch (default 2048 signals:
+7.9 GB read + 7.9 GB written per step - far past the cache, SURVEY.md 8d - and long enough that the
+K = 20 steps the driver asks for are ~65 ms of timed kernel, not a 4 ms sample).
 "1 sample" = one float32 output channel-sample.
 
-One process per GPU (torch.distributed / RCCL when launched by torchrun).  The
-path shards by independent streams: each rank owns its own pool, the only
-communication is one RCCL broadcast of the serialized tap table before the
-timed region, and no collective sits on the data path ("scaling": "weak").
+One process per GPU (torch.distributed / RCCL when launched by torchrun).  The path shards by
+independent streams: each rank owns its own pool, the only communication is one RCCL broadcast of
+the serialized tap table before the timed region, and no collective sits on the data path
+("scaling": "weak").
 
 The JSON line also carries
-  roofline      algorithmic HBM bytes (8 B per output sample) / kernel time
-                measured with HIP events on the launch stream, vs 8 TB/s;
+  roofline      algorithmic HBM bytes (8 B per output sample) / kernel time measured with HIP
+                events on the launch stream, vs 8 TB/s; `traffic` = HBM bytes per launch from the
+                committed PMC passes of the same launch geometry (`traffic_source` says which file);
   cpu_baseline  the NumPy restatement of the reference's convolve_velvet_noise
-                (oracle/vnd_oracle.py, single thread - NumPy slicing does not
-                multithread) timed on this host on a bounded number of cfg2
-                signals; rank 0, N=1 only.
+                (oracle/vnd_oracle.py, single thread - NumPy slicing does not multithread) timed on
+                this host on a bounded number of cfg2 signals; rank 0, N=1 only;
+  secondary     the other BASELINE configs on one GPU (cfg3, cfg5, cfg4; kernel ms, GB/s, the
+                binding limit named) - parity for them lives in tests/, these are rates only;
+  cfg4_strong   SURVEY 8(d) "Scaling (cfg4)": the 1024 x 1 s stereo batch split over the ranks with
+                distributed.shard_range, timed from "table broadcast done, shards resident" to "all
+                ranks done" (max over ranks); reported at every N, so N = 1/2/4/8 lines give the curve;
+  end_to_end    the synchronous host API (H2D + kernel + D2H) on pageable and pinned NumPy buffers,
+                N=1 only - PCIe-inclusive, never part of `value`.
 """
 from __future__ import annotations
 
@@ -45,21 +52,23 @@ TAPS = 30
 FIR_SECONDS = 0.03
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 ALGO_BYTES_PER_SAMPLE = 8      # 4 B read + 4 B written per output channel-sample
+MIN_TIMED_MS = 50.0            # the timed region of the headline must be at least this long
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=400)
-    ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--min-warmup-ms', type=float, default=150.0,
                     help='keep issuing untimed warm-up steps until this much wall time has passed: the GPU '
                          'ramps its clocks over the first ~40 ms of load (tools/sustain.py)')
-    ap.add_argument('--pool', type=int, default=128, help='distinct cfg2 signals per rank and step')
+    ap.add_argument('--pool', type=int, default=2048, help='distinct cfg2 signals per rank and step')
     ap.add_argument('--mode', choices=['exact', 'fma', 'fast'], default=os.environ.get('VND_BENCH_MODE', 'fast'))
     ap.add_argument('--cpu-seconds', type=float, default=10.0, help='budget of the CPU baseline leg')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-exact', action='store_true', help='skip the extra exact-mode timing')
+    ap.add_argument('--no-secondary', action='store_true', help='skip cfg3/cfg5/cfg4, cfg4_strong and end_to_end')
     ap.add_argument('--variant', type=int, default=-1, help='kernel variant override (tuning)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo for rehearsals)')
     return ap.parse_args()
@@ -104,6 +113,159 @@ def cpu_baseline(budget_s: float) -> dict:
                       f'NumPy restatement of convolve_velvet_noise, mean {mean * 1e3:.1f} ms, '
                       f'min {best * 1e3:.1f} ms, host cores available {os.cpu_count()}',
             'best_value': round(x.size / best / 1e6, 3)}
+
+
+def device_rate(torch, table, shape, mode, *, min_ms=30.0, buffers=1):
+    """Kernel milliseconds per launch of `table` over a resident (batch, n, C) pool (HIP events on the
+    launch stream, >= min_ms timed after a clock-settling warm-up).  `buffers` > 1 rotates distinct
+    pools so that small shapes still stream from HBM, not from the 256 MiB Infinity Cache."""
+    batch, n, c = shape
+    xs = [torch.empty(shape, dtype=torch.float32, device='cuda').uniform_(-1.0, 1.0) for _ in range(buffers)]
+    ys = [torch.empty_like(xs[0]) for _ in range(buffers)]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def launch(i):
+        table.convolve_device(xs[i % buffers].data_ptr(), ys[i % buffers].data_ptr(), batch, n, c, mode, stream)
+
+    t0, i = time.perf_counter(), 0
+    while (time.perf_counter() - t0) * 1e3 < 120.0:
+        launch(i); i += 1
+        if i % 8 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    launch(0)
+    torch.cuda.synchronize()
+    iters = 4
+    while True:
+        e0.record()
+        for k in range(iters):
+            launch(k)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        if ms >= min_ms or iters >= 4096:
+            break
+        iters *= 2
+    per = ms / iters
+    bytes_per_launch = ALGO_BYTES_PER_SAMPLE * batch * n * c
+    return {'kernel_ms': round(per, 4), 'achieved_GBs': round(bytes_per_launch / (per * 1e-3) / 1e9, 1),
+            'frac_of_8TBs': round(bytes_per_launch / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            'Msamples_s': round(batch * n * c / (per * 1e-3) / 1e6, 1), 'launches_timed': iters,
+            'launch': table.describe(batch, n, c, mode)}
+
+
+def secondary_configs(torch, vnd, _native, ctx, mode) -> dict:
+    """The other BASELINE configs on one GPU (rates only; their parity is tests/test_gpu_*.py)."""
+    from vndecorrelate_amd.taps import function_path_arrays
+    out = {}
+
+    def table_of(**kw):
+        fir = vnd.generate_velvet_noise(**kw)
+        a = function_path_arrays(fir)
+        return _native.TapTable.create(ctx, a.tap_offsets, a.tap_index, a.tap_weight)
+
+    specs = [
+        ('cfg3', dict(duration_seconds=0.03, num_impulses=128, num_outs=2, sample_rate_hz=48000,
+                      log_distribution_strength=0.0, seed=1), (24, 2880000, 2), 1,
+         '48 kHz stereo, 60 s, 128 taps (segmented decay, kappa 0); pool of 24',
+         'LDS reads + VALU (128 taps per sample: 4 x the LDS bytes and FMAs of cfg2 per HBM byte)'),
+        ('cfg5', dict(duration_seconds=0.03, num_impulses=64, num_outs=8, sample_rate_hz=96000, seed=1),
+         (16, 960000, 8), 1, '96 kHz 8-channel, 10 s, 64 log-distributed taps; pool of 16',
+         'LDS reads + VALU (64 taps per sample)'),
+        ('cfg4', dict(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1),
+         (1024, 48000, 2), 2, '1024 independent 1 s stereo streams, 30 taps, one launch; 2 rotating pools',
+         'board power cap, as cfg2'),
+    ]
+    for name, kw, shape, buffers, what, limit in specs:
+        try:
+            t = table_of(**kw)
+            r = device_rate(torch, t, shape, mode, buffers=buffers)
+            r.update({'workload': what, 'binding_limit': limit})
+            out[name] = r
+            t.close()
+        except Exception as exc:                        # a secondary leg must never cost the headline
+            out[name] = {'error': repr(exc)}
+        torch.cuda.empty_cache()
+    return out
+
+
+def end_to_end(torch, vnd, mode) -> dict:
+    """PCIe-inclusive rates of the synchronous host API: one cfg2 signal and the cfg4 batch."""
+    out = {}
+    fir = vnd.generate_velvet_noise(duration_seconds=FIR_SECONDS, num_impulses=TAPS, num_outs=CHANNELS,
+                                    sample_rate_hz=SAMPLE_RATE, seed=1)
+    rng = np.random.default_rng(3)
+    for name, shape in (('cfg2_one_signal', (1, 480000, 2)), ('cfg4_batch', (1024, 48000, 2))):
+        x = rng.uniform(-1, 1, shape).astype(np.float32)
+        rec = {}
+        for kind in ('pageable', 'pinned'):
+            xin = x
+            if kind == 'pinned':
+                xin = torch.from_numpy(x).pin_memory().numpy()
+            call = (lambda a: vnd.convolve_velvet_noise_batched(a, fir, mode=mode)) if shape[0] > 1 else \
+                   (lambda a: vnd.convolve_velvet_noise(a[0], fir, mode=mode))
+            call(xin)
+            reps, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < 0.5 and reps < 200:
+                call(xin)
+                reps += 1
+            dt = (time.perf_counter() - t0) / reps
+            rec[kind] = {'ms_per_call': round(dt * 1e3, 3), 'Msamples_s': round(x.size / dt / 1e6, 1),
+                         'GBs_in_plus_out': round(2 * x.nbytes / dt / 1e9, 2)}
+        out[name] = rec
+    out['note'] = ('host pointers in, host pointers out (H2D + kernel + D2H inside the call); the result array is '
+                   'allocated by the call as the reference does; never part of `value`')
+    return out
+
+
+def cfg4_strong(torch, dist, vnd, _native, ctx, table_image, mode, world, rank, device, backend) -> dict:
+    """SURVEY 8(d) scaling leg: 1024 x 1 s stereo streams, contiguous shards, no data-path collective."""
+    from vndecorrelate_amd.distributed import shard_range
+    table = _native.TapTable.from_bytes(ctx, table_image)
+    streams, n = 1024, 48000
+    lo, hi = shard_range(streams, world, rank)
+    mine = hi - lo
+    # rotate enough distinct shard buffers that a step streams from HBM (a 1/8 shard is 49 MB)
+    buffers = max(1, int(np.ceil(600e6 / max(1, mine * n * CHANNELS * 4 * 2))))
+    gen = torch.Generator(device=device)
+    gen.manual_seed(99 + rank)
+    xs = [torch.empty((mine, n, CHANNELS), dtype=torch.float32, device=device).uniform_(-1, 1, generator=gen)
+          for _ in range(buffers)]
+    ys = [torch.empty_like(xs[0]) for _ in range(buffers)]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        table.convolve_device(xs[i % buffers].data_ptr(), ys[i % buffers].data_ptr(), mine, n, CHANNELS, mode, stream)
+
+    t0, i = time.perf_counter(), 0
+    while (time.perf_counter() - t0) * 1e3 < 100.0:
+        step(i); i += 1
+        if i % 8 == 0:
+            torch.cuda.synchronize()
+    steps = 200
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    per = elapsed / steps
+    total = streams * n * CHANNELS
+    return {'streams': streams, 'frames_per_stream': n, 'ranks': world, 'streams_on_rank0': mine, 'steps': steps,
+            'ms_per_pass_max_over_ranks': round(per * 1e3, 4), 'Msamples_s': round(total / per / 1e6, 1),
+            'aggregate_GBs': round(ALGO_BYTES_PER_SAMPLE * total / per / 1e9, 1),
+            'timed_from': 'table broadcast done, shards resident; barrier + sync both sides, max over ranks',
+            'launch_rank0': table.describe(mine, n, CHANNELS, mode)}
 
 
 def main():
@@ -170,7 +332,7 @@ def main():
         while done < warmup or (time.perf_counter() - t_w) * 1e3 < args.min_warmup_ms:
             run(m)
             done += 1
-            if done % 16 == 0:
+            if done % 4 == 0:
                 torch.cuda.synchronize()
         warmups.append(done)
         torch.cuda.synchronize()
@@ -189,6 +351,7 @@ def main():
         return time.perf_counter() - t0, ev0.elapsed_time(ev1) / steps
 
     elapsed, kernel_ms = timed(mode, args.steps, args.warmup)
+    timed_ms = elapsed * 1e3
     y_timed = y[args.pool - 1].cpu().numpy() if rank == 0 else None
 
     if world > 1:
@@ -215,6 +378,7 @@ def main():
             assert np.array_equal(y[args.pool - 1].cpu().numpy(), want), 'exact mode differs from the oracle'
             exact_info = {'kernel_ms': round(e_kernel_ms, 4),
                           'achieved_GBs': round(ALGO_BYTES_PER_SAMPLE * samples_per_step / (e_kernel_ms * 1e-3) / 1e9, 1),
+                          'warmup_actual': warmups[-1],
                           'parity': 'bit-identical to the oracle (sha-checked in tests)',
                           'launch': table.describe(args.pool, n, CHANNELS, vnd.MODE_EXACT)}
 
@@ -222,32 +386,44 @@ def main():
     # written per sample, the kernel's algorithmic traffic), the honest companion of the 8 TB/s figure
     copy_gbs = None
     if rank == 0:
-        for _ in range(5):
+        for _ in range(3):
             y.copy_(x)
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         c0.record()
-        for _ in range(20):
+        for _ in range(10):
             y.copy_(x)
         c1.record()
         torch.cuda.synchronize()
-        copy_gbs = ALGO_BYTES_PER_SAMPLE * samples_per_step / (c0.elapsed_time(c1) / 20 * 1e-3) / 1e9
+        copy_gbs = ALGO_BYTES_PER_SAMPLE * samples_per_step / (c0.elapsed_time(c1) / 10 * 1e-3) / 1e9
+
+    launch_text = table.describe(args.pool, n, CHANNELS, mode)
+    del x, y
+    torch.cuda.empty_cache()
+
+    strong = None
+    if not args.no_secondary:
+        strong = cfg4_strong(torch, dist, vnd, _native, ctx, image, mode, world, rank, device, args.backend)
 
     if rank == 0:
         value = world * samples_per_step * args.steps / elapsed / 1e6
         achieved = ALGO_BYTES_PER_SAMPLE * samples_per_step / (kernel_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed PMC passes (profiles/hbm_traffic.json), if they
-        # were taken on this very launch geometry
-        traffic = None
+        # HBM bytes per launch from the committed PMC passes (separate --pmc runs, FETCH_SIZE x 2 +
+        # WRITE_SIZE as MI355X_MICROARCH.md prescribes), scaled to this pool when they were taken on
+        # the same kernel geometry per stream
+        traffic, traffic_source = None, None
         prof = REPO / 'profiles' / 'hbm_traffic.json'
         if prof.exists():
             rec = json.loads(prof.read_text())
-            if rec.get('launch') == table.describe(args.pool, n, CHANNELS, mode):
-                traffic = rec.get('bytes_per_launch')
+            if rec.get('kernel') and rec['kernel'] in launch_text and rec.get('bytes_per_stream'):
+                traffic = int(rec['bytes_per_stream'] * args.pool)
+                traffic_source = ('profiles/hbm_traffic.json: rocprofv3 --pmc passes of this kernel on a pool of '
+                                  f"{rec.get('pool')} streams ({rec.get('source')}), scaled per stream - not re-measured in this run")
         line = {
             'metric': 'Msamples/sec decorrelated (stereo, 30 taps) + achieved HBM GB/s vs roofline',
             'value': round(value, 1), 'unit': 'Msamples/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': warmups[0], 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+            'warmup': args.warmup, 'warmup_actual': warmups[0], 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+            'timed_ms': round(timed_ms, 2), 'min_timed_ms_met': timed_ms >= MIN_TIMED_MS,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'cfg2: 48 kHz stereo float32, 10 s, 30 taps / 30 ms velvet FIR (seed 1); '
@@ -255,15 +431,22 @@ def main():
                        'pool_signals_per_gpu': args.pool, 'frames': n, 'channels': CHANNELS,
                        'Mframes_per_s': round(value / CHANNELS, 1),
                        'arithmetic': args.mode, 'parity_vs_oracle_of_peak': (0.0 if mode == vnd.MODE_EXACT else parity),
-                       'launch': table.describe(args.pool, n, CHANNELS, mode), 'exact_mode': exact_info,
+                       'launch': launch_text, 'exact_mode': exact_info,
                        'sharding': 'independent streams per rank; RCCL broadcast of the tap table only'},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                         'traffic_source': traffic_source,
                          'read_only_frac': round(achieved / 2 / HBM_PEAK_GBS, 4),
                          'kernel_ms': round(kernel_ms, 4), 'device_copy_GBs': round(copy_gbs, 1),
-                         'limit': 'board power cap (1400 W; clock falls to ~1.83 GHz under this kernel), DESIGN.md 3.5',
+                         'limit': 'board power cap (1400 W; the shader clock falls to ~1.9 GHz under this kernel), '
+                                  'DESIGN.md 3.5',
                          'algorithmic_bytes_per_launch': ALGO_BYTES_PER_SAMPLE * samples_per_step},
         }
+        if strong is not None:
+            line['cfg4_strong'] = strong
+        if world == 1 and not args.no_secondary:
+            line['secondary'] = secondary_configs(torch, vnd, _native, ctx, mode)
+            line['end_to_end'] = end_to_end(torch, vnd, mode)
         if world == 1 and not args.no_cpu:
             line['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)

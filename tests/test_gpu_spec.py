@@ -1,0 +1,177 @@
+"""GPU tier: the per-table (hipRTC) fast kernel - VND_MODE_FAST's default whenever it applies -
+against the oracle, driven through span seams, ring wrap-arounds, stream tails and real sizes.
+Bar: <= 1e-6 of the output peak (the north-star tolerance), as for the generic fast kernel."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from oracle import vnd_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_PEAK = 1e-6
+FORCE = 1 << 23            # specialise however little work there is
+GENERIC = 1 << 25          # never specialise
+
+
+def span_bits(min_span, rounds):
+    return (min_span << 20) | (rounds << 28)
+
+
+@pytest.fixture(scope='module')
+def env():
+    import vndecorrelate_amd.decorrelation as d
+    from vndecorrelate_amd import _native
+    ctx = _native.default_context()
+    yield d, _native, ctx
+    ctx.set_variant(-1)
+
+
+def _table(native, ctx, fir):
+    from vndecorrelate_amd.taps import function_path_arrays
+    a = function_path_arrays(fir)
+    return native.TapTable.create(ctx, a.tap_offsets, a.tap_index, a.tap_weight)
+
+
+def _check(got, want, what, tol=TOL_PEAK):
+    peak = float(np.max(np.abs(want))) or 1.0
+    err = float(np.max(np.abs(got.astype(np.float64) - want))) / peak
+    assert err <= tol, f'{what}: {err:.2e} of peak'
+
+
+def test_headline_workload_takes_the_specialised_kernel(env, golden):
+    d, native, ctx = env
+    ctx.set_variant(-1)
+    table = _table(native, ctx, golden.fir('g48k_k30'))
+    text = table.describe(128, 480000, 2, d.MODE_FAST)
+    assert text.startswith('conv_spec'), text            # a silent fallback must not pass for the real thing
+    assert table.describe(128, 480000, 2, d.MODE_EXACT).startswith('conv_ordered')
+    ctx.set_variant(GENERIC)
+    assert table.describe(128, 480000, 2, d.MODE_FAST).startswith('conv_fast')
+    ctx.set_variant(-1)
+    assert table.describe(1, 5000, 2, d.MODE_FAST).startswith('conv_fast')       # too little work for persistent workgroups
+    table.close()
+
+
+@pytest.mark.parametrize('gname', ['g48k_k30', 'g44k_k30', 'g48k_k128_l', 'g48k_k128_u', 'g44k_noenv', 'g96k_k64_c8'])
+def test_forced_small_signals_and_span_seams(env, golden, gname):
+    """Every length class around the tile (1024 frames) and ring (slots x tile) sizes, spans of 1 to
+    7 tiles so that seams, carries and the span-end reduction all run, batches, and both span
+    arithmetic extremes.  Checked against the NumPy oracle."""
+    d, native, ctx = env
+    fir = golden.fir(gname)
+    C = fir.shape[1]
+    table = _table(native, ctx, fir)
+    # 1e-6 of peak up to 64 taps per channel (the north-star configuration and cfg5); 2e-6 for the
+    # 128-tap tables, where the reference's own two associations differ by 1.2e-6 of peak
+    tol = 2e-6 if 'k128' in gname else TOL_PEAK
+    rng = np.random.default_rng(11)
+    lengths = [1, 2, 31, 1023, 1024, 1025, 2047, 2048, 4096, 4097, 5000, 9001, 12346]
+    for n in lengths:
+        for batch in (1, 3):
+            if batch > 1 and n % 2:
+                continue                                  # odd stereo streams are 8-byte aligned: generic kernel (below)
+            x = rng.uniform(-1, 1, (batch, n, C)).astype(np.float32)
+            want = np.stack([O.convolve_velvet_noise(x[b], fir) for b in range(batch)])
+            for min_span, rounds in ((1, 7), (2, 1), (7, 3)):
+                ctx.set_variant(FORCE | span_bits(min_span, rounds))
+                assert table.describe(batch, n, C, d.MODE_FAST).startswith('conv_spec')
+                _check(table.convolve_host(x, d.MODE_FAST), want, f'{gname} n={n} batch={batch} spans=({min_span},{rounds})', tol)
+    ctx.set_variant(-1)
+    table.close()
+
+
+def test_other_geometries(env, golden):
+    """The tile shapes the geometry choice can fall back to (pairs per lane 1, 2, 8)."""
+    d, native, ctx = env
+    fir = golden.fir('g48k_k30')
+    table = _table(native, ctx, fir)
+    x = np.random.default_rng(3).uniform(-1, 1, (2, 30000, 2)).astype(np.float32)
+    want = np.stack([O.convolve_velvet_noise(x[b], fir) for b in range(2)])
+    for rr in (1, 2, 8):
+        ctx.set_variant(FORCE | span_bits(1, 5) | rr)
+        text = table.describe(2, 30000, 2, d.MODE_FAST)
+        assert f'pairs_per_lane={rr} ' in text, text
+        _check(table.convolve_host(x, d.MODE_FAST), want, f'rr={rr}')
+    for dd in (1, 2):
+        ctx.set_variant(FORCE | span_bits(1, 5) | (dd << 26))
+        assert f'prefetch={dd} ' in table.describe(2, 30000, 2, d.MODE_FAST)
+        _check(table.convolve_host(x, d.MODE_FAST), want, f'dd={dd}')
+    ctx.set_variant(-1)
+    table.close()
+
+
+def test_out_of_scope_launches_take_the_generic_kernel(env, golden):
+    d, native, ctx = env
+    ctx.set_variant(FORCE)
+    t3 = _table(native, ctx, golden.fir('g48k_c3'))                       # odd channel count
+    assert t3.describe(4, 50000, 3, d.MODE_FAST).startswith('conv_fast')
+    t2 = _table(native, ctx, golden.fir('g48k_k30'))
+    assert t2.describe(3, 50001, 2, d.MODE_FAST).startswith('conv_fast')  # odd streams: 8-byte aligned bases
+    assert t2.describe(4, 50000, 1, d.MODE_FAST).startswith('conv_fast')  # fan-out launch
+    x = np.random.default_rng(5).uniform(-1, 1, (3, 50001, 2)).astype(np.float32)
+    want = np.stack([O.convolve_velvet_noise(x[b], golden.fir('g48k_k30')) for b in range(3)])
+    _check(t2.convolve_host(x, d.MODE_FAST), want, 'odd streams')
+    ctx.set_variant(-1)
+    t2.close(); t3.close()
+
+
+def test_real_size_pool_matches_the_exact_kernel(env, golden):
+    """cfg2 streams at full length, enough of them for the automatic choice to specialise (8 spans
+    of 59 tiles per stream): every stream against the bit-exact kernel on the device, three of them
+    against the C oracle, and batch == loop."""
+    import torch
+    d, native, ctx = env
+    ctx.set_variant(-1)
+    fir = golden.fir('g48k_k30')
+    table = _table(native, ctx, fir)
+    pool, n = 24, 480000
+    assert table.describe(pool, n, 2, d.MODE_FAST).startswith('conv_spec')
+    x = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1)
+    y, ye = torch.empty_like(x), torch.empty_like(x)
+    stream = torch.cuda.current_stream().cuda_stream
+    table.convolve_device(x.data_ptr(), y.data_ptr(), pool, n, 2, mode=d.MODE_FAST, stream=stream)
+    table.convolve_device(x.data_ptr(), ye.data_ptr(), pool, n, 2, mode=d.MODE_EXACT, stream=stream)
+    torch.cuda.synchronize()
+    peak = float(ye.abs().max())
+    assert float((y - ye).abs().max()) <= TOL_PEAK * peak
+    offs, idx, w = O.fir_to_taps(fir)
+    for b in (0, 11, 23):
+        want = c_oracle.convolve(x[b].cpu().numpy(), offs, idx, w)
+        assert np.array_equal(ye[b].cpu().numpy(), want)
+        _check(y[b].cpu().numpy(), want, f'stream {b}')
+    # the same streams one launch each (forced: a single stream is too little work otherwise)
+    ctx.set_variant(FORCE)
+    y1 = torch.empty((1, n, 2), dtype=torch.float32, device='cuda')
+    for b in (5, 23):
+        table.convolve_device(x[b].data_ptr(), y1.data_ptr(), 1, n, 2, mode=d.MODE_FAST, stream=stream)
+        torch.cuda.synchronize()
+        assert torch.equal(y1[0], y[b])                  # same arithmetic whatever the span layout: bit-identical
+    ctx.set_variant(-1)
+    table.close()
+
+
+def test_linearity_and_shift_at_full_size(env, golden):
+    """Size-independent properties on the specialised path: exact dyadic scaling and shift invariance."""
+    import torch
+    d, native, ctx = env
+    ctx.set_variant(-1)
+    table = _table(native, ctx, golden.fir('g48k_k30'))
+    pool, n = 32, 240000
+    x = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1)
+    y, y2 = torch.empty_like(x), torch.empty_like(x)
+    s = torch.cuda.current_stream().cuda_stream
+    assert table.describe(pool, n, 2, d.MODE_FAST).startswith('conv_spec')
+    table.convolve_device(x.data_ptr(), y.data_ptr(), pool, n, 2, mode=d.MODE_FAST, stream=s)
+    x4 = (x * 4.0).contiguous()
+    table.convolve_device(x4.data_ptr(), y2.data_ptr(), pool, n, 2, mode=d.MODE_FAST, stream=s)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y * 4.0)
+    # shifting the input by one tile shifts the output by one tile (interior frames)
+    shift = 2048
+    xs = torch.zeros_like(x)
+    xs[:, shift:] = x[:, :-shift]
+    table.convolve_device(xs.data_ptr(), y2.data_ptr(), pool, n, 2, mode=d.MODE_FAST, stream=s)
+    torch.cuda.synchronize()
+    assert torch.equal(y2[:, shift:-2000], y[:, :-shift - 2000])
+    table.close()

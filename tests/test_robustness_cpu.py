@@ -19,7 +19,7 @@ def test_build_watches_every_native_source(tmp_path, monkeypatch):
     fake = tmp_path / 'libvnd_amd.so'
     fake.write_bytes(b'')
     monkeypatch.setattr(entry, 'LIB', fake)
-    sources = sorted((REPO / 'vndecorrelate_amd' / 'csrc').glob('*.h*')) + sorted((REPO / 'include').glob('*.h'))
+    sources = sorted((REPO / 'vndecorrelate_amd' / 'csrc').glob('*.h*')) + sorted((REPO / 'vndecorrelate_amd' / 'csrc').glob('*.inc')) + sorted((REPO / 'include').glob('*.h'))
     assert len(sources) >= 6
     newest = max(s.stat().st_mtime for s in sources)
     for src in sources:

@@ -1,0 +1,93 @@
+"""CPU tier: the per-table (hipRTC) fast kernel's source generator.  No GPU here: the source the
+library would compile is fetched through the C ABI, cross-compiled for gfx950 with hipcc, and its
+ISA is checked for the properties the design rests on."""
+import pathlib
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+REPO = pathlib.Path(__file__).resolve().parents[1]
+HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+
+
+@pytest.fixture(scope='module')
+def native():
+    import __graft_entry__ as entry
+    entry.build()
+    from vndecorrelate_amd import _native
+    _native.load_library()
+    return _native
+
+
+def _table(fir):
+    from vndecorrelate_amd.taps import function_path_arrays
+    a = function_path_arrays(fir)
+    return a.tap_offsets, a.tap_index, a.tap_weight
+
+
+def _macro(src, name):
+    return int(re.search(rf'#define {name} (\d+)', src).group(1))
+
+
+def test_source_carries_the_table(native, golden):
+    fir = golden.fir('g48k_k30')
+    offs, idx, w = _table(fir)
+    src = native.spec_kernel_source(offs, idx, w)
+    assert _macro(src, 'VS_C') == 2 and _macro(src, 'VS_GROUPS') == 1
+    n = int(re.search(r'VS_N\[1\] = \{(\d+),', src).group(1))
+    assert n == len(idx) == 60
+    off_list = [int(v) for v in re.search(r'VS_OFF\[1\]\[\d+\] = \{\{([^}]*)\}', src).group(1).strip(',').split(',')]
+    set_list = [int(v) for v in re.search(r'VS_SET\[1\]\[\d+\] = \{\{([^}]*)\}', src).group(1).strip(',').split(',')]
+    w_list = [float.fromhex(v.rstrip('f')) for v in re.search(r'VS_W\[1\]\[\d+\] = \{\{([^}]*)\}', src).group(1).strip(',').split(',')]
+    # every tap exactly once: (channel, index & ~1, parity, weight) as a multiset
+    got = sorted((s >> 1, o, s & 1, np.float32(x)) for o, s, x in zip(off_list, set_list, w_list))
+    want = sorted((c, int(i) & ~1, int(i) & 1, np.float32(wt)) for c in range(2)
+                  for i, wt in zip(idx[offs[c]:offs[c + 1]], w[offs[c]:offs[c + 1]]))
+    assert got == want
+    # the ring holds one tile plus the halo plus the slot being refilled
+    T = 2 * _macro(src, 'VS_NT') * _macro(src, 'VS_RR')
+    assert (_macro(src, 'VS_PP') - 1) * T >= T + int(idx.max()) + 1
+    assert _macro(src, 'VS_PP') % _macro(src, 'VS_DD') == 0
+
+
+def test_scope_checks(native):
+    offs = np.array([0, 1, 2, 3], np.int32)
+    with pytest.raises(ValueError):            # odd channel count: channel pairs share a workgroup
+        native.spec_kernel_source(offs, np.array([1, 2, 3], np.int32), np.ones(3, np.float32))
+    with pytest.raises(native.NativeError):    # a halo far beyond LDS
+        native.spec_kernel_source(offs[:3], np.array([1, 1 << 20], np.int32), np.ones(2, np.float32))
+    with pytest.raises(native.NativeError):
+        native.spec_kernel_source(offs[:3], np.array([1, 2], np.int32), np.array([1.0, np.inf], np.float32))
+
+
+@pytest.mark.parametrize('gname', ['g48k_k30', 'g96k_k64_c8'])
+def test_source_compiles_for_gfx950_with_the_intended_isa(native, golden, tmp_path, gname):
+    fir = golden.fir(gname)
+    offs, idx, w = _table(fir)
+    src = native.spec_kernel_source(offs, idx, w)
+    f = tmp_path / 'k.hip'
+    f.write_text(src)
+    out = tmp_path / 'k.s'
+    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '--cuda-device-only',
+                        '-include', 'hip/hip_runtime.h', '-S', str(f), '-o', str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = out.read_text()
+    assert re.search(r'ScratchSize: 0\b', asm), 'the specialised kernel must not spill'
+    assert int(re.search(r'NumVgprs: (\d+)', asm).group(1)) <= 128
+    ops = re.findall(r'^\s+([a-z0-9_]+)', asm, re.M)
+    count = {o: ops.count(o) for o in set(ops)}
+    assert count.get('flat_load_dwordx2', 0) == 0, 'LDS reads fell back to flat loads'
+    groups, pp, rr = fir.shape[1] // 2, _macro(src, 'VS_PP'), _macro(src, 'VS_RR')
+    taps = len(idx)
+    # one aligned ds_read_b64 and one packed FMA per (tap, row), in each of the PP unrolled slot phases
+    assert count['v_pk_fma_f32'] == taps * rr * pp
+    assert count['ds_read_b64'] >= taps * rr * pp
+    # no tap read fused into the half-rate two-address forms (the few ds_read2 left are the
+    # wave-boundary exchange of the merge, rows x slot phases of them)
+    assert count.get('ds_read2st64_b64', 0) == 0 and count.get('ds_read2_b64', 0) <= rr * pp * groups
+    assert count['s_barrier'] == groups * (pp + 1)           # one per tile phase + the prologue's
+    # offsets are immediates: no per-tap address arithmetic
+    assert count.get('v_add_u32_e32', 0) < 40 * groups

@@ -8,7 +8,7 @@ tag=${1:-run}; shift || true
 out=gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-args=(--steps 40 --warmup 10 --no-cpu --no-exact "$@")
+args=(--steps 20 --warmup 5 --no-cpu --no-exact --no-secondary "$@")
 run() {  # name, rocprof options...
   local name=$1; shift
   rocprofv3 "$@" -d "$out/$name" -o p --output-format csv -- python3 bench.py "${args[@]}" > "$out/$name.log" 2>&1

@@ -10,8 +10,8 @@ kernel = next(k for k in digest['kernels'] if needle in k)
 trace = digest['kernels'][kernel]
 counters = {c: round(v['mean'], 1) for c, v in digest['counters'].get(kernel, {}).items()}
 out = {
-    'command': 'rocprofv3 {--kernel-trace --stats | --pmc <one group per pass>} -- python3 bench.py --steps 40 '
-               '--warmup 10 --no-cpu --no-exact [--mode exact]  (tools/profile.sh)',
+    'command': 'rocprofv3 {--kernel-trace --stats | --pmc <one group per pass>} -- python3 bench.py --steps 20 '
+               '--warmup 5 --no-cpu --no-exact --no-secondary [--mode exact]  (tools/profile.sh)',
     'kernel': kernel,
     'kernel_trace_us': trace,
     'counters_mean_per_dispatch': dict(sorted(counters.items())),
@@ -20,7 +20,17 @@ out = {
               '(MI355X_MICROARCH.md, HBM section): doubled below'],
 }
 c = counters
-derived = {'algorithmic_bytes_per_launch': 983040000}
+# the bench line of the traced pass tells the pool size and the launch geometry
+bench_line = {}
+for line in (REPO / 'gpurun_out' / f'prof_{tag}' / 'trace.log').read_text().splitlines():
+    if line.startswith('{"metric"'):
+        bench_line = json.loads(line)
+pool = bench_line.get('config', {}).get('pool_signals_per_gpu', 128)
+launch = bench_line.get('config', {}).get('launch', '')
+out['bench_line_of_traced_pass'] = {k: bench_line.get(k) for k in ('value', 'ms_per_step', 'steps', 'warmup_actual')}
+out['bench_line_of_traced_pass']['kernel_ms'] = bench_line.get('roofline', {}).get('kernel_ms')
+out['launch'] = launch
+derived = {'algorithmic_bytes_per_launch': 8 * pool * 480000 * 2, 'pool_signals': pool}
 if 'FETCH_SIZE' in c:
     derived['hbm_read_bytes_per_launch'] = c['FETCH_SIZE'] * 1024 * 2
 if 'WRITE_SIZE' in c:
@@ -39,6 +49,14 @@ if 'SQ_WAVES' in c:
             derived[name.lower().replace('sq_', '') + '_per_wave'] = round(c[name] / c['SQ_WAVES'], 1)
 out['derived'] = derived
 (REPO / 'profiles' / f'{stem}_pmc.json').write_text(json.dumps(out, indent=1) + '\n')
+if 'hbm_read_bytes_per_launch' in derived and 'hbm_write_bytes_per_launch' in derived and '--no-traffic' not in sys.argv:
+    total = derived['hbm_read_bytes_per_launch'] + derived['hbm_write_bytes_per_launch']
+    (REPO / 'profiles' / 'hbm_traffic.json').write_text(json.dumps({
+        'kernel': launch.split(' prefetch=')[0].split(' mode=')[0],       # kernel + tile geometry, as vnd_describe_launch prints it
+        'pool': pool, 'bytes_per_launch': int(total), 'bytes_per_stream': total / pool,
+        'read_bytes': int(derived['hbm_read_bytes_per_launch']), 'write_bytes': int(derived['hbm_write_bytes_per_launch']),
+        'algorithmic_bytes_per_stream': 8 * 480000 * 2, 'launch': launch,
+        'source': f'profiles/{stem}_pmc.json: FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate --pmc passes'}, indent=1) + '\n')
 stats = glob.glob(str(REPO / 'gpurun_out' / f'prof_{tag}' / 'trace' / '**' / '*kernel_stats.csv'), recursive=True)
 if stats:
     lines = pathlib.Path(stats[0]).read_text().splitlines()

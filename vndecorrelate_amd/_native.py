@@ -102,6 +102,8 @@ SIGNATURES = {
                                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                  ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,
                                                  _c_f32p]),
+    'vnd_spec_kernel_source': (ctypes.c_int, [ctypes.c_int32, _c_i32p, _c_i32p, _c_f32p, ctypes.c_char_p,
+                                              ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
     'vnd_set_variant': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     'vnd_describe_launch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                            ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
@@ -454,6 +456,21 @@ def polar_moments_device(ctx: 'Context', y_ptr: int, n: int, pairs: int, moments
                                               ctypes.c_void_p(moments_ptr), ctypes.c_void_p(workspace_ptr),
                                               workspace_bytes, ctypes.c_void_p(stream)),
            'vnd_polar_moments_f32_dev')
+
+
+def spec_kernel_source(tap_offsets, tap_index, tap_weight) -> str:
+    """HIP source of the per-table fast kernel the library would compile with hipRTC
+    (``vnd_spec_kernel_source``; needs no device)."""
+    offs = np.ascontiguousarray(tap_offsets, np.int32)
+    idx = np.ascontiguousarray(tap_index, np.int32)
+    w = np.ascontiguousarray(tap_weight, np.float32)
+    lib = load_library()
+    need = ctypes.c_int64()
+    args = (len(offs) - 1, _ptr(offs, ctypes.c_int32), _ptr(idx, ctypes.c_int32), _ptr(w, ctypes.c_float))
+    _check(lib.vnd_spec_kernel_source(*args, None, 0, ctypes.byref(need)), 'vnd_spec_kernel_source')
+    buf = ctypes.create_string_buffer(need.value)
+    _check(lib.vnd_spec_kernel_source(*args, buf, need.value, ctypes.byref(need)), 'vnd_spec_kernel_source')
+    return buf.value.decode()
 
 
 def device_count() -> int:

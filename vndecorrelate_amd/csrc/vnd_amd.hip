@@ -4,6 +4,7 @@
 #include "vnd_epilogue.hpp"
 #include "vnd_moments.hpp"
 #include "vnd_haas.hpp"
+#include "vnd_spec.hpp"
 #include "../../include/vnd_amd.h"
 
 #include <algorithm>
@@ -11,6 +12,8 @@
 #include <cstdio>
 #include <cstring>
 #include <cmath>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -85,6 +88,11 @@ struct vnd_taps {
     int32_t *d_tap_off = nullptr, *d_seg_off = nullptr, *d_seg_end = nullptr;
     float *d_seg_gain = nullptr;
     uint8_t *d_flags = nullptr;
+    // fast mode, specialised per table (vnd_spec.hpp): modules are compiled on first use
+    SpecTable spec_table;          // effective weights (segment gain folded in)
+    bool spec_ok = false;          // the table is within the specialised kernel's scope
+    std::mutex spec_mutex;
+    std::map<SpecConfig, std::unique_ptr<SpecModule>> spec_modules;
 };
 
 // ------------------------------------------------------------------------------
@@ -360,6 +368,128 @@ static vnd_status check_shape(const vnd_ctx *ctx, const vnd_taps *t, int64_t bat
     return VND_OK;
 }
 
+// ------------------------------------------------------------------------------
+// the specialised fast kernel (vnd_spec.hpp, vnd_spec_kernel.inc)
+// ------------------------------------------------------------------------------
+struct SpecPlan {
+    bool use = false;
+    SpecConfig cfg;
+    int tiles_total = 0, tiles_per_span = 0, spans = 0;
+    uint32_t nblocks = 0;
+    const char *why = "";           // when !use: the reason, for vnd_describe_launch
+};
+
+static bool spec_disabled_by_env()
+{
+    static const bool off = [] { const char *e = getenv("VND_SPEC"); return e && e[0] == '0'; }();
+    return off;
+}
+
+// variant word, specialised kernel: bit 25 forces the generic kernel; bits 26-27 prefetch depth
+// (0 = auto), bits 28-30 spans per resident slot ("rounds", 0 = auto); bits 0-4 = pairs per lane as ever;
+// bits 20-22 shortest span in tiles (0 = auto, 8) and bit 23 "specialise however little work there
+// is" - the two that let the tests drive span seams and tiny signals through this kernel.
+static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const float *x, const float *y, int64_t batch,
+                               int64_t n, int C, int Cx, int mode, bool epi)
+{
+    SpecPlan p;
+    const int v = ctx->variant;
+    if (mode != VND_MODE_FAST) { p.why = "not the fast mode"; return p; }
+    if (epi || Cx != C) { p.why = "fused epilogue or fan-out launch"; return p; }
+    if (!t->spec_ok) { p.why = "table outside the specialised kernel's scope"; return p; }
+    const bool force = v >= 0 && ((v >> 23) & 1);
+    // Wider signals stage 8 bytes per frame and channel pair: measured slower than the generic kernel
+    // on the 8-channel config (bench.py secondary cfg5), so only stereo specialises by default.
+    if (C != 2 && !force) { p.why = "more than two channels"; return p; }
+    if (spec_disabled_by_env() || (v >= 0 && ((v >> 25) & 1))) { p.why = "disabled"; return p; }
+    // access shape: 16 bytes per frame pair (stereo) or 8 per frame, from every stream's first sample
+    const uintptr_t align = C == 2 ? 16 : 8;
+    if (((uintptr_t)x | (uintptr_t)y) & (align - 1)) { p.why = "unaligned base"; return p; }
+    if (batch > 1 && ((uint64_t)n * C * 4) % align != 0) { p.why = "unaligned streams"; return p; }
+    const int rr_hint = (v >= 0 && (v & 31) != 0 && (v & 31) <= 8) ? (v & 31) : 0;
+    const int dd_hint = v >= 0 ? ((v >> 26) & 3) : 0;
+    if (!spec_pick_config(t->spec_table, (size_t)ctx->lds_limit, rr_hint, dd_hint, &p.cfg)) { p.why = "halo does not fit the ring"; return p; }
+    const int64_t T = p.cfg.tile();
+    const int64_t tiles_total = (n + T - 1) / T;
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    // resident workgroups per CU: LDS-bound, within the 32 waves a CU holds
+    const int64_t per_cu = std::min<int64_t>(std::min<int64_t>(16, 2048 / p.cfg.nt), (int64_t)(160 * 1024) / (int64_t)p.cfg.lds_bytes());
+    const int64_t resident = (int64_t)cus * std::max<int64_t>(per_cu, 1);
+    const int64_t units = batch * (C / 2);                     // (stream, channel pair)
+    // a workgroup needs a span long enough to amortise filling its ring
+    const int64_t min_span = (v >= 0 && ((v >> 20) & 7)) ? ((v >> 20) & 7) : 8;
+    if (!force && units * tiles_total < resident * min_span) { p.why = "too little work for persistent workgroups"; return p; }
+    // Spans per stream: the workgroups are equally long, so the grid should fill the resident slots
+    // a whole number of times ("rounds") - 1.5 rounds cost as much as 2.  Fewest spans (longest
+    // rings) whose last round is at least 95 % full, else the fullest.
+    const int rounds = (v >= 0 && ((v >> 28) & 7)) ? ((v >> 28) & 7) : 0;
+    const int64_t max_spans = std::max<int64_t>(1, tiles_total / min_span);
+    int64_t spans = 1;
+    if (rounds > 0) {
+        spans = std::min(std::max<int64_t>(1, resident * rounds / units), max_spans);
+    } else {
+        double best = -1.0;
+        const int64_t limit = std::min<int64_t>(max_spans, std::max<int64_t>(1, 4 * resident / units + 1));
+        for (int64_t sp = 1; sp <= limit; ++sp) {
+            const int64_t per = (tiles_total + sp - 1) / sp;
+            const int64_t wgs = units * ((tiles_total + per - 1) / per);
+            const double fill = (double)wgs / (double)(((wgs + resident - 1) / resident) * resident);
+            if (fill > best + 1e-9) { best = fill; spans = sp; }
+            if (fill >= 0.95) { spans = sp; break; }
+        }
+    }
+    int64_t per_span = (tiles_total + spans - 1) / spans;
+    // descriptor offsets are 32-bit: keep a span (plus what it prefetches) under 2 GiB
+    const int64_t max_tiles = ((int64_t)0x7fffffff / (T * C * 4)) - p.cfg.pp - p.cfg.dd - 1;
+    if (max_tiles < 1) { p.why = "tile too large"; return p; }
+    per_span = std::min(per_span, max_tiles);
+    spans = (tiles_total + per_span - 1) / per_span;
+    if (units * spans > 0x7fffffffLL) { p.why = "grid too large"; return p; }
+    p.cfg.nt_stores = (batch * n * C * (int64_t)sizeof(float) >= ((int64_t)64 << 20)) ? 1 : 0;
+    p.tiles_total = (int)tiles_total; p.tiles_per_span = (int)per_span; p.spans = (int)spans;
+    p.nblocks = (uint32_t)(units * spans);
+    p.use = true;
+    return p;
+}
+
+// compiled on first use, once per (table, geometry); a failed build is remembered and the generic
+// kernel takes over (the reason stays readable through vnd_describe_launch)
+static SpecModule *spec_module(vnd_ctx *ctx, const vnd_taps *t_, const SpecConfig &cfg)
+{
+    vnd_taps *t = const_cast<vnd_taps *>(t_);
+    std::lock_guard<std::mutex> g(t->spec_mutex);
+    auto it = t->spec_modules.find(cfg);
+    if (it == t->spec_modules.end()) {
+        std::unique_ptr<SpecModule> m(new SpecModule);
+        spec_compile(t->spec_table, cfg, ctx->device, ctx->lds_limit, m.get());
+        it = t->spec_modules.emplace(cfg, std::move(m)).first;
+    }
+    return it->second.get();
+}
+
+static vnd_status launch_spec(vnd_ctx *ctx, const vnd_taps *t, const SpecPlan &p, const float *x, float *y, int64_t n,
+                              hipStream_t stream, bool *launched)
+{
+    *launched = false;
+    SpecModule *m = spec_module(ctx, t, p.cfg);
+    if (!m || m->failed) return VND_OK;                      // generic kernel instead
+    SpecArgs a{};
+    a.x = x; a.y = y; a.n = n;
+    a.tiles_total = p.tiles_total; a.tiles_per_span = p.tiles_per_span; a.spans = p.spans; a.nblocks = p.nblocks;
+    void *params[] = {&a};
+    hipError_t e = hipModuleLaunchKernel(m->fn, p.nblocks, 1, 1, p.cfg.nt, 1, 1, (unsigned)p.cfg.lds_bytes(), stream, params,
+                                         nullptr);
+    if (e != hipSuccess) {
+        std::lock_guard<std::mutex> g(const_cast<vnd_taps *>(t)->spec_mutex);
+        m->failed = true;
+        m->log = std::string("launch failed: ") + hipGetErrorString(e);
+        (void)hipGetLastError();
+        return VND_OK;
+    }
+    *launched = true;
+    return VND_OK;
+}
+
 struct EpiFuse {                 // non-null => launch the fused-epilogue instantiation
     double *partials;
     int ms_encode, use_width, normalize;
@@ -372,6 +502,14 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
 {
     if (batch == 0 || n == 0) return VND_OK;
     if (Cx == 0) Cx = C;
+    {
+        const SpecPlan sp = make_spec_plan(ctx, t, x, y, batch, n, C, Cx, mode, epi != nullptr);
+        if (sp.use) {
+            bool launched = false;
+            vnd_status st = launch_spec(ctx, t, sp, x, y, n, stream, &launched);
+            if (st != VND_OK || launched) return st;
+        }
+    }
     const Plan p = make_plan(ctx, t, batch, n, C, mode, Cx);
     KArgs a{};
     a.x = x; a.y = y; a.taps = t->d_taps; a.taps_fast = t->d_taps_fast; a.taps_ord = t->d_taps_ord; a.fast_off = t->d_fast_off; a.fast_even = t->d_fast_even; a.tap_off = t->d_tap_off;
@@ -598,6 +736,13 @@ vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, 
             fast_off[c + 1] = (int32_t)fast.size();
         }
         fast.resize(fast.size() + 16, FastTap{0.0f, 0});
+        // the specialised fast kernel's view of the table: channel pairs, every channel filtered
+        t->spec_table.C = C;
+        t->spec_table.tap_off = t->tap_off;
+        t->spec_table.idx = t->idx;
+        t->spec_table.w = eff;
+        t->spec_table.max_index = max_index;
+        t->spec_ok = t->lds_images && !t->nonfinite && !t->has_flags && C % 2 == 0 && C <= 64 && total > 0;
     }
     if (e == hipSuccess) e = upload(&t->d_taps_fast, fast.data(), fast.size());
     {   // ordered image: table order, weight first (SGPR pair layout), byte offsets, padded
@@ -626,6 +771,8 @@ vnd_status vnd_taps_destroy(vnd_taps *t)
     if (!t) return VND_OK;
     (void)hipSetDevice(t->ctx->device);
     free_taps_dev(t);
+    for (auto &kv : t->spec_modules)
+        if (kv.second && kv.second->module) (void)hipModuleUnload(kv.second->module);
     delete t;
     return VND_OK;
 }
@@ -825,6 +972,34 @@ vnd_status vnd_time_convolve_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const floa
     return VND_OK;
 }
 
+vnd_status vnd_spec_kernel_source(int32_t C, const int32_t *tap_offsets, const int32_t *tap_index,
+                                  const float *tap_weight, char *text, int64_t capacity, int64_t *bytes)
+{
+    if (!bytes) return fail(VND_ERR_INVALID, "null bytes pointer");
+    if (C <= 0 || C % 2 != 0 || C > 64 || !tap_offsets || tap_offsets[0] != 0)
+        return fail(VND_ERR_INVALID, "the specialised kernel takes an even channel count (2..64) and a CSR tap table");
+    SpecTable t;
+    t.C = C;
+    t.tap_off.assign(tap_offsets, tap_offsets + C + 1);
+    const int32_t total = tap_offsets[C];
+    if (total <= 0 || !tap_index || !tap_weight) return fail(VND_ERR_INVALID, "empty tap table");
+    for (int32_t k = 0; k < total; ++k) {
+        if (tap_index[k] < 0 || tap_index[k] >= (1 << 24) || !std::isfinite(tap_weight[k]))
+            return fail(VND_ERR_UNSUPPORTED, "tap %d is outside the specialised kernel's scope", k);
+        t.max_index = std::max(t.max_index, tap_index[k]);
+    }
+    t.idx.assign(tap_index, tap_index + total);
+    t.w.assign(tap_weight, tap_weight + total);
+    SpecConfig cfg;
+    if (!spec_pick_config(t, 160 * 1024, 0, 0, &cfg)) return fail(VND_ERR_UNSUPPORTED, "halo does not fit the LDS ring");
+    const std::string src = spec_prologue(t, cfg) + kSpecKernelSource;
+    *bytes = (int64_t)src.size() + 1;
+    if (!text) return VND_OK;                    // size query
+    if (capacity < *bytes) return fail(VND_ERR_INVALID, "buffer too small: need %lld bytes", (long long)*bytes);
+    memcpy(text, src.c_str(), src.size() + 1);
+    return VND_OK;
+}
+
 vnd_status vnd_set_variant(vnd_ctx *ctx, int32_t variant)
 {
     if (!ctx) return fail(VND_ERR_INVALID, "null context");
@@ -839,6 +1014,21 @@ static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64
     vnd_status st = check_shape(ctx, t, batch, n, C, mode, Cx);
     if (st != VND_OK) return st;
     if (!text || len <= 0) return fail(VND_ERR_INVALID, "null text buffer");
+    // the pointers only decide alignment: describe the launch of 256-byte-aligned buffers (hipMalloc's)
+    const SpecPlan sp = make_spec_plan(ctx, t, nullptr, nullptr, batch, n, C, Cx, mode, false);
+    if (sp.use) {
+        DeviceScope on(ctx->device);
+        SpecModule *m = spec_module(ctx, t, sp.cfg);
+        if (m && !m->failed) {
+            snprintf(text, (size_t)len,
+                     "conv_spec (hipRTC, per table) pairs_per_lane=%d tile=%d ring_slots=%d prefetch=%d reads_ahead=%d "
+                     "nt_stores=%d mode=%d lds=%zuB workgroups=%u (%d spans x %d tiles per stream) threads=%d",
+                     sp.cfg.rr, sp.cfg.tile(), sp.cfg.pp, sp.cfg.dd, sp.cfg.la, sp.cfg.nt_stores, mode, sp.cfg.lds_bytes(),
+                     sp.nblocks, sp.spans, sp.tiles_per_span, sp.cfg.nt);
+            return VND_OK;
+        }
+        if (m && getenv("VND_SPEC_VERBOSE")) fprintf(stderr, "vnd: specialised kernel unavailable: %s\n", m->log.c_str());
+    }
     const Plan p = make_plan(ctx, t, batch, n, C, mode, Cx);
     if (p.direct)
         snprintf(text, (size_t)len, "conv_direct mode=%d blocks=%u threads=%d", mode, p.nblocks, kDirectThreads);

@@ -913,8 +913,8 @@ __global__ __launch_bounds__(kDirectThreads) void conv_direct_kernel(const KArgs
             for (; k < kend; ++k) {
                 const Tap tp = a.taps[k];
                 const int64_t m = n0 + tp.idx;
-                const float v = m < a.n ? xs[m * Cx + cx] : 0.0f;
-                sb = tap_op<MODE>(sb, v, tp.w);
+                if (m >= a.n) continue;          // the slice does not reach this output: the term DROPS (decorrelation.py:656-658)
+                sb = tap_op<MODE>(sb, xs[m * Cx + cx], tp.w);
             }
             if (has_seg) {
                 if (a.apply_gain) sb = sb * a.seg_gain[s_begin + s];
