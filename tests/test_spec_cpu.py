@@ -83,7 +83,8 @@ def test_source_compiles_for_gfx950_with_the_intended_isa(native, golden, tmp_pa
     groups, pp, rr = fir.shape[1] // 2, _macro(src, 'VS_PP'), _macro(src, 'VS_RR')
     taps = len(idx)
     # one aligned ds_read_b64 and one packed FMA per (tap, row), in each of the PP unrolled slot phases
-    assert count['v_pk_fma_f32'] == taps * rr * pp
+    # (+ the span-end chain over the odd taps, which hipcc may pack across the two channels)
+    assert taps * rr * pp <= count['v_pk_fma_f32'] <= taps * rr * pp + taps
     assert count['ds_read_b64'] >= taps * rr * pp
     # no tap read fused into the half-rate two-address forms (the few ds_read2 left are the
     # wave-boundary exchange of the merge, rows x slot phases of them)
