@@ -589,6 +589,54 @@ def test_exact_rms_sums_are_numpys(vnd, name, x):
     assert np.array_equal(yd.cpu().numpy(), ref, equal_nan=True), name
 
 
+def test_block_parallel_sums_equal_the_sequential_kernel(vnd):
+    """The block-parallel exact sums (rms_par_*: predicted binades, prefix-summed runs, prefetched crossing
+    groups) against the one-workgroup-per-stream kernel and NumPy, on batches whose streams cross binades
+    at different places, hit ties, start silent, or carry non-finite samples; forced for a large batch too."""
+    import torch
+    from vndecorrelate_amd import _native
+    ctx = _native.default_context()
+    rng = np.random.default_rng(123)
+    n = 150001
+    streams = []
+    for k in range(24):
+        amp = 10.0 ** rng.uniform(-3, 3)
+        sig = (rng.uniform(-1, 1, (n, 2)) * amp).astype(np.float32)
+        if k % 4 == 1:
+            sig = np.round(sig * 64) / 64                               # short mantissas: ties
+        if k % 4 == 2:
+            sig[:rng.integers(1, 40000)] = 0                            # silent start
+        if k % 6 == 3:
+            sig *= np.linspace(0.01, 30, n, dtype=np.float32)[:, None]  # growing level: crossings late in the signal
+        if k == 5:
+            sig[100000, 0] = np.inf
+        if k == 7:
+            sig[30000, 1] = np.nan
+        streams.append(sig.astype(np.float32))
+    x = np.stack(streams)
+    offsets = np.arange(3, dtype=np.int32)
+    table = _native.TapTable.create(ctx, offsets, np.zeros(2, np.int32), np.ones(2, np.float32))
+    st = torch.cuda.current_stream().cuda_stream
+    results = {}
+    for label, variant, batch in (('parallel', -1, 24), ('sequential', 1 << 19, 24), ('parallel-forced', 1 << 17, 24)):
+        ctx.set_variant(variant)
+        xd = torch.from_numpy(x[:batch]).cuda()
+        yd = torch.empty_like(xd)
+        ws_bytes = _native.decorrelate_workspace_bytes(batch, n, 2)
+        ws = torch.zeros(ws_bytes // 8 + 1, dtype=torch.float64, device='cuda')
+        table.decorrelate_device(xd.data_ptr(), yd.data_ptr(), batch, n, 2, mode=vnd.MODE_EXACT, ms_encode=False, width=None,
+                                 normalize=True, workspace_ptr=ws.data_ptr(), workspace_bytes=ws_bytes, stream=st)
+        torch.cuda.synchronize()
+        results[label] = (ws[:4 * batch].cpu().numpy().astype(np.float32).reshape(batch, 4), yd.cpu().numpy())
+    ctx.set_variant(-1)
+    want = np.stack([_seq_sums(s) for s in streams])
+    for label, (sums, y) in results.items():
+        assert np.array_equal(sums[:, :2], want, equal_nan=True), label
+        assert np.array_equal(sums[:, 2:], want, equal_nan=True), label          # y == x for this table
+        assert np.array_equal(y, results['sequential'][1], equal_nan=True), label
+    table.close()
+
+
 def test_fortran_ordered_signal_keeps_numpys_sum_order(vnd, golden):
     """NumPy sums a Fortran-ordered (n, 2) signal pairwise per column, not row by row: the default
     policy must then leave the normaliser to NumPy - the result equals the host-epilogue stage."""

@@ -1059,10 +1059,14 @@ static int64_t epi_chunks(int64_t n) { return (n + kEpiChunk - 1) / kEpiChunk; }
 // rows of partial sums per stream: pass-1 chunks, or - fused - one row per tile (>= 512 frames each)
 static int64_t epi_rows_max(int64_t n) { return std::max<int64_t>(epi_chunks(n), (n + 511) / 512 + 1); }
 
+static int64_t par_blocks(int64_t n) { return std::max<int64_t>((n + kParFrames - 1) / kParFrames, 1); }
+
 vnd_status vnd_decorrelate_workspace_bytes(int64_t batch, int64_t n, int32_t C, int64_t *bytes)
 {
     if (!bytes || batch < 0 || n < 0 || C <= 0) return fail(VND_ERR_INVALID, "bad workspace query");
     *bytes = batch * epi_rows_max(n) * 2 * C * (int64_t)sizeof(double) + batch * C * (int64_t)sizeof(float) + 16;
+    // the parallel exact sums of a stereo table: per stream and chain, a float64 sum and a record per block
+    if (C == 2) *bytes += 32 + batch * 4 * (par_blocks(n) * (int64_t)(sizeof(double) + sizeof(ParRec) + sizeof(ParGrp)) + (int64_t)sizeof(float));
     return VND_OK;
 }
 
@@ -1138,7 +1142,38 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
             hipLaunchKernelGGL(epilogue_pointwise_kernel, grid, dim3(kEpiThreads), 0, stream, e);
         sums_pending = seq;
     }
-    if (sums_pending) {
+    // stereo: the sums parallel over the stream's blocks (vnd_epilogue.hpp, rms_par_*); variant bit 19
+    // keeps the one-workgroup-per-stream kernel (A/B runs)
+    // (up to 64 streams: beyond that the one-workgroup-per-stream kernel fills the chip by itself and
+    // reads the data once instead of twice; bit 17 forces the block-parallel form for any batch)
+    const bool par_sums = sums_pending && C == 2 && !(ctx->variant >= 0 && ((ctx->variant >> 19) & 1)) &&
+                          par_blocks(n) <= 0x7fffffff && (batch <= 64 || (ctx->variant >= 0 && ((ctx->variant >> 17) & 1)));
+    if (par_sums) {
+        e.rows = 1;
+        e.exact_rms = 1;
+        e.normalize = 1;
+        RArgs r{};
+        r.x = x; r.y = y; r.n = n; r.Cx = Cx; r.nblocks = (int32_t)par_blocks(n);
+        char *extra = (char *)(e.scales + batch * C);
+        extra += (16 - ((uintptr_t)extra & 15)) & 15;
+        r.blk_sum = (double *)extra;
+        r.rec = (ParRec *)(r.blk_sum + batch * 4 * (int64_t)r.nblocks);
+        r.grp = (ParGrp *)(r.rec + batch * 4 * (int64_t)r.nblocks);
+        r.first = (float *)(r.grp + batch * 4 * (int64_t)r.nblocks);
+        r.partials = e.partials;
+        r.debug_skip_slow = (ctx->variant >= 0 && ((ctx->variant >> 18) & 1)) ? 1 : 0;
+        const dim3 pgrid((unsigned)r.nblocks, (unsigned)batch), tgrid((unsigned)(r.nblocks - 1), (unsigned)batch);
+        const dim3 sgrid((unsigned)(batch * 4));
+        if (Cx == 1) {
+            hipLaunchKernelGGL(rms_par_sum_kernel<true>, pgrid, dim3(kParThreads), 0, stream, r);
+            if (r.nblocks > 1) hipLaunchKernelGGL(rms_par_tally_kernel<true>, tgrid, dim3(kParThreads), 0, stream, r);
+            hipLaunchKernelGGL(rms_par_stitch_kernel<true>, sgrid, dim3(64), 0, stream, r);
+        } else {
+            hipLaunchKernelGGL(rms_par_sum_kernel<false>, pgrid, dim3(kParThreads), 0, stream, r);
+            if (r.nblocks > 1) hipLaunchKernelGGL(rms_par_tally_kernel<false>, tgrid, dim3(kParThreads), 0, stream, r);
+            hipLaunchKernelGGL(rms_par_stitch_kernel<false>, sgrid, dim3(64), 0, stream, r);
+        }
+    } else if (sums_pending) {
         e.rows = 1;
         e.exact_rms = 1;
         e.normalize = 1;

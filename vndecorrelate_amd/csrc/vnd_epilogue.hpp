@@ -343,6 +343,350 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
         if (lane == 0) a.partials[b * a.rows * chains + ch] = (double)acc[slot];
 }
 
+// ---- the same sums, parallel over the stream (stereo tables) -----------------
+// The sequential kernel above walks a 10 s signal block after block in ONE workgroup (437 us, 17 GB/s).
+// The recurrence itself cannot be split, but what it needs per block can: whether a run of squares
+// can be settled in integers depends only on the BINADE of the running sum when the run starts, and
+// that is predictable from a float64 prefix of the block sums.  So:
+//   rms_par_sum     one workgroup per block of 2048 frames: float64 sum of each chain's squares
+//                   (block 0, whose starting sum is known - zero - is summed for good, sequentially);
+//   rms_par_tally   one workgroup per block: predicts the binade e at the block's start from the
+//                   prefix of those sums and, where the sum is about to leave the binade, the group
+//                   g* of 256 squares in which it will; computes the integer tallies QA (groups
+//                   before g*, against ulp(e)) and QB (groups after g*, against ulp(e + 1)) with their
+//                   tie / range flags;
+//   rms_par_stitch  one wave per chain walks the blocks in order.  Runs of blocks whose prediction
+//                   holds are accepted 64 at a time (a wave prefix sum of their tallies finds the
+//                   first one that does not fit); a block that crosses a binade costs two integer
+//                   adds and the 256 dependent float additions of its group g* (prefetched when the
+//                   kernel starts); only what defeats the prediction - ties, a sum that crosses where
+//                   it was not expected to - is re-read and summed by the sequential code above.
+// Every accepted step is exactly what the dependent float32 additions produce, every prediction
+// is verified against the actual running sum, so the result is the sequential kernel's (NumPy's,
+// utils/dsp.py:87-109) bit for bit.
+constexpr int kParFrames = 2048;
+constexpr int kParThreads = 256;
+constexpr int kParGroups = kParFrames / kSeqGroup;       // 8
+constexpr int kParSlots = 16;                            // binade crossings prefetched per chain (a sum crosses each binade once)
+constexpr uint32_t kParZero = 1u << 9, kParBad = 1u << 10, kParHint = 1u << 12;
+
+struct ParRec {                       // 16 bytes per (chain, block)
+    uint32_t tag;                     // bits 0-8 predicted biased exponent e; flags; bits 16-18 g* (with kParHint)
+    uint32_t qtot;                    // the whole block's tally against ulp(e) (valid unless kParBad)
+    uint32_t bad;                     // bit g: group g cannot be settled against ulp(e); bit 8 + g: against ulp(e + 1)
+    uint32_t pad;
+};
+struct ParGrp { uint32_t qe[kParGroups], qf[kParGroups]; };      // per-group tallies against ulp(e) and ulp(e + 1)
+
+struct RArgs {
+    const float *__restrict__ x;
+    const float *__restrict__ y;
+    int64_t n;
+    int32_t Cx;                      // 1 (mono fanned out) or 2
+    int32_t nblocks;
+    double *__restrict__ blk_sum;    // [batch][4][nblocks]
+    ParRec *__restrict__ rec;        // [batch][4][nblocks]
+    ParGrp *__restrict__ grp;        // [batch][4][nblocks]
+    float *__restrict__ first;       // [batch][4]: the sum after block 0
+    double *__restrict__ partials;   // [batch][4]: the sums, as the sequential kernel writes them
+    int32_t debug_skip_slow;
+};
+
+// squares of block `blk` of stream b into sq[4][2048] (chains: x ch0, x ch1, y ch0, y ch1); frames
+// past the end of the stream read 0 and add +0, exact
+template <bool MONO>
+__device__ __forceinline__ void par_stage(const RArgs &a, int64_t b, int blk, float *sq, int tid)
+{
+    const int64_t f0 = (int64_t)blk * kParFrames;
+    const float *xs = a.x + (b * a.n + f0) * (MONO ? 1 : 2);
+    const float *ys = a.y + (b * a.n + f0) * 2;
+    const v4i rx = make_rsrc(xs, (a.n - f0) * (MONO ? 4 : 8));
+    const v4i ry = make_rsrc(ys, (a.n - f0) * 8);
+    // 8 bytes per access: a stream's first sample is only 8-byte aligned when n is odd
+    v4f yv[2][2], xv[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                         // frames 4*tid + 1024*u + {0..3}
+        const int fr = 4 * tid + 1024 * u;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const v2f y0 = buf_load2(ry, (fr + 2 * h) * 8, 0, 0), y1 = buf_load2(ry, (fr + 2 * h + 1) * 8, 0, 0);
+            yv[u][h] = v4f{y0.x, y0.y, y1.x, y1.y};
+            if constexpr (MONO) {
+                const float m0 = buf_load1(rx, (fr + 2 * h) * 4, 0, 0), m1 = buf_load1(rx, (fr + 2 * h + 1) * 4, 0, 0);
+                xv[u][h] = v4f{m0, m0, m1, m1};
+            } else {
+                const v2f x0 = buf_load2(rx, (fr + 2 * h) * 8, 0, 0), x1 = buf_load2(rx, (fr + 2 * h + 1) * 8, 0, 0);
+                xv[u][h] = v4f{x0.x, x0.y, x1.x, x1.y};
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        float4 *dst = (float4 *)(sq + 4 * tid + 1024 * u);
+        const v4f p = xv[u][0], q = xv[u][1], r = yv[u][0], t = yv[u][1];
+        dst[0 * kParFrames / 4] = make_float4(p.x * p.x, p.z * p.z, q.x * q.x, q.z * q.z);
+        dst[1 * kParFrames / 4] = make_float4(p.y * p.y, p.w * p.w, q.y * q.y, q.w * q.w);
+        dst[2 * kParFrames / 4] = make_float4(r.x * r.x, r.z * r.z, t.x * t.x, t.z * t.z);
+        dst[3 * kParFrames / 4] = make_float4(r.y * r.y, r.w * r.w, t.y * t.y, t.w * t.w);
+    }
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) v += __shfl_xor(v, sh);
+    return v;
+}
+
+template <bool MONO>
+__global__ __launch_bounds__(kParThreads) void rms_par_sum_kernel(const RArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float sq[4 * kParFrames];
+    const int tid = threadIdx.x, lane = tid & 63, chain = tid >> 6;
+    const int blk = blockIdx.x;
+    const int64_t b = blockIdx.y;
+    par_stage<MONO>(a, b, blk, sq, tid);
+    __syncthreads();
+    const float *row = sq + chain * kParFrames;
+    double s = 0.0;
+#pragma unroll
+    for (int g = 0; g < kParFrames; g += 256) {
+        const float4 v = *(const float4 *)(row + g + 4 * lane);
+        s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+    }
+    s = wave_sum_f64(s);
+    if (lane == 0) a.blk_sum[(b * 4 + chain) * a.nblocks + blk] = s;
+    if (blk == 0) {                                       // the chain's start: the recurrence itself, from +0
+        const float acc = seq_sum_block<kParFrames>(row, 0.0f, lane);
+        if (lane == 0) a.first[b * 4 + chain] = acc;
+    }
+}
+
+// sum of round(s / ulp) over the groups [g0, g1) of a staged row, with the flags of seq_settle
+__device__ __forceinline__ uint32_t par_tally_groups(const float *row, int g0, int g1, int eb, int lane, bool *bad, bool *zero)
+{
+    SeqTally t;
+    const bool eb_ok = eb >= 23 && eb < 255;
+    const float scale = seq_scale(eb_ok ? eb : 127);
+    for (int g = g0; g < g1; ++g) seq_tally(t, *(const float4 *)(row + g * kSeqGroup + 4 * lane), scale);
+    const float lane_total = t.q.x + t.q.y;
+    const bool lane_bad = !eb_ok || !(lane_total < 16777216.0f) || !(fmaxf(t.smax.x, t.smax.y) < 4194304.0f) ||
+                          fmaxf(t.rmax.x, t.rmax.y) == 0.5f || fminf(t.rmin.x, t.rmin.y) == -0.5f;
+    const bool any_bad = __ballot(lane_bad) != 0;
+    const uint32_t q = wave_sum_u32(lane_bad ? 0u : (uint32_t)lane_total);
+    *bad = any_bad || q >= (1u << 24);
+    *zero = __ballot(t.any_bits != 0) == 0;
+    return q;
+}
+
+template <bool MONO>
+__global__ __launch_bounds__(kParThreads) void rms_par_tally_kernel(const RArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float sq[4 * kParFrames];
+    const int tid = threadIdx.x, lane = tid & 63, chain = tid >> 6;
+    const int blk = blockIdx.x + 1;                       // block 0 was summed by rms_par_sum
+    const int64_t b = blockIdx.y;
+    par_stage<MONO>(a, b, blk, sq, tid);
+    // where the running sum stands when this block starts, to within float64 rounding: only its
+    // binade matters, and a wrong guess merely sends the block down the sequential path
+    const double *sums = a.blk_sum + (b * 4 + chain) * a.nblocks;
+    double pre = 0.0;
+    for (int j = lane; j < blk; j += 64) pre += sums[j];
+    pre = wave_sum_f64(pre);
+    const int eb = (int)(__float_as_uint((float)pre) >> 23);
+    __syncthreads();
+    const float *row = sq + chain * kParFrames;
+    // group sums (float64) locate the group g* in which the sum is expected to reach the next power of two
+    const double next = (double)__uint_as_float((uint32_t)min(eb + 1, 254) << 23);       // 2^(e + 1 - 127)
+    int gstar = kParGroups;
+    double run = pre;
+#pragma unroll
+    for (int g = 0; g < kParGroups; ++g) {
+        const float4 v = *(const float4 *)(row + g * kSeqGroup + 4 * lane);
+        const double after = run + wave_sum_f64((double)v.x + (double)v.y + (double)v.z + (double)v.w);
+        if (run < next && after >= next && gstar == kParGroups) gstar = g;
+        run = after;
+    }
+    // per group: the tally against ulp(e) and against ulp(e + 1) (the stitch uses whichever binade the
+    // running sum is really in), and whether each can be trusted
+    uint32_t bad_bits = 0, qtot = 0, mine_e = 0, mine_f = 0;
+    bool all_zero = true;
+#pragma unroll
+    for (int g = 0; g < kParGroups; ++g) {
+        bool be = false, bf = false, ze = true, zf = true;
+        const uint32_t qe = par_tally_groups(row, g, g + 1, eb, lane, &be, &ze);
+        const uint32_t qf = par_tally_groups(row, g, g + 1, eb + 1, lane, &bf, &zf);
+        if (be) bad_bits |= 1u << g;
+        if (bf) bad_bits |= 1u << (8 + g);
+        all_zero &= ze;
+        qtot += qe;
+        if (lane == g) mine_e = qe;
+        if (lane == 8 + g) mine_f = qf;
+    }
+    const int64_t at = (b * 4 + chain) * a.nblocks + blk;
+    if (lane < kParGroups) a.grp[at].qe[lane] = mine_e;
+    else if (lane < 2 * kParGroups) a.grp[at].qf[lane - kParGroups] = mine_f;
+    if (lane == 0) {
+        ParRec r;
+        r.tag = (uint32_t)(eb & 0x1ff);
+        if (all_zero) r.tag |= kParZero;
+        if ((bad_bits & 0xffu) != 0 || qtot >= (1u << 24)) r.tag |= kParBad;
+        if (gstar < kParGroups) r.tag |= kParHint | ((uint32_t)gstar << 16);
+        r.qtot = qtot; r.bad = bad_bits; r.pad = 0;
+        a.rec[at] = r;
+    }
+}
+
+// squares of `count` frames of one chain, starting at frame f0 of stream b, into dst (4 per lane and round)
+template <bool MONO>
+__device__ __forceinline__ void par_load_squares(const RArgs &a, int64_t b, int chain, int64_t f0, int count, float *dst, int lane)
+{
+    const bool from_x = chain < 2;
+    const int ch = chain & 1;
+    if (from_x && MONO) {
+        const v4i rs = make_rsrc(a.x + b * a.n + f0, (a.n - f0) * 4);
+        for (int u = 0; u < count; u += 256) {
+            const int fr = u + 4 * lane;
+            const float s0 = buf_load1(rs, (fr + 0) * 4, 0, 0), s1 = buf_load1(rs, (fr + 1) * 4, 0, 0);
+            const float s2 = buf_load1(rs, (fr + 2) * 4, 0, 0), s3 = buf_load1(rs, (fr + 3) * 4, 0, 0);
+            *(float4 *)(dst + fr) = make_float4(s0 * s0, s1 * s1, s2 * s2, s3 * s3);
+        }
+    } else {
+        const float *src = (from_x ? a.x : a.y) + (b * a.n + f0) * 2 + ch;
+        const v4i rs = make_rsrc(src, ((a.n - f0) * 2 - ch) * 4);
+        for (int u = 0; u < count; u += 256) {
+            const int fr = u + 4 * lane;
+            const float s0 = buf_load1(rs, (fr + 0) * 8, 0, 0), s1 = buf_load1(rs, (fr + 1) * 8, 0, 0);
+            const float s2 = buf_load1(rs, (fr + 2) * 8, 0, 0), s3 = buf_load1(rs, (fr + 3) * 8, 0, 0);
+            *(float4 *)(dst + fr) = make_float4(s0 * s0, s1 * s1, s2 * s2, s3 * s3);
+        }
+    }
+}
+
+// inclusive prefix sum over the wave's lanes (DPP row shifts, then the row totals)
+__device__ __forceinline__ uint32_t wave_prefix_u32(uint32_t x, int lane)
+{
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)x, sh);
+        if (lane >= sh) x += up;
+    }
+    return x;
+}
+
+// the 256 dependent float32 additions of one group (every lane runs the chain on broadcast reads)
+__device__ __forceinline__ float par_add_group(const float *sqs, float t)
+{
+#pragma unroll 1
+    for (int i = 0; i < kSeqGroup; i += 16) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const float4 *)(sqs + i + 4 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { t = t + v[u].x; t = t + v[u].y; t = t + v[u].z; t = t + v[u].w; }
+    }
+    return t;
+}
+
+// one wave per (stream, chain): blockIdx.x = stream * 4 + chain
+template <bool MONO>
+__global__ __launch_bounds__(64) void rms_par_stitch_kernel(const RArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float crossing[kParSlots][kSeqGroup];      // squares of the hinted groups g*
+    __shared__ uint32_t grp_lds[kParSlots][2 * kParGroups];                            // and their blocks' group tallies
+    __shared__ __attribute__((aligned(16))) float scratch[kSeqGroup];                  // a group fetched on demand
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x >> 2;
+    const int chain = blockIdx.x & 3;
+    const ParRec *rec = a.rec + (b * 4 + chain) * a.nblocks;
+    const ParGrp *grp = a.grp + (b * 4 + chain) * a.nblocks;
+
+    // the blocks in which the sum is expected to cross a binade: start the loads of their group g* and of
+    // their group tallies now, so that the walk below never waits for memory there
+    int slots = 0;
+    for (int base = 1; base < a.nblocks && slots < kParSlots; base += 64) {
+        const int mine = base + lane;
+        const uint32_t tag = mine < a.nblocks ? rec[mine].tag : 0u;
+        uint64_t m = __ballot((tag & kParHint) != 0);
+        while (m != 0 && slots < kParSlots) {
+            const int i = __builtin_ctzll(m);
+            m &= m - 1;
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tag, i);
+            const int64_t f0 = (int64_t)(base + i) * kParFrames + (int64_t)((t >> 16) & 7u) * kSeqGroup;
+            par_load_squares<MONO>(a, b, chain, f0, kSeqGroup, crossing[slots], lane);
+            if (lane < 2 * kParGroups) grp_lds[slots][lane] = ((const uint32_t *)&grp[base + i])[lane];
+            ++slots;
+        }
+    }
+    float acc = a.first[b * 4 + chain];
+    int hints_before = 0;                                  // hinted blocks in earlier chunks (slots are in block order)
+    ParRec nxt = {kParZero, 0u, 0u, 0u};
+    if (1 + lane < a.nblocks) nxt = rec[1 + lane];
+    for (int base = 1; base < a.nblocks; base += 64) {
+        const ParRec r = nxt;
+        nxt = ParRec{kParZero, 0u, 0u, 0u};
+        if (base + 64 + lane < a.nblocks) nxt = rec[base + 64 + lane];     // in flight while this chunk is walked
+        const int count = min(64, a.nblocks - base);
+        const uint64_t hint_mask = __ballot((r.tag & kParHint) != 0);      // a hinted block may also be accepted in a run
+        int cur = 0;
+        while (cur < count) {
+            // every block from `cur` on that can be settled against acc's binade, as far as the integer
+            // sum stays inside it: one prefix sum accepts the whole run
+            const uint32_t ab = __float_as_uint(acc);
+            const uint32_t eb = ab >> 23;
+            const bool zero = (r.tag & kParZero) != 0;
+            const bool plain = zero || ((r.tag & kParBad) == 0 && (r.tag & 0x1ffu) == eb);
+            const uint32_t q = (lane >= cur && plain && !zero) ? r.qtot : 0u;
+            const uint32_t pfx = wave_prefix_u32(q, lane);
+            const uint32_t mant = (ab & 0x7fffffu) | 0x800000u;
+            const bool fits = lane < cur || (plain && (zero || (eb >= 23 && eb < 255 && mant + pfx < (1u << 24))));
+            uint64_t stop = __ballot(!fits);
+            if (count < 64) stop |= ~0ull << count;
+            const int f = stop ? (int)__builtin_ctzll(stop) : 64;           // first block that does not fit
+            if (f > cur) {
+                const uint32_t add = (uint32_t)__builtin_amdgcn_readlane((int)pfx, f - 1);
+                if (add != 0) acc = __uint_as_float((eb << 23) | ((mant + add) & 0x7fffffu));
+                cur = f;
+                continue;
+            }
+            // block `cur` needs care: group by group, each either one integer add (its tally against the
+            // binade acc is really in) or its 256 dependent additions - exact whatever the data
+            const uint32_t tag = (uint32_t)__builtin_amdgcn_readlane((int)r.tag, cur);
+            const uint32_t bad = (uint32_t)__builtin_amdgcn_readlane((int)r.bad, cur);
+            const int blk = base + cur;
+            const bool hinted = (tag & kParHint) != 0;
+            const int slot = hinted ? hints_before + (int)__builtin_popcountll(hint_mask & ((1ull << cur) - 1ull)) : -1;
+            ++cur;
+            if (a.debug_skip_slow) continue;              // timing experiments only (variant bit 18): wrong sums
+            const int e0 = (int)(tag & 0x1ffu);
+            const int gstar = (int)((tag >> 16) & 7u);
+            uint32_t gq = 0;                               // lane g: qe[g], lane 8 + g: qf[g]
+            if (slot >= 0 && slot < slots) { if (lane < 2 * kParGroups) gq = grp_lds[slot][lane]; }
+            else if (lane < 2 * kParGroups) gq = ((const uint32_t *)&grp[blk])[lane];
+            for (int g = 0; g < kParGroups; ++g) {
+                const uint32_t cb = __float_as_uint(acc);
+                const int k = (int)(cb >> 23) - e0;       // 0: still in the predicted binade, 1: the next one
+                const uint32_t m2 = (cb & 0x7fffffu) | 0x800000u;
+                if ((k == 0 || k == 1) && e0 >= 23 && e0 + k < 255 && !((bad >> (8 * k + g)) & 1u)) {
+                    const uint32_t qg = (uint32_t)__builtin_amdgcn_readlane((int)gq, 8 * k + g);
+                    if (m2 + qg < (1u << 24)) {
+                        acc = __uint_as_float((cb & 0xff800000u) | ((m2 + qg) & 0x7fffffu));
+                        continue;
+                    }
+                }
+                const float *sqs = crossing[slot >= 0 && slot < slots ? slot : 0];
+                if (!(slot >= 0 && slot < slots && g == gstar)) {
+                    par_load_squares<MONO>(a, b, chain, (int64_t)blk * kParFrames + (int64_t)g * kSeqGroup, kSeqGroup, scratch, lane);
+                    sqs = scratch;
+                }
+                acc = par_add_group(sqs, acc);
+            }
+        }
+        hints_before += (int)__builtin_popcountll(hint_mask);
+    }
+    if (lane == 0) a.partials[b * 4 + chain] = (double)acc;
+}
+
 // Pass 2: y[:, c] *= scale[c]
 __global__ __launch_bounds__(kEpiThreads) void epilogue_scale_kernel(const EArgs a)
 {
