@@ -224,8 +224,7 @@ def cfg4_strong(torch, dist, vnd, _native, ctx, table_image, mode, world, rank, 
     from vndecorrelate_amd.distributed import shard_range
     table = _native.TapTable.from_bytes(ctx, table_image)
     streams, n = 1024, 48000
-    lo, hi = shard_range(streams, world, rank)
-    mine = hi - lo
+    _, mine = shard_range(streams, world, rank)            # (first stream, count) of this rank's contiguous block
     # rotate enough distinct shard buffers that a step streams from HBM (a 1/8 shard is 49 MB)
     buffers = max(1, int(np.ceil(600e6 / max(1, mine * n * CHANNELS * 4 * 2))))
     gen = torch.Generator(device=device)

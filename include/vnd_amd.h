@@ -222,6 +222,17 @@ vnd_status vnd_haas_f64_host(vnd_ctx *ctx, const float *x, double *y, int64_t ba
                              int32_t in_channels, int32_t delay_frames, int32_t delayed_channel,
                              int32_t ms_mode, int32_t use_width, double width);
 
+/* ---- host staging memory ---------------------------------------------------------
+ * The reference returns a freshly allocated array from every call (out = np.zeros(...),
+ * decorrelation.py:647).  A fresh pageable buffer costs a page fault per 4 KiB and a staged,
+ * host-blocking download; page-locked memory takes the GPU's DMA directly.  These allocate /
+ * release page-locked host memory (hipHostMalloc) for the "*_host" calls' buffers - the Python
+ * layer draws its result arrays from a pool of them.  Any host pointer is accepted by the
+ * "*_host" calls; pinned ones are just faster.  The "*_host" calls themselves cut a batch into
+ * groups of streams on two HIP streams, so uploads, kernels and downloads overlap.        */
+vnd_status vnd_host_alloc(int64_t bytes, void **ptr);
+vnd_status vnd_host_free(void *ptr);
+
 /* ---- measurement helpers (used by bench.py; not on the data path) ---------- */
 /* Launches the convolve `iters` times back to back on `hip_stream`, cycling
  * through `n_buffers` (x,y) pairs laid out at x_dev + i*stride_elems, and

@@ -1,0 +1,103 @@
+"""GPU tier: the many-stream mode with more than one rank on real hardware, and cfg4 at full size.
+
+Two ranks, one process each (torch.multiprocessing): with two or more GPUs they use `nccl` (RCCL over
+xGMI) and one device each - the production configuration; on a one-GPU box both ranks share device 0
+and broadcast over `gloo`, which still drives the product code end to end: table built on rank 0 only,
+broadcast, contiguous shards, device-resident sharded convolution, no data-path collective."""
+import hashlib
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, backend, n_devices, result_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    device_index = rank % n_devices
+    os.environ['VND_DEVICE'] = str(device_index)
+    import sys
+    import pathlib
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(device_index)
+    device = torch.device('cuda', device_index)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import vndecorrelate_amd.decorrelation as vnd
+        from oracle import vnd_oracle as O
+        from vndecorrelate_amd.distributed import ShardedDecorrelator
+        from vndecorrelate_amd.taps import function_path_arrays
+        arrays = None
+        fir = O.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1)
+        if rank == 0:                                   # only the source rank builds the table
+            arrays = function_path_arrays(vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2,
+                                                                    sample_rate_hz=48000, seed=1))
+        sharded = ShardedDecorrelator(arrays, src=0, device=device if backend == 'nccl' else None)
+        streams, n = 7, 30000                            # ragged: 4 + 3
+        x_all = np.random.default_rng(17).uniform(-1, 1, (streams, n, 2)).astype(np.float32)
+        start, count = sharded.shard(streams)
+        x_local = torch.from_numpy(x_all[start:start + count]).to(device)
+        y_exact = sharded.convolve_local_device(x_local, mode=vnd.MODE_EXACT)
+        y_fast = sharded.convolve_local_device(x_local, mode=vnd.MODE_FAST)
+        torch.cuda.synchronize()
+        ok = True
+        for i in range(count):
+            want = O.convolve_velvet_noise(x_all[start + i], fir)
+            ok &= bool(np.array_equal(y_exact[i].cpu().numpy(), want))
+            ok &= bool(np.max(np.abs(y_fast[i].cpu().numpy() - want)) <= 1e-6 * np.max(np.abs(want)))
+        # host-array form agrees
+        ok &= bool(np.array_equal(sharded.convolve_local(x_all[start:start + count], vnd.MODE_EXACT), y_exact.cpu().numpy()))
+        with open(os.path.join(result_dir, f'rank{rank}.txt'), 'w') as f:
+            f.write(f'{int(ok)} {start} {count} {backend} {device_index}')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_shard_on_the_gpu(tmp_path):
+    import torch
+    import torch.multiprocessing as mp
+    n_devices = torch.cuda.device_count()
+    if n_devices < 1:
+        pytest.skip('needs a GPU')
+    backend = 'nccl' if n_devices >= 2 else 'gloo'
+    mp.spawn(_rank_main, args=(2, _free_port(), backend, n_devices, str(tmp_path)), nprocs=2, join=True)
+    spans = []
+    for r in range(2):
+        ok, start, count, used, dev = (tmp_path / f'rank{r}.txt').read_text().split()
+        assert ok == '1', f'rank {r} disagrees with the oracle ({used}, device {dev})'
+        spans.append((int(start), int(count)))
+    assert spans == [(0, 4), (4, 3)]
+
+
+def test_cfg4_full_size_is_bit_exact_per_stream():
+    """BASELINE configs[3] whole: 1024 independent 1 s stereo streams in one launch, exact mode against
+    the C oracle (sha256 per stream), fast mode within 1e-6 of peak, through the host batch API."""
+    import vndecorrelate_amd.decorrelation as vnd
+    from oracle import c_oracle
+    from oracle import vnd_oracle as O
+    fir = vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1)
+    x = np.random.default_rng(4).uniform(-1, 1, (1024, 48000, 2)).astype(np.float32)
+    offs, idx, w = O.fir_to_taps(fir)
+    want = c_oracle.convolve(x, offs, idx, w, threads=min(os.cpu_count() or 1, 16))
+    got = vnd.convolve_velvet_noise_batched(x, fir, mode=vnd.MODE_EXACT)
+    for b in range(0, 1024):
+        if hashlib.sha256(got[b].tobytes()).digest() != hashlib.sha256(want[b].tobytes()).digest():
+            raise AssertionError(f'stream {b} differs from the oracle')
+    fast = vnd.convolve_velvet_noise_batched(x, fir, mode=vnd.MODE_FAST)
+    assert np.max(np.abs(fast - want)) <= 1e-6 * np.max(np.abs(want))
+    # the pipelined host path returns page-locked result arrays; they behave like any other ndarray
+    assert fast.flags.writeable and fast.dtype == np.float32 and fast.shape == x.shape
+    del got, fast

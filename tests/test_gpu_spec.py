@@ -157,7 +157,7 @@ def test_linearity_and_shift_at_full_size(env, golden):
     d, native, ctx = env
     ctx.set_variant(-1)
     table = _table(native, ctx, golden.fir('g48k_k30'))
-    pool, n = 32, 240000
+    pool, n = 40, 240000
     x = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1)
     y, y2 = torch.empty_like(x), torch.empty_like(x)
     s = torch.cuda.current_stream().cuda_stream

@@ -10,6 +10,7 @@ import ctypes
 import os
 import pathlib
 import threading
+import weakref
 from typing import Optional
 
 import numpy as np
@@ -102,6 +103,8 @@ SIGNATURES = {
                                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                  ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,
                                                  _c_f32p]),
+    'vnd_host_alloc': (ctypes.c_int, [ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
+    'vnd_host_free': (ctypes.c_int, [ctypes.c_void_p]),
     'vnd_spec_kernel_source': (ctypes.c_int, [ctypes.c_int32, _c_i32p, _c_i32p, _c_f32p, ctypes.c_char_p,
                                               ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
     'vnd_set_variant': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
@@ -177,6 +180,80 @@ def _check(rc: int, what: str):
 
 def _ptr(a: Optional[np.ndarray], ctype):
     return None if a is None else a.ctypes.data_as(ctypes.POINTER(ctype))
+
+
+class _PinnedPool:
+    """Result arrays of the host API in page-locked memory (``vnd_host_alloc``).
+
+    The reference allocates its result afresh in every call (decorrelation.py:647); a fresh pageable
+    array of hundreds of MB costs tens of milliseconds of page faults and a staged download.  Blocks
+    are recycled when the NumPy array (and every view of it) is garbage-collected; the pool keeps at
+    most ``VND_PINNED_POOL_MB`` (default 2048; 0 turns it off) of idle blocks.  Results below 1 MiB stay
+    ordinary NumPy arrays."""
+
+    MIN_BYTES = 1 << 20
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._free: dict = {}            # rounded size -> [ptr, ...]
+        self._idle = 0
+        self.limit = int(os.environ.get('VND_PINNED_POOL_MB', '2048')) << 20
+        self.hits = self.misses = 0
+
+    @staticmethod
+    def _round(nbytes: int) -> int:
+        size = 1 << 20
+        while size < nbytes:
+            size <<= 1
+        return size if size - nbytes <= nbytes // 4 else ((nbytes + (1 << 20) - 1) >> 20) << 20
+
+    def empty(self, shape, dtype=np.float32) -> np.ndarray:
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        if self.limit <= 0 or nbytes < self.MIN_BYTES:
+            return np.empty(shape, dtype)
+        size = self._round(nbytes)
+        ptr = None
+        with self._lock:
+            blocks = self._free.get(size)
+            if blocks:
+                ptr = blocks.pop()
+                self._idle -= size
+                self.hits += 1
+        if ptr is None:
+            h = ctypes.c_void_p()
+            try:
+                rc = load_library().vnd_host_alloc(size, ctypes.byref(h))
+            except Exception:
+                rc = 1
+            if rc != 0 or not h.value:
+                return np.empty(shape, dtype)          # no pinned memory to be had: an ordinary array
+            ptr = h.value
+            self.misses += 1
+        buf = (ctypes.c_char * nbytes).from_address(ptr)
+        weakref.finalize(buf, self._release, ptr, size)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def _release(self, ptr: int, size: int):
+        with self._lock:
+            if self._idle + size <= self.limit:
+                self._free.setdefault(size, []).append(ptr)
+                self._idle += size
+                return
+        try:
+            load_library().vnd_host_free(ctypes.c_void_p(ptr))
+        except Exception:
+            pass
+
+    def trim(self):
+        with self._lock:
+            blocks = [p for v in self._free.values() for p in v]
+            self._free.clear()
+            self._idle = 0
+        for p in blocks:
+            load_library().vnd_host_free(ctypes.c_void_p(p))
+
+
+pinned_pool = _PinnedPool()
 
 
 class Context:
@@ -305,7 +382,7 @@ class TapTable:
             batch, n, c = x.shape
         else:
             raise ValueError(f'expected (n, C) or (batch, n, C), got {x.shape}')
-        y = np.empty(x.shape[:-1] + (self.num_channels,), np.float32)
+        y = pinned_pool.empty(x.shape[:-1] + (self.num_channels,), np.float32)
         return batch, n, c, y
 
     def convolve_host(self, x: np.ndarray, mode: int = MODE_EXACT) -> np.ndarray:

@@ -53,6 +53,7 @@ struct vnd_ctx {
     hipDeviceProp_t prop{};
     int lds_limit = 65536;        // bytes of LDS one workgroup may use
     hipStream_t stream = nullptr; // used by the *_host entry points
+    hipStream_t stream2 = nullptr;    // second lane of the chunked host pipeline
     float *scratch_x = nullptr, *scratch_y = nullptr;
     size_t scratch_elems = 0;
     char *work = nullptr;         // grow-only workspace of the *_host entry points
@@ -619,7 +620,9 @@ vnd_status vnd_ctx_create(int32_t device, vnd_ctx **out)
     else
         c->lds_limit = (int)c->prop.sharedMemPerBlock;
     if (c->lds_limit < 65536) c->lds_limit = 65536;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) {
+        if (c->stream) (void)hipStreamDestroy(c->stream);
         delete c;
         return fail(VND_ERR_HIP, "hipStreamCreate failed");
     }
@@ -635,6 +638,7 @@ vnd_status vnd_ctx_destroy(vnd_ctx *c)
     if (c->scratch_y) (void)hipFree(c->scratch_y);
     if (c->work) (void)hipFree(c->work);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
     return VND_OK;
 }
@@ -852,6 +856,15 @@ static vnd_status ensure_scratch(vnd_ctx *ctx, size_t elems)
     return VND_OK;
 }
 
+// groups of streams the host entry points pipeline a batch in: one below 16 MB of traffic, then about
+// 32 MB each, at most 16
+static int host_chunks(int64_t batch, size_t bytes)
+{
+    if (batch < 2 || bytes < ((size_t)16 << 20)) return 1;
+    const size_t want = (bytes + ((size_t)32 << 20) - 1) / ((size_t)32 << 20);
+    return (int)std::min<int64_t>(std::min<int64_t>(batch, 16), (int64_t)std::max<size_t>(want, 2));
+}
+
 static vnd_status ensure_work(vnd_ctx *ctx, size_t bytes)
 {
     if (bytes <= ctx->work_bytes) return VND_OK;
@@ -907,12 +920,23 @@ static vnd_status convolve_host(vnd_ctx *ctx, const vnd_taps *t, const float *x,
     const size_t in_elems = (size_t)batch * n * Cx, out_elems = (size_t)batch * n * C;
     st = ensure_scratch(ctx, out_elems);
     if (st != VND_OK) return st;
-    HIP_TRY(hipMemcpyAsync(ctx->scratch_x, x, in_elems * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    st = launch(ctx, t, ctx->scratch_x, ctx->scratch_y, batch, n, C, mode, ctx->stream, nullptr, Cx);
-    if (st != VND_OK) return st;
-    HIP_TRY(hipMemcpyAsync(y, ctx->scratch_y, out_elems * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    // A batch is cut into groups of whole streams that alternate between two HIP streams: the upload of
+    // one group runs beside the kernel and the download of the one before (PCIe is full duplex, and a
+    // download into pinned memory - vnd_host_alloc - does not hold the host thread).
+    const int chunks = host_chunks(batch, (in_elems + out_elems) * sizeof(float));
+    for (int c = 0; c < chunks; ++c) {
+        const int64_t b0 = batch * c / chunks, b1 = batch * (c + 1) / chunks;
+        if (b1 == b0) continue;
+        hipStream_t s = (c & 1) ? ctx->stream2 : ctx->stream;
+        const size_t xo = (size_t)b0 * n * Cx, yo = (size_t)b0 * n * C;
+        HIP_TRY(hipMemcpyAsync(ctx->scratch_x + xo, x + xo, (size_t)(b1 - b0) * n * Cx * sizeof(float), hipMemcpyHostToDevice, s));
+        st = launch(ctx, t, ctx->scratch_x + xo, ctx->scratch_y + yo, b1 - b0, n, C, mode, s, nullptr, Cx);
+        if (st != VND_OK) break;
+        HIP_TRY(hipMemcpyAsync(y + yo, ctx->scratch_y + yo, (size_t)(b1 - b0) * n * C * sizeof(float), hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return VND_OK;
+    if (chunks > 1) HIP_TRY(hipStreamSynchronize(ctx->stream2));
+    return st;
 }
 
 vnd_status vnd_convolve_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
@@ -969,6 +993,21 @@ vnd_status vnd_time_convolve_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const floa
     if (st != VND_OK) return st;
     if (he != hipSuccess) return fail(VND_ERR_HIP, "timing: %s", hipGetErrorString(he));
     *avg_ms = ms / iters;
+    return VND_OK;
+}
+
+vnd_status vnd_host_alloc(int64_t bytes, void **ptr)
+{
+    if (!ptr || bytes <= 0) return fail(VND_ERR_INVALID, "bad host allocation request");
+    *ptr = nullptr;
+    hipError_t e = hipHostMalloc(ptr, (size_t)bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(VND_ERR_NOMEM, "hipHostMalloc(%lld): %s", (long long)bytes, hipGetErrorString(e)); }
+    return VND_OK;
+}
+
+vnd_status vnd_host_free(void *ptr)
+{
+    if (ptr && hipHostFree(ptr) != hipSuccess) { (void)hipGetLastError(); return fail(VND_ERR_HIP, "hipHostFree failed"); }
     return VND_OK;
 }
 
@@ -1211,13 +1250,29 @@ static vnd_status decorrelate_host(vnd_ctx *ctx, const vnd_taps *t, const float 
     vnd_decorrelate_workspace_bytes(batch, n, C, &ws);
     st = ensure_work(ctx, (size_t)ws);
     if (st != VND_OK) return st;
-    HIP_TRY(hipMemcpyAsync(ctx->scratch_x, x, in_elems * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    st = decorrelate_dev(ctx, t, ctx->scratch_x, ctx->scratch_y, batch, n, Cx, C, mode, ms_encode, use_width,
-                         width, normalize, eps, ctx->work, ws, ctx->stream);
-    if (st != VND_OK) return st;
-    HIP_TRY(hipMemcpyAsync(y, ctx->scratch_y, out_elems * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    const int chunks = host_chunks(batch, (in_elems + out_elems) * sizeof(float));
+    if (chunks > 1) {
+        // one workspace per pipeline lane: the two lanes' epilogues run side by side
+        const int64_t per = (batch + chunks - 1) / chunks;
+        vnd_decorrelate_workspace_bytes(per, n, C, &ws);
+        ws = (ws + 255) & ~(int64_t)255;
+        st = ensure_work(ctx, (size_t)ws * 2);
+        if (st != VND_OK) return st;
+    }
+    for (int c = 0; c < chunks; ++c) {
+        const int64_t b0 = batch * c / chunks, b1 = batch * (c + 1) / chunks;
+        if (b1 == b0) continue;
+        hipStream_t s = (c & 1) ? ctx->stream2 : ctx->stream;
+        const size_t xo = (size_t)b0 * n * Cx, yo = (size_t)b0 * n * C;
+        HIP_TRY(hipMemcpyAsync(ctx->scratch_x + xo, x + xo, (size_t)(b1 - b0) * n * Cx * sizeof(float), hipMemcpyHostToDevice, s));
+        st = decorrelate_dev(ctx, t, ctx->scratch_x + xo, ctx->scratch_y + yo, b1 - b0, n, Cx, C, mode, ms_encode, use_width,
+                             width, normalize, eps, ctx->work + (size_t)(c & 1) * (size_t)ws, ws, s);
+        if (st != VND_OK) break;
+        HIP_TRY(hipMemcpyAsync(y + yo, ctx->scratch_y + yo, (size_t)(b1 - b0) * n * C * sizeof(float), hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return VND_OK;
+    if (chunks > 1) HIP_TRY(hipStreamSynchronize(ctx->stream2));
+    return st;
 }
 
 vnd_status vnd_decorrelate_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,

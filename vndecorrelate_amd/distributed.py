@@ -97,6 +97,26 @@ class ShardedDecorrelator:
             return np.zeros(x_local.shape, np.float32)
         return self._convolve(x_local, mode)
 
+    def convolve_local_device(self, x_local, y_local=None, mode: int = 2, stream: Optional[int] = None):
+        """Device-resident form of :meth:`convolve_local`: ``x_local`` is this rank's ``(b_local, n, C)``
+        float32 block already on ITS GPU (a torch tensor); the kernels are enqueued on ``stream`` (default:
+        torch's current stream) and the result tensor is returned without a host round trip - shards stay
+        resident between the table broadcast and whatever consumes the output."""
+        import torch
+        table = getattr(self._convolve, 'table', None)
+        if table is None:
+            raise RuntimeError('the device-resident path needs the GPU backend')
+        if x_local.dim() != 3 or x_local.dtype != torch.float32 or not x_local.is_contiguous() or not x_local.is_cuda:
+            raise ValueError('expected a contiguous float32 CUDA tensor (streams, n, C)')
+        b_local, n, c = x_local.shape
+        if y_local is None:
+            y_local = torch.empty((b_local, n, table.num_channels), dtype=torch.float32, device=x_local.device)
+        if b_local:
+            with torch.cuda.device(x_local.device):
+                s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+                table.convolve_device(x_local.data_ptr(), y_local.data_ptr(), b_local, n, c, mode, s)
+        return y_local
+
     def convolve_global(self, x_all: np.ndarray, mode: int = 2) -> np.ndarray:
         """Convenience for small jobs: every rank passes the same full batch and gets
         back only ITS block; stack blocks in rank order to rebuild the batch."""
