@@ -32,25 +32,56 @@ def _macro(src, name):
     return int(re.search(rf'#define {name} (\d+)', src).group(1))
 
 
+def _array(src, name):
+    body = re.search(rf'{name}\[1\]\[\d+\] = \{{\{{([^}}]*)\}}', src).group(1).strip(',').split(',')
+    return body
+
+
 def test_source_carries_the_table(native, golden):
+    """The generated read schedule covers every (tap, row) exactly once: each unique LDS read
+    (plane, (i & ~1) + 2*NT*row) lists the FMAs it feeds."""
     fir = golden.fir('g48k_k30')
     offs, idx, w = _table(fir)
     src = native.spec_kernel_source(offs, idx, w)
     assert _macro(src, 'VS_C') == 2 and _macro(src, 'VS_GROUPS') == 1
-    n = int(re.search(r'VS_N\[1\] = \{(\d+),', src).group(1))
-    assert n == len(idx) == 60
-    off_list = [int(v) for v in re.search(r'VS_OFF\[1\]\[\d+\] = \{\{([^}]*)\}', src).group(1).strip(',').split(',')]
-    set_list = [int(v) for v in re.search(r'VS_SET\[1\]\[\d+\] = \{\{([^}]*)\}', src).group(1).strip(',').split(',')]
-    w_list = [float.fromhex(v.rstrip('f')) for v in re.search(r'VS_W\[1\]\[\d+\] = \{\{([^}]*)\}', src).group(1).strip(',').split(',')]
-    # every tap exactly once: (channel, index & ~1, parity, weight) as a multiset
-    got = sorted((s >> 1, o, s & 1, np.float32(x)) for o, s, x in zip(off_list, set_list, w_list))
-    want = sorted((c, int(i) & ~1, int(i) & 1, np.float32(wt)) for c in range(2)
-                  for i, wt in zip(idx[offs[c]:offs[c + 1]], w[offs[c]:offs[c + 1]]))
-    assert got == want
+    nt, rr = _macro(src, 'VS_NT'), _macro(src, 'VS_RR')
+    n_reads = int(re.search(r'VS_RD_N\[1\] = \{(\d+),', src).group(1))
+    plane = [int(v) for v in _array(src, 'VS_RD_PLANE')][:n_reads]
+    off = [int(v) for v in _array(src, 'VS_RD_OFF')][:n_reads]
+    first = [int(v) for v in _array(src, 'VS_RD_FIRST')][:n_reads + 1]
+    cs_set = [int(v) for v in _array(src, 'VS_CS_SET')]
+    cs_row = [int(v) for v in _array(src, 'VS_CS_ROW')]
+    cs_w = [float.fromhex(v.rstrip('f')) for v in _array(src, 'VS_CS_W')]
+    assert len(set(zip(plane, off))) == n_reads, 'a read is scheduled twice'
+    assert first[0] == 0 and first[-1] == len(idx) * rr and n_reads <= len(idx) * rr
+    got = []
+    for k in range(n_reads):
+        for m in range(first[k], first[k + 1]):
+            assert cs_set[m] >> 1 == plane[k]
+            got.append((cs_set[m] >> 1, off[k] - 2 * nt * cs_row[m], cs_set[m] & 1, cs_row[m], np.float32(cs_w[m])))
+    want = sorted((c, int(i) & ~1, int(i) & 1, j, np.float32(wt)) for c in range(2)
+                  for i, wt in zip(idx[offs[c]:offs[c + 1]], w[offs[c]:offs[c + 1]]) for j in range(rr))
+    assert sorted(got) == want
+    # the span-end chain repeats row 0's odd accumulation order
+    for c in range(2):
+        chain = [(off[k], np.float32(cs_w[m])) for k in range(n_reads) for m in range(first[k], first[k + 1])
+                 if cs_set[m] == 2 * c + 1 and cs_row[m] == 0]
+        body = re.search(r'VS_ODD_OFF\[1\]\[2\]\[\d+\] = \{\{(.*?)\},\},\};', src).group(1)
+        offs_c = [int(v) for v in body.split('},{')[c].strip('{},').split(',') if v][:len(chain)]
+        assert offs_c == [o for o, _ in chain]
     # the ring holds one tile plus the halo plus the slot being refilled
-    T = 2 * _macro(src, 'VS_NT') * _macro(src, 'VS_RR')
+    T = 2 * nt * rr
     assert (_macro(src, 'VS_PP') - 1) * T >= T + int(idx.max()) + 1
     assert _macro(src, 'VS_PP') % _macro(src, 'VS_DD') == 0
+
+
+def test_rows_share_reads_on_a_dense_table(native, golden):
+    """128 taps per channel: taps whose offsets differ by a multiple of the row stride share their reads."""
+    fir = golden.fir('g48k_k128_u')
+    offs, idx, w = _table(fir)
+    src = native.spec_kernel_source(offs, idx, w)
+    n_reads = int(re.search(r'VS_RD_N\[1\] = \{(\d+),', src).group(1))
+    assert n_reads < 0.9 * len(idx) * _macro(src, 'VS_RR')
 
 
 def test_scope_checks(native):
@@ -63,9 +94,14 @@ def test_scope_checks(native):
         native.spec_kernel_source(offs[:3], np.array([1, 2], np.int32), np.array([1.0, np.inf], np.float32))
 
 
-@pytest.mark.parametrize('gname', ['g48k_k30', 'g96k_k64_c8'])
+@pytest.mark.parametrize('gname', ['g48k_k30', 'four_channels'])
 def test_source_compiles_for_gfx950_with_the_intended_isa(native, golden, tmp_path, gname):
-    fir = golden.fir(gname)
+    if gname == 'four_channels':                      # two channel pairs: the dispatch over pairs compiles too
+        a, b = golden.fir('g48k_k30'), golden.fir('g44k_k30')
+        fir = np.zeros((max(len(a), len(b)), 4), np.float32)
+        fir[:len(a), :2], fir[:len(b), 2:] = a, b
+    else:
+        fir = golden.fir(gname)
     offs, idx, w = _table(fir)
     src = native.spec_kernel_source(offs, idx, w)
     f = tmp_path / 'k.hip'
@@ -82,10 +118,11 @@ def test_source_compiles_for_gfx950_with_the_intended_isa(native, golden, tmp_pa
     assert count.get('flat_load_dwordx2', 0) == 0, 'LDS reads fell back to flat loads'
     groups, pp, rr = fir.shape[1] // 2, _macro(src, 'VS_PP'), _macro(src, 'VS_RR')
     taps = len(idx)
-    # one aligned ds_read_b64 and one packed FMA per (tap, row), in each of the PP unrolled slot phases
-    # (+ the span-end chain over the odd taps, which hipcc may pack across the two channels)
+    reads = sum(int(v) for v in re.search(r'VS_RD_N\[\d+\] = \{([^}]*)\}', src).group(1).strip(',').split(','))
+    # one packed FMA per (tap, row) and one aligned ds_read_b64 per unique read, in each of the PP unrolled
+    # slot phases (+ the span-end chain over the odd taps, which hipcc may pack across the two channels)
     assert taps * rr * pp <= count['v_pk_fma_f32'] <= taps * rr * pp + taps
-    assert count['ds_read_b64'] >= taps * rr * pp
+    assert reads * pp <= count['ds_read_b64'] <= reads * pp + 8 * groups * pp
     # no tap read fused into the half-rate two-address forms (the few ds_read2 left are the
     # wave-boundary exchange of the merge, rows x slot phases of them)
     assert count.get('ds_read2st64_b64', 0) == 0 and count.get('ds_read2_b64', 0) <= rr * pp * groups

@@ -10,11 +10,17 @@ from vndecorrelate_amd import _native
 from vndecorrelate_amd.taps import function_path_arrays
 
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 1.5
+which = sys.argv[2] if len(sys.argv) > 2 else 'cfg2'
 ctx = _native.default_context()
-fir = vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1)
+if which == 'cfg3':
+    fir = vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=128, num_outs=2, sample_rate_hz=48000,
+                                    log_distribution_strength=0.0, seed=1)
+    pool, n = 24, 2880000
+else:
+    fir = vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1)
+    pool, n = 128, 480000
 arr = function_path_arrays(fir)
 table = _native.TapTable.create(ctx, arr.tap_offsets, arr.tap_index, arr.tap_weight)
-pool, n = 128, 480000
 x = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1)
 y = torch.empty_like(x)
 stream = torch.cuda.current_stream().cuda_stream
@@ -29,7 +35,7 @@ def rate(variant, label):
         best.append(table.time_device(x.data_ptr(), y.data_ptr(), pool, n, 2, mode=2, n_buffers=1, stride_elems=0,
                                       iters=100, stream=stream))
     tail = best[len(best) // 2:]
-    print(f'{label:28s} {np.mean(tail):.4f} ms/launch {983.04 / np.mean(tail):6.0f} GB/s  (min {min(best):.4f})  {desc}', flush=True)
+    print(f'{label:28s} {np.mean(tail):.4f} ms/launch {8e-6 * pool * n * 2 / np.mean(tail):6.0f} GB/s  (min {min(best):.4f})  {desc}', flush=True)
 
 
 # parity first: spec vs exact (oracle-identical) on a few streams, and the whole pool vs the generic fast kernel
@@ -68,9 +74,8 @@ def env_rate(label, **env):
     rate(-1, f'{label} err={err:.1e}')
 
 
-configs = [dict(), dict(nt=128, rr=4), dict(nt=128, rr=4, dd=2), dict(nt=128, rr=8), dict(nt=128, rr=8, la=1), dict(nt=128, rr=6),
-           dict(nt=64, rr=4), dict(nt=64, rr=8), dict(nt=64, rr=8, dd=3), dict(nt=64, rr=16, la=0), dict(nt=128, rr=4, la=2), dict(nt=128, rr=4, la=6),
-           dict(nt=512, rr=2, dd=3), dict(nt=256, rr=3, dd=3), dict(nt=128, rr=2)]
+configs = [dict(), dict(nt=128, rr=8), dict(nt=64, rr=8), dict(nt=64, rr=8, la=12), dict(nt=128, rr=4, la=8), dict(nt=128, rr=4, la=12),
+           dict(nt=128, rr=8, la=12), dict(nt=64, rr=16, la=12), dict(nt=256, rr=4, la=8), dict(nt=192, rr=4, la=8)]
 for rep in range(2):
     rate(GENERIC, 'generic fast')
     for c in configs:

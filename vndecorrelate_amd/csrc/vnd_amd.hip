@@ -67,7 +67,7 @@ struct vnd_ctx {
     // kernels already opted in to > 64 KiB of dynamic LDS on THIS context's device
     // (hipFuncSetAttribute applies to the current device's copy of the function)
     std::mutex raised_mutex;
-    std::vector<const void *> raised;
+    std::map<const void *, size_t> raised;      // kernel -> dynamic LDS bytes it has been allowed
 };
 
 typedef std::lock_guard<std::mutex> HostLock;
@@ -302,7 +302,7 @@ static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int6
     }
     const int *sizes = fast ? kFastR : kOrderedR;
     const int nsizes = fast ? (int)(sizeof kFastR / sizeof *kFastR) : (int)(sizeof kOrderedR / sizeof *kOrderedR);
-    const size_t limit = (size_t)ctx->lds_limit;
+    const size_t limit = (size_t)ctx->lds_limit - 1024;       // the kernels' static LDS (reduction scratch) shares the 160 KiB
     auto fits = [&](int r_) { return lds_need(nt, cg, r_, t->max_index, bc) <= limit; };
 
     int r = (v >= 0) ? (v & 31) : 0;
@@ -495,6 +495,7 @@ struct EpiFuse {                 // non-null => launch the fused-epilogue instan
     double *partials;
     int ms_encode, use_width, normalize;
     float w_mid, w_side;
+    double *sink = nullptr;      // moments sink: [tiles][groups][8]; the output is reduced, not written
 };
 
 static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
@@ -536,13 +537,16 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
         if (epi) {
             a.epi_partials = epi->partials; a.epi_ms_encode = epi->ms_encode; a.epi_use_width = epi->use_width;
             a.epi_normalize = epi->normalize; a.epi_w_mid = epi->w_mid; a.epi_w_side = epi->w_side;
+            a.sink_partials = epi->sink;
         }
         if (p.lds_bytes > 65536) {           // opt in to > 64 KiB of dynamic LDS, once per (device, kernel)
+            // ask for what the launch needs, not for the whole LDS: a kernel's static LDS (reduction
+            // scratch of the epilogue instantiations) counts against the same 160 KiB
             std::lock_guard<std::mutex> g(ctx->raised_mutex);
-            if (std::find(ctx->raised.begin(), ctx->raised.end(), (const void *)k) == ctx->raised.end()) {
-                HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            ctx->lds_limit));
-                ctx->raised.push_back((const void *)k);
+            size_t &have = ctx->raised[(const void *)k];
+            if (have < p.lds_bytes) {
+                HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+                have = p.lds_bytes;
             }
         }
         hipLaunchKernelGGL(k, dim3(p.nblocks), dim3(p.nt), p.lds_bytes, stream, a);
@@ -1415,6 +1419,33 @@ vnd_status vnd_scan_bank_f32_host(vnd_ctx *ctx, const vnd_taps *t, const float *
     const int32_t pairs = t->C / 2;
     HostLock lock(ctx->host_mutex);
     HIP_TRY(hipSetDevice(ctx->device));
+    // Fused form: the convolution kernel's store phase reduces each tile to the eight moments per
+    // candidate (KArgs.sink_partials) - the [n][2F] output, 1.6 GB there and back for 400 candidates
+    // of a 5.7 s signal, is never written.  Needs the two-channels-per-workgroup epilogue instantiation.
+    if (n > 0 && !(ctx->variant >= 0 && ((ctx->variant >> 16) & 0x100))) {
+        const Plan p = make_plan(ctx, t, 1, n, t->C, mode, in_channels);
+        kern_t k = p.direct ? nullptr
+                            : (mode == VND_MODE_FAST ? fast_epi_kernel(p) : ordered_epi_kernel(p, arithmetic_of(t, mode)));
+        if (k != nullptr && p.cg == 2) {
+            const size_t part_bytes = (size_t)p.tiles * pairs * kMoments * sizeof(double);
+            const size_t out_bytes = (size_t)pairs * kMoments * sizeof(double);
+            st = ensure_scratch(ctx, (size_t)n * in_channels);
+            if (st != VND_OK) return st;
+            st = ensure_work(ctx, part_bytes + out_bytes);
+            if (st != VND_OK) return st;
+            HIP_TRY(hipMemcpyAsync(ctx->scratch_x, x, (size_t)n * in_channels * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+            EpiFuse f{nullptr, 0, 0, 0, 0.0f, 0.0f, (double *)ctx->work};
+            st = launch(ctx, t, ctx->scratch_x, ctx->scratch_y, 1, n, t->C, mode, ctx->stream, &f, in_channels);
+            if (st != VND_OK) return st;
+            MArgs m{};
+            m.partials = (double *)ctx->work; m.moments = (double *)(ctx->work + part_bytes); m.n = n; m.F = pairs; m.chunks = p.tiles;
+            hipLaunchKernelGGL(moments_reduce_kernel, dim3((unsigned)pairs), dim3(kMomThreads), 0, ctx->stream, m);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(moments, ctx->work + part_bytes, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            return VND_OK;
+        }
+    }
     st = ensure_scratch(ctx, (size_t)std::max<int64_t>(n, 1) * t->C);
     if (st != VND_OK) return st;
     int64_t ws = 0;

@@ -28,6 +28,8 @@
 #include <stdint.h>
 #include <utility>
 
+#include "vnd_polar.hpp"
+
 namespace vnd {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -74,6 +76,10 @@ struct KArgs {
     double *__restrict__ epi_partials;      // [batch][tiles][2*C]: sum x_c^2, then sum y_c^2, per tile
     int32_t epi_ms_encode, epi_use_width, epi_normalize;
     float epi_w_mid, epi_w_side;
+    // moments sink (EPI instantiations, candidate scan of SURVEY.md 8 f3): when set, the workgroup's
+    // channel pair is one candidate's (L, R); its tile is reduced to the eight polar moments
+    // (vnd_polar.hpp) and NOT written - y never exists.  [stream][tile][groups][8]
+    double *__restrict__ sink_partials;
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Map
@@ -103,6 +109,33 @@ __device__ __forceinline__ BlockCoord decode_block(const KArgs &a)
     bc.tile = lid % (uint32_t)a.tiles;
     bc.stream = lid / (uint32_t)a.tiles;
     return bc;
+}
+
+// Workgroup reduction of one tile's polar moments into sink_partials (fixed order: deterministic).
+template <int NT>
+__device__ __forceinline__ void sink_reduce_store(const KArgs &a, const BlockCoord &bc, const PolarAcc &acc, int tid)
+{
+    __shared__ double sink_red[NT / 64][kMoments];
+    double v[kMoments];
+    polar_store(v, acc);
+#pragma unroll
+    for (int k = 0; k < kMoments; ++k) {
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) {
+            const double o = __shfl_xor(v[k], sh);
+            v[k] = k == 4 ? fmax(v[k], o) : v[k] + o;
+        }
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < kMoments; ++k) sink_red[tid >> 6][k] = v[k];
+    }
+    __syncthreads();
+    if (tid < kMoments) {
+        double t = sink_red[0][tid];
+        for (int w = 1; w < NT / 64; ++w) t = tid == 4 ? fmax(t, sink_red[w][tid]) : t + sink_red[w][tid];
+        a.sink_partials[(((int64_t)bc.stream * a.tiles + bc.tile) * a.groups + bc.group) * kMoments + tid] = t;
+    }
 }
 
 // ---- global memory: raw buffer descriptors ---------------------------------------
@@ -671,6 +704,7 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
     const int shape = access_shape<CG>(dst, C);
     const int strideG = C / CG;
     float sum_x[CG], sum_y[CG];
+    PolarAcc pacc;
 #pragma unroll
     for (int c = 0; c < CG; ++c) { sum_x[c] = 0.0f; sum_y[c] = 0.0f; }
 #pragma unroll
@@ -696,7 +730,17 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
                 sum_y[c] += v[c] * v[c] + v[CG + c] * v[CG + c];
             }
         }
+        if constexpr (EPI && CG == 2) {
+            if (a.sink_partials != nullptr) {            // frames past the stream's end are (0, 0): r = 0, theta = 0
+                polar_add(pacc, v[0], v[1]);
+                polar_add(pacc, v[2], v[3]);
+                continue;
+            }
+        }
         store_result<CG>(rdst, shape, a.stream_out, q, strideG, C, v);
+    }
+    if constexpr (EPI && CG == 2) {
+        if (a.sink_partials != nullptr) { sink_reduce_store<NT>(a, bc, pacc, tid); return; }
     }
     if constexpr (EPI) {
         if (a.epi_normalize) {
@@ -854,6 +898,7 @@ __global__ __launch_bounds__(NT) void conv_ordered_kernel(const KArgs a)
     const v4i rdst = make_rsrc(dst, bytes_left);
     const int shape = access_shape<CG>(dst, C);
     const int strideG = C / CG;
+    PolarAcc pacc;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         float v[2 * CG];
@@ -864,8 +909,16 @@ __global__ __launch_bounds__(NT) void conv_ordered_kernel(const KArgs a)
             const float2 x0 = *(const float2 *)(lds + 2 * q), x1 = *(const float2 *)(lds + (BC ? 0 : W) + 2 * q);
             const float xin[4] = {x0.x, x1.x, x0.y, x1.y};
             epi_pointwise(a, v, xin);
+            if (a.sink_partials != nullptr) {
+                polar_add(pacc, v[0], v[1]);
+                polar_add(pacc, v[2], v[3]);
+                continue;
+            }
         }
         store_result<CG>(rdst, shape, a.stream_out, tid + NT * j, strideG, C, v);
+    }
+    if constexpr (EPI && CG == 2) {
+        if (a.sink_partials != nullptr) sink_reduce_store<NT>(a, bc, pacc, tid);
     }
 }
 

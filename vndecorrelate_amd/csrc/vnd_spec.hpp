@@ -33,7 +33,7 @@ struct SpecConfig {
     int rr = 2;        // frame pairs per lane and tile
     int pp = 4;        // ring slots
     int dd = 1;        // tiles prefetched ahead
-    int la = 4;        // taps of LDS reads in flight
+    int la = 8;        // LDS reads in flight ahead of the FMAs
     int nt_stores = 0; // non-temporal output stores
     int tile() const { return 2 * nt * rr; }
     size_t lds_bytes() const
@@ -67,10 +67,10 @@ inline int spec_env(const char *name, int fallback)
 inline bool spec_pick_config(const SpecTable &t, size_t lds_limit, int rr_hint, int dd_hint, SpecConfig *out)
 {
     const int reach = (t.max_index | 1) + 1;          // frames past a pair's first frame that an (aligned) read touches
-    // (threads, pairs per lane), best first.  Measured on cfg2 (tools/spec_try.py, two boxes): every
-    // geometry lands within 3 % - the kernel runs on the board's power cap - with 2-wave workgroups
-    // of 1024-frame tiles a little ahead (fewer waves per barrier, 4 workgroups per CU).
-    static const int kShapes[][2] = {{128, 4}, {256, 2}, {128, 2}, {256, 1}, {128, 8}, {256, 4}};
+    // (threads, pairs per lane), best first.  Measured on cfg2 and cfg3 (tools/spec_try.py, several boxes):
+    // the geometries land within 7 % of each other - the kernel runs on the board's power cap - with
+    // 3-wave workgroups of 1536-frame tiles ahead (3 ring slots, 4 workgroups per CU).
+    static const int kShapes[][2] = {{192, 4}, {256, 4}, {128, 4}, {256, 2}, {128, 2}, {256, 1}};
     const int nt_env = spec_env("VND_SPEC_NT", 0);
     rr_hint = spec_env("VND_SPEC_RR", rr_hint);
     dd_hint = spec_env("VND_SPEC_DD", dd_hint);
@@ -123,77 +123,111 @@ inline std::string spec_prologue(const SpecTable &t, const SpecConfig &c)
     spec_append(s, "#define VS_NT %d\n#define VS_RR %d\n#define VS_PP %d\n#define VS_DD %d\n#define VS_LA %d\n", c.nt, c.rr,
                 c.pp, c.dd, c.la);
     spec_append(s, "#define VS_C %d\n#define VS_GROUPS %d\n#define VS_NT_STORES %d\n", t.C, groups, c.nt_stores);
-    size_t max_n = 1, max_odd = 1;
-    std::vector<std::vector<int>> seq_off(groups), seq_set(groups);
-    std::vector<std::vector<float>> seq_w(groups);
+    struct Read { int plane, off; std::vector<int> set, row; std::vector<float> w; };
+    std::vector<std::vector<Read>> sched(groups);
     std::vector<std::vector<int>> odd_off(2 * groups);
     std::vector<std::vector<float>> odd_w(2 * groups);
+    size_t max_reads = 1, max_cons = 1, max_odd = 1;
     for (int g = 0; g < groups; ++g) {
         std::vector<std::pair<int, float>> sets[4];
         for (int cc = 0; cc < 2; ++cc) {
             const int ch = 2 * g + cc;
             for (int32_t k = t.tap_off[ch]; k < t.tap_off[ch + 1]; ++k) {
                 if (t.w[k] == 0.0f) continue;                         // adds nothing in any summation order
-                const int parity = t.idx[k] & 1;
-                sets[cc * 2 + parity].push_back({t.idx[k] & ~1, t.w[k]});
-                if (parity) { odd_off[2 * g + cc].push_back(t.idx[k] & ~1); odd_w[2 * g + cc].push_back(t.w[k]); }
+                sets[cc * 2 + (t.idx[k] & 1)].push_back({t.idx[k] & ~1, t.w[k]});
             }
         }
+        // taps round-robin over the four accumulator sets (consecutive FMAs never depend on each other,
+        // the LDS planes alternate), rows innermost; a (plane, offset) pair already scheduled takes
+        // the new consumer instead of a second read
         size_t pos[4] = {0, 0, 0, 0};
+        std::vector<Read> &rd = sched[g];
         for (bool any = true; any;) {
             any = false;
-            static const int order[4] = {0, 2, 1, 3};                 // alternate the LDS planes too
+            static const int order[4] = {0, 2, 1, 3};
             for (int o = 0; o < 4; ++o) {
                 const int st = order[o];
-                if (pos[st] < sets[st].size()) {
-                    seq_off[g].push_back(sets[st][pos[st]].first);
-                    seq_w[g].push_back(sets[st][pos[st]].second);
-                    seq_set[g].push_back(st);
-                    ++pos[st];
-                    any = true;
+                if (pos[st] >= sets[st].size()) continue;
+                const int off = sets[st][pos[st]].first;
+                const float w = sets[st][pos[st]].second;
+                ++pos[st];
+                any = true;
+                for (int j = 0; j < c.rr; ++j) {
+                    const int plane = st >> 1, at = off + 2 * c.nt * j;
+                    Read *hit = nullptr;
+                    for (Read &r : rd) if (r.plane == plane && r.off == at) { hit = &r; break; }
+                    if (!hit) { rd.push_back(Read{plane, at, {}, {}, {}}); hit = &rd.back(); }
+                    hit->set.push_back(st); hit->row.push_back(j); hit->w.push_back(w);
                 }
             }
         }
-        max_n = std::max(max_n, seq_off[g].size());
+        size_t cons = 0;
+        for (const Read &r : rd) {
+            cons += r.set.size();
+            // the order in which row 0 of each channel's odd set accumulates: the span-end chain repeats it
+            for (size_t m = 0; m < r.set.size(); ++m)
+                if ((r.set[m] & 1) && r.row[m] == 0) { odd_off[2 * g + (r.set[m] >> 1)].push_back(r.off); odd_w[2 * g + (r.set[m] >> 1)].push_back(r.w[m]); }
+        }
+        max_reads = std::max(max_reads, rd.size());
+        max_cons = std::max(max_cons, cons);
         for (int cc = 0; cc < 2; ++cc) max_odd = std::max(max_odd, odd_off[2 * g + cc].size());
     }
-    auto int_rows = [&](const char *name, const std::vector<std::vector<int>> &rows, size_t width, int per) {
-        spec_append(s, "__device__ constexpr int %s", name);
-        if (per == 1) spec_append(s, "[%d][%zu] = {", groups, width);
-        else spec_append(s, "[%d][2][%zu] = {", groups, width);
-        for (size_t r = 0; r < rows.size(); ++r) {
-            if (per == 2 && r % 2 == 0) s += "{";
-            s += "{";
-            for (size_t k = 0; k < width; ++k) spec_append(s, "%d,", k < rows[r].size() ? rows[r][k] : 0);
-            s += "},";
-            if (per == 2 && r % 2 == 1) s += "},";
-        }
-        s += "};\n";
+    auto open_array = [&](const char *type, const char *name, size_t width) {
+        spec_append(s, "__device__ constexpr %s %s[%d][%zu] = {", type, name, groups, width);
     };
-    auto float_rows = [&](const char *name, const std::vector<std::vector<float>> &rows, size_t width, int per) {
-        spec_append(s, "__device__ constexpr float %s", name);
-        if (per == 1) spec_append(s, "[%d][%zu] = {", groups, width);
-        else spec_append(s, "[%d][2][%zu] = {", groups, width);
-        for (size_t r = 0; r < rows.size(); ++r) {
-            if (per == 2 && r % 2 == 0) s += "{";
-            s += "{";
-            for (size_t k = 0; k < width; ++k) { s += (k < rows[r].size() ? spec_float(rows[r][k]) : std::string("0.0f")); s += ","; }
-            s += "},";
-            if (per == 2 && r % 2 == 1) s += "},";
-        }
-        s += "};\n";
-    };
-    spec_append(s, "__device__ constexpr int VS_N[%d] = {", groups);
-    for (int g = 0; g < groups; ++g) spec_append(s, "%zu,", seq_off[g].size());
+    spec_append(s, "__device__ constexpr int VS_RD_N[%d] = {", groups);
+    for (int g = 0; g < groups; ++g) spec_append(s, "%zu,", sched[g].size());
     s += "};\n";
-    int_rows("VS_OFF", seq_off, max_n, 1);
-    float_rows("VS_W", seq_w, max_n, 1);
-    int_rows("VS_SET", seq_set, max_n, 1);
+    open_array("int", "VS_RD_PLANE", max_reads);
+    for (int g = 0; g < groups; ++g) { s += "{"; for (size_t k = 0; k < max_reads; ++k) spec_append(s, "%d,", k < sched[g].size() ? sched[g][k].plane : 0); s += "},"; }
+    s += "};\n";
+    open_array("int", "VS_RD_OFF", max_reads);
+    for (int g = 0; g < groups; ++g) { s += "{"; for (size_t k = 0; k < max_reads; ++k) spec_append(s, "%d,", k < sched[g].size() ? sched[g][k].off : 0); s += "},"; }
+    s += "};\n";
+    open_array("int", "VS_RD_FIRST", max_reads + 1);
+    for (int g = 0; g < groups; ++g) {
+        s += "{";
+        size_t run = 0;
+        for (size_t k = 0; k <= max_reads; ++k) { spec_append(s, "%zu,", run); if (k < sched[g].size()) run += sched[g][k].set.size(); }
+        s += "},";
+    }
+    s += "};\n";
+    auto consumers = [&](const char *type, const char *name, int what) {
+        open_array(type, name, max_cons);
+        for (int g = 0; g < groups; ++g) {
+            s += "{";
+            size_t n = 0;
+            for (const Read &r : sched[g])
+                for (size_t m = 0; m < r.set.size(); ++m, ++n) {
+                    if (what == 0) spec_append(s, "%d,", r.set[m]);
+                    else if (what == 1) spec_append(s, "%d,", r.row[m]);
+                    else { s += spec_float(r.w[m]); s += ","; }
+                }
+            for (; n < max_cons; ++n) s += what == 2 ? "0.0f," : "0,";
+            s += "},";
+        }
+        s += "};\n";
+    };
+    consumers("int", "VS_CS_SET", 0);
+    consumers("int", "VS_CS_ROW", 1);
+    consumers("float", "VS_CS_W", 2);
     spec_append(s, "__device__ constexpr int VS_NODD[%d][2] = {", groups);
     for (int g = 0; g < groups; ++g) spec_append(s, "{%zu,%zu},", odd_off[2 * g].size(), odd_off[2 * g + 1].size());
     s += "};\n";
-    int_rows("VS_ODD_OFF", odd_off, max_odd, 2);
-    float_rows("VS_ODD_W", odd_w, max_odd, 2);
+    spec_append(s, "__device__ constexpr int VS_ODD_OFF[%d][2][%zu] = {", groups, max_odd);
+    for (int g = 0; g < groups; ++g) {
+        s += "{";
+        for (int cc = 0; cc < 2; ++cc) { s += "{"; for (size_t k = 0; k < max_odd; ++k) spec_append(s, "%d,", k < odd_off[2 * g + cc].size() ? odd_off[2 * g + cc][k] : 0); s += "},"; }
+        s += "},";
+    }
+    s += "};\n";
+    spec_append(s, "__device__ constexpr float VS_ODD_W[%d][2][%zu] = {", groups, max_odd);
+    for (int g = 0; g < groups; ++g) {
+        s += "{";
+        for (int cc = 0; cc < 2; ++cc) { s += "{"; for (size_t k = 0; k < max_odd; ++k) { s += (k < odd_off[2 * g + cc].size() ? spec_float(odd_w[2 * g + cc][k]) : std::string("0.0f")); s += ","; } s += "},"; }
+        s += "},";
+    }
+    s += "};\n";
     s += "#define VS_DISPATCH(g) switch (g) {";
     for (int g = 0; g < groups; ++g) spec_append(s, " case %d: vs_span<%d>(a, lds, stream, span); break;", g, g);
     s += " default: break; }\n";
