@@ -93,9 +93,10 @@ def test_other_geometries(env, golden):
         text = table.describe(2, 30000, 2, d.MODE_FAST)
         assert f'pairs_per_lane={rr} ' in text, text
         _check(table.convolve_host(x, d.MODE_FAST), want, f'rr={rr}')
-    for dd in (1, 2):
-        ctx.set_variant(FORCE | span_bits(1, 5) | (dd << 26))
-        assert f'prefetch={dd} ' in table.describe(2, 30000, 2, d.MODE_FAST)
+    for dd in (1, 2):                                    # prefetch depth must divide the slot count: 4 slots at 2 pairs per lane
+        ctx.set_variant(FORCE | span_bits(1, 5) | (dd << 26) | 2)
+        text = table.describe(2, 30000, 2, d.MODE_FAST)
+        assert f'prefetch={dd} ' in text and 'ring_slots=4' in text, text
         _check(table.convolve_host(x, d.MODE_FAST), want, f'dd={dd}')
     ctx.set_variant(-1)
     table.close()
@@ -125,7 +126,7 @@ def test_real_size_pool_matches_the_exact_kernel(env, golden):
     ctx.set_variant(-1)
     fir = golden.fir('g48k_k30')
     table = _table(native, ctx, fir)
-    pool, n = 24, 480000
+    pool, n = 32, 480000
     assert table.describe(pool, n, 2, d.MODE_FAST).startswith('conv_spec')
     x = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1)
     y, ye = torch.empty_like(x), torch.empty_like(x)
@@ -136,14 +137,14 @@ def test_real_size_pool_matches_the_exact_kernel(env, golden):
     peak = float(ye.abs().max())
     assert float((y - ye).abs().max()) <= TOL_PEAK * peak
     offs, idx, w = O.fir_to_taps(fir)
-    for b in (0, 11, 23):
+    for b in (0, 11, 31):
         want = c_oracle.convolve(x[b].cpu().numpy(), offs, idx, w)
         assert np.array_equal(ye[b].cpu().numpy(), want)
         _check(y[b].cpu().numpy(), want, f'stream {b}')
     # the same streams one launch each (forced: a single stream is too little work otherwise)
     ctx.set_variant(FORCE)
     y1 = torch.empty((1, n, 2), dtype=torch.float32, device='cuda')
-    for b in (5, 23):
+    for b in (5, 31):
         table.convolve_device(x[b].data_ptr(), y1.data_ptr(), 1, n, 2, mode=d.MODE_FAST, stream=stream)
         torch.cuda.synchronize()
         assert torch.equal(y1[0], y[b])                  # same arithmetic whatever the span layout: bit-identical
@@ -157,7 +158,7 @@ def test_linearity_and_shift_at_full_size(env, golden):
     d, native, ctx = env
     ctx.set_variant(-1)
     table = _table(native, ctx, golden.fir('g48k_k30'))
-    pool, n = 40, 240000
+    pool, n = 64, 240000
     x = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1)
     y, y2 = torch.empty_like(x), torch.empty_like(x)
     s = torch.cuda.current_stream().cuda_stream

@@ -376,7 +376,7 @@ struct SpecPlan {
     bool use = false;
     SpecConfig cfg;
     int tiles_total = 0, tiles_per_span = 0, spans = 0;
-    uint32_t nblocks = 0;
+    uint32_t nblocks = 0, units = 0;
     const char *why = "";           // when !use: the reason, for vnd_describe_launch
 };
 
@@ -409,7 +409,9 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     if (batch > 1 && ((uint64_t)n * C * 4) % align != 0) { p.why = "unaligned streams"; return p; }
     const int rr_hint = (v >= 0 && (v & 31) != 0 && (v & 31) <= 8) ? (v & 31) : 0;
     const int dd_hint = v >= 0 ? ((v >> 26) & 3) : 0;
-    if (!spec_pick_config(t->spec_table, (size_t)ctx->lds_limit, rr_hint, dd_hint, &p.cfg)) { p.why = "halo does not fit the ring"; return p; }
+    // 1536-frame tiles unless a span would be shorter than 36 of them (cfg4's 1 s streams): then 1024-frame ones
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    if (!spec_pick_config(t->spec_table, (size_t)ctx->lds_limit, rr_hint, dd_hint, &p.cfg, attempt == 1)) { p.why = "halo does not fit the ring"; return p; }
     const int64_t T = p.cfg.tile();
     const int64_t tiles_total = (n + T - 1) / T;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
@@ -448,8 +450,12 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     if (units * spans > 0x7fffffffLL) { p.why = "grid too large"; return p; }
     p.cfg.nt_stores = (batch * n * C * (int64_t)sizeof(float) >= ((int64_t)64 << 20)) ? 1 : 0;
     p.tiles_total = (int)tiles_total; p.tiles_per_span = (int)per_span; p.spans = (int)spans;
-    p.nblocks = (uint32_t)(units * spans);
+    // one round of workgroups: at most the resident slots, each walking units w, w + nblocks, ...
+    p.units = (uint32_t)(units * spans);
+    p.nblocks = (uint32_t)std::min<int64_t>(units * spans, resident);
     p.use = true;
+    if (per_span >= 36 || rr_hint > 0) break;
+    }
     return p;
 }
 
@@ -477,6 +483,7 @@ static vnd_status launch_spec(vnd_ctx *ctx, const vnd_taps *t, const SpecPlan &p
     SpecArgs a{};
     a.x = x; a.y = y; a.n = n;
     a.tiles_total = p.tiles_total; a.tiles_per_span = p.tiles_per_span; a.spans = p.spans; a.nblocks = p.nblocks;
+    a.units = p.units;
     void *params[] = {&a};
     hipError_t e = hipModuleLaunchKernel(m->fn, p.nblocks, 1, 1, p.cfg.nt, 1, 1, (unsigned)p.cfg.lds_bytes(), stream, params,
                                          nullptr);
@@ -1065,9 +1072,9 @@ static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64
         if (m && !m->failed) {
             snprintf(text, (size_t)len,
                      "conv_spec (hipRTC, per table) pairs_per_lane=%d tile=%d ring_slots=%d prefetch=%d reads_ahead=%d "
-                     "nt_stores=%d mode=%d lds=%zuB workgroups=%u (%d spans x %d tiles per stream) threads=%d",
+                     "nt_stores=%d mode=%d lds=%zuB workgroups=%u (%u units: %d spans x %d tiles per stream) threads=%d",
                      sp.cfg.rr, sp.cfg.tile(), sp.cfg.pp, sp.cfg.dd, sp.cfg.la, sp.cfg.nt_stores, mode, sp.cfg.lds_bytes(),
-                     sp.nblocks, sp.spans, sp.tiles_per_span, sp.cfg.nt);
+                     sp.nblocks, sp.units, sp.spans, sp.tiles_per_span, sp.cfg.nt);
             return VND_OK;
         }
         if (m && getenv("VND_SPEC_VERBOSE")) fprintf(stderr, "vnd: specialised kernel unavailable: %s\n", m->log.c_str());

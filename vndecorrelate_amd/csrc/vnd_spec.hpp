@@ -64,13 +64,18 @@ inline int spec_env(const char *name, int fallback)
     return (e && *e) ? atoi(e) : fallback;
 }
 
-inline bool spec_pick_config(const SpecTable &t, size_t lds_limit, int rr_hint, int dd_hint, SpecConfig *out)
+inline bool spec_pick_config(const SpecTable &t, size_t lds_limit, int rr_hint, int dd_hint, SpecConfig *out,
+                             bool small_tiles = false)
 {
     const int reach = (t.max_index | 1) + 1;          // frames past a pair's first frame that an (aligned) read touches
     // (threads, pairs per lane), best first.  Measured on cfg2 and cfg3 (tools/spec_try.py, several boxes):
     // the geometries land within 7 % of each other - the kernel runs on the board's power cap - with
     // 3-wave workgroups of 1536-frame tiles ahead (3 ring slots, 4 workgroups per CU).
-    static const int kShapes[][2] = {{192, 4}, {256, 4}, {128, 4}, {256, 2}, {128, 2}, {256, 1}};
+    // Short spans (a ring is filled once per span, three tiles of loads before the first output) do
+    // better with 1024-frame tiles: small_tiles starts the list there.
+    static const int kLong[][2] = {{192, 4}, {256, 4}, {128, 4}, {256, 2}, {128, 2}, {256, 1}};
+    static const int kShort[][2] = {{128, 4}, {256, 2}, {128, 2}, {256, 1}, {192, 4}, {256, 4}};
+    const int (&kShapes)[6][2] = small_tiles ? kShort : kLong;
     const int nt_env = spec_env("VND_SPEC_NT", 0);
     rr_hint = spec_env("VND_SPEC_RR", rr_hint);
     dd_hint = spec_env("VND_SPEC_DD", dd_hint);
@@ -240,7 +245,7 @@ struct SpecArgs {
     float *y;
     long long n;
     int tiles_total, tiles_per_span, spans;
-    unsigned nblocks;
+    unsigned nblocks, units;
 };
 
 struct SpecModule {
