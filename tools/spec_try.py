@@ -74,8 +74,7 @@ def env_rate(label, **env):
     rate(-1, f'{label} err={err:.1e}')
 
 
-configs = [dict(), dict(nt=128, rr=4, la=4), dict(nt=128, rr=4, la=8), dict(nt=128, rr=4, la=6), dict(nt=192, rr=4, la=8), dict(nt=192, rr=4, la=4),
-           dict(nt=192, rr=4, la=12), dict(nt=192, rr=3, la=8), dict(nt=256, rr=3, la=8), dict(nt=192, rr=2, la=8)]
+configs = [dict(), dict(dd=1), dict(nt=128, rr=4), dict(nt=256, rr=4), dict(nt=128, rr=8), dict(nt=64, rr=8), dict(nt=192, rr=4, la=12)]
 for rep in range(2):
     rate(GENERIC, 'generic fast')
     for c in configs:

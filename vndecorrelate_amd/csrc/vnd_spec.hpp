@@ -88,8 +88,7 @@ inline bool spec_pick_config(const SpecTable &t, size_t lds_limit, int rr_hint, 
         const int T = c.tile();
         c.pp = (T + reach + T - 1) / T + 1;            // slots covering tile + halo, plus the one being refilled
         if (c.pp < 2) c.pp = 2;
-        c.dd = (dd_hint > 0 ? dd_hint : 2);
-        while (c.dd > 1 && c.pp % c.dd != 0) --c.dd;
+        c.dd = std::min(dd_hint > 0 ? dd_hint : (c.pp >= 4 ? 2 : 1), 3);      // measured: 2 ahead only pays with 4+ slots
         if (c.pp <= 8 && c.lds_bytes() <= std::min<size_t>(lds_limit, 64 * 1024) &&
             2 * ((size_t)c.pp * T + 2 * c.nt) * 4 < 65536) {
             *out = c;
@@ -128,6 +127,11 @@ inline std::string spec_prologue(const SpecTable &t, const SpecConfig &c)
     spec_append(s, "#define VS_NT %d\n#define VS_RR %d\n#define VS_PP %d\n#define VS_DD %d\n#define VS_LA %d\n", c.nt, c.rr,
                 c.pp, c.dd, c.la);
     spec_append(s, "#define VS_C %d\n#define VS_GROUPS %d\n#define VS_NT_STORES %d\n", t.C, groups, c.nt_stores);
+    {   // resident workgroups per CU (LDS-bound, at most 32 waves) -> waves per SIMD the register budget must allow
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, 2048 / c.nt), (160 * 1024) / c.lds_bytes()));
+        const int waves = (per_cu * (c.nt / 64) + 3) / 4;
+        spec_append(s, "#define VS_WAVES_PER_EU %d\n", std::max(1, std::min(waves, 8)));
+    }
     struct Read { int plane, off; std::vector<int> set, row; std::vector<float> w; };
     std::vector<std::vector<Read>> sched(groups);
     std::vector<std::vector<int>> odd_off(2 * groups);
@@ -180,6 +184,9 @@ inline std::string spec_prologue(const SpecTable &t, const SpecConfig &c)
     auto open_array = [&](const char *type, const char *name, size_t width) {
         spec_append(s, "__device__ constexpr %s %s[%d][%zu] = {", type, name, groups, width);
     };
+    int max_off = 0;
+    for (int g = 0; g < groups; ++g) for (const Read &r : sched[g]) max_off = std::max(max_off, r.off);
+    spec_append(s, "#define VS_MAX_OFF %d\n", max_off);
     spec_append(s, "__device__ constexpr int VS_RD_N[%d] = {", groups);
     for (int g = 0; g < groups; ++g) spec_append(s, "%zu,", sched[g].size());
     s += "};\n";
