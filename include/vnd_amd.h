@@ -243,14 +243,15 @@ vnd_status vnd_time_convolve_f32_dev(vnd_ctx *ctx, const vnd_taps *taps, const f
                                      int32_t n_channels, int32_t mode, int32_t n_buffers,
                                      int64_t stride_elems, int32_t iters, void *hip_stream,
                                      float *avg_ms);
-/* The throughput mode (VND_MODE_FAST) compiles a kernel PER TAP TABLE with hipRTC on first use
- * (offsets become LDS-read immediates, weights literals; persistent workgroups over an LDS ring);
- * the generic kernels take over whenever that is not possible.  This returns the HIP source the
+/* VND_MODE_FAST and VND_MODE_EXACT compile a kernel PER TAP TABLE with hipRTC on first use
+ * (offsets become LDS-read immediates, weights literals; persistent workgroups over an LDS ring;
+ * `mode` picks the arithmetic: free summation order, or the reference's own association bit for
+ * bit); the generic kernels take over whenever that is not possible.  This returns the HIP source the
  * library would hand to hipRTC for a function-path table - no device needed - so that it can be
  * audited or compiled offline (`hipcc --offload-arch=gfx950 -include hip/hip_runtime.h`).
  * text == NULL queries the size.  Even channel counts only (channel pairs share a workgroup). */
 vnd_status vnd_spec_kernel_source(int32_t num_channels, const int32_t *tap_offsets,
-                                  const int32_t *tap_index, const float *tap_weight,
+                                  const int32_t *tap_index, const float *tap_weight, int32_t mode,
                                   char *text, int64_t capacity, int64_t *bytes);
 /* Kernel variant override for tuning runs: -1 = automatic choice. */
 vnd_status vnd_set_variant(vnd_ctx *ctx, int32_t variant);

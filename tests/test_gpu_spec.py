@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 TOL_PEAK = 1e-6
 FORCE = 1 << 23            # specialise however little work there is
 GENERIC = 1 << 25          # never specialise
+EXACT_TOO = 1 << 15        # specialise VND_MODE_EXACT as well (off by default: 2 % gain)
 
 
 def span_bits(min_span, rounds):
@@ -175,4 +176,71 @@ def test_linearity_and_shift_at_full_size(env, golden):
     table.convolve_device(xs.data_ptr(), y2.data_ptr(), pool, n, 2, mode=d.MODE_FAST, stream=s)
     torch.cuda.synchronize()
     assert torch.equal(y2[:, shift:-2000], y[:, :-shift - 2000])
+    table.close()
+
+
+# ---- VND_MODE_EXACT through the specialised kernel: bit-identical, like the generic ordered kernel ----
+@pytest.mark.parametrize('gname', ['g48k_k30', 'g44k_k30', 'g48k_k128_l', 'g44k_noenv', 'g96k_k64_c8'])
+def test_exact_mode_specialised_is_bit_identical(env, golden, gname):
+    """Table order, separately rounded products and sums, odd offsets as two dword reads: the per-table
+    kernel in exact mode must equal the oracle bit for bit - through span seams, ring wrap-arounds,
+    stream tails and batches, as the fast mode's test above."""
+    d, native, ctx = env
+    fir = golden.fir(gname)
+    C = fir.shape[1]
+    table = _table(native, ctx, fir)
+    rng = np.random.default_rng(21)
+    for n in [1, 2, 31, 1023, 1024, 1025, 1536, 3071, 4097, 9001, 12346]:
+        for batch in (1, 3):
+            if batch > 1 and n % 2:
+                continue
+            x = rng.uniform(-1, 1, (batch, n, C)).astype(np.float32)
+            want = np.stack([O.convolve_velvet_noise(x[b], fir) for b in range(batch)])
+            for min_span, rounds in ((1, 7), (3, 2)):
+                ctx.set_variant(FORCE | EXACT_TOO | span_bits(min_span, rounds))
+                assert table.describe(batch, n, C, d.MODE_EXACT).startswith('conv_spec_exact')
+                got = table.convolve_host(x, d.MODE_EXACT)
+                assert np.array_equal(got, want), f'{gname} n={n} batch={batch} spans=({min_span},{rounds})'
+    ctx.set_variant(-1)
+    table.close()
+
+
+@pytest.mark.parametrize('name', sorted(__import__('json').loads((__import__('pathlib').Path(__file__).parent / 'golden' / 'manifest.json').read_text())['cls_convolve']))
+def test_exact_mode_specialised_class_path(env, golden, name):
+    """VelvetNoise.convolve's association (segments of -/+ unit taps, one multiply per segment, segments
+    summed; decorrelation.py:402-414) through the specialised exact kernel: the reference's sha256."""
+    from conftest import make_input
+    d, native, ctx = env
+    meta = golden.manifest['cls_convolve'][name]
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in golden.manifest['class_taps'][meta['class']]['kwargs'].items()}
+    vn = d.VelvetNoise(**kw)
+    x = make_input(meta['input'])
+    ctx.set_variant(FORCE | EXACT_TOO | span_bits(1, 3))
+    try:
+        y = vn.convolve(x)
+    finally:
+        ctx.set_variant(-1)
+    golden.expect(name, y, exact=x.dtype == np.float32, rtol_peak=TOL_PEAK)
+
+
+def test_exact_mode_real_size_equals_the_generic_kernel(env, golden):
+    import torch
+    d, native, ctx = env
+    fir = golden.fir('g48k_k30')
+    table = _table(native, ctx, fir)
+    pool, n = 32, 480000
+    x = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1)
+    y, yg = torch.empty_like(x), torch.empty_like(x)
+    s = torch.cuda.current_stream().cuda_stream
+    ctx.set_variant(EXACT_TOO)
+    assert table.describe(pool, n, 2, d.MODE_EXACT).startswith('conv_spec_exact')
+    table.convolve_device(x.data_ptr(), y.data_ptr(), pool, n, 2, mode=d.MODE_EXACT, stream=s)
+    ctx.set_variant(GENERIC)
+    assert table.describe(pool, n, 2, d.MODE_EXACT).startswith('conv_ordered')
+    table.convolve_device(x.data_ptr(), yg.data_ptr(), pool, n, 2, mode=d.MODE_EXACT, stream=s)
+    torch.cuda.synchronize()
+    ctx.set_variant(-1)
+    assert torch.equal(y, yg)
+    offs, idx, w = O.fir_to_taps(fir)
+    assert np.array_equal(y[7].cpu().numpy(), c_oracle.convolve(x[7].cpu().numpy(), offs, idx, w))
     table.close()

@@ -116,16 +116,17 @@ def test_source_compiles_for_gfx950_with_the_intended_isa(native, golden, tmp_pa
     ops = re.findall(r'^\s+([a-z0-9_]+)', asm, re.M)
     count = {o: ops.count(o) for o in set(ops)}
     assert count.get('flat_load_dwordx2', 0) == 0, 'LDS reads fell back to flat loads'
-    groups, pp, rr = fir.shape[1] // 2, _macro(src, 'VS_PP'), _macro(src, 'VS_RR')
+    groups, dd, rr = fir.shape[1] // 2, _macro(src, 'VS_DD'), _macro(src, 'VS_RR')
     taps = len(idx)
     reads = sum(int(v) for v in re.search(r'VS_RD_N\[\d+\] = \{([^}]*)\}', src).group(1).strip(',').split(','))
-    # one packed FMA per (tap, row) and one aligned ds_read_b64 per unique read, in each of the PP unrolled
-    # slot phases (+ the span-end chain over the odd taps, which hipcc may pack across the two channels)
-    assert taps * rr * pp <= count['v_pk_fma_f32'] <= taps * rr * pp + taps
-    assert reads * pp <= count['ds_read_b64'] <= reads * pp + 8 * groups * pp
+    # one packed FMA per (tap, row) and one aligned ds_read_b64 per unique read; ONE tile body per prefetch
+    # buffer (the ring's slot phase is a run-time base register, not an unrolled copy of the code)
+    # (+ the span-end chain over the odd taps, which hipcc may pack across the two channels)
+    assert taps * rr * dd <= count['v_pk_fma_f32'] <= taps * rr * dd + taps
+    assert reads * dd <= count['ds_read_b64'] <= reads * dd + 8 * groups * dd
     # no tap read fused into the half-rate two-address forms (the few ds_read2 left are the
-    # wave-boundary exchange of the merge, rows x slot phases of them)
-    assert count.get('ds_read2st64_b64', 0) == 0 and count.get('ds_read2_b64', 0) <= rr * pp * groups
-    assert count['s_barrier'] == groups * (pp + 1)           # one per tile phase + the prologue's
+    # wave-boundary exchange of the merge)
+    assert count.get('ds_read2st64_b64', 0) == 0 and count.get('ds_read2_b64', 0) <= rr * 4 * groups
+    assert count['s_barrier'] == groups * (dd + 1) + 1       # one per tile body, the prologue's, the one between units
     # offsets are immediates: no per-tap address arithmetic
     assert count.get('v_add_u32_e32', 0) < 40 * groups

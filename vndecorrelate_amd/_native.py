@@ -105,7 +105,7 @@ SIGNATURES = {
                                                  _c_f32p]),
     'vnd_host_alloc': (ctypes.c_int, [ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
     'vnd_host_free': (ctypes.c_int, [ctypes.c_void_p]),
-    'vnd_spec_kernel_source': (ctypes.c_int, [ctypes.c_int32, _c_i32p, _c_i32p, _c_f32p, ctypes.c_char_p,
+    'vnd_spec_kernel_source': (ctypes.c_int, [ctypes.c_int32, _c_i32p, _c_i32p, _c_f32p, ctypes.c_int32, ctypes.c_char_p,
                                               ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
     'vnd_set_variant': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     'vnd_describe_launch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
@@ -535,7 +535,7 @@ def polar_moments_device(ctx: 'Context', y_ptr: int, n: int, pairs: int, moments
            'vnd_polar_moments_f32_dev')
 
 
-def spec_kernel_source(tap_offsets, tap_index, tap_weight) -> str:
+def spec_kernel_source(tap_offsets, tap_index, tap_weight, mode: int = MODE_FAST) -> str:
     """HIP source of the per-table fast kernel the library would compile with hipRTC
     (``vnd_spec_kernel_source``; needs no device)."""
     offs = np.ascontiguousarray(tap_offsets, np.int32)
@@ -543,7 +543,7 @@ def spec_kernel_source(tap_offsets, tap_index, tap_weight) -> str:
     w = np.ascontiguousarray(tap_weight, np.float32)
     lib = load_library()
     need = ctypes.c_int64()
-    args = (len(offs) - 1, _ptr(offs, ctypes.c_int32), _ptr(idx, ctypes.c_int32), _ptr(w, ctypes.c_float))
+    args = (len(offs) - 1, _ptr(offs, ctypes.c_int32), _ptr(idx, ctypes.c_int32), _ptr(w, ctypes.c_float), int(mode))
     _check(lib.vnd_spec_kernel_source(*args, None, 0, ctypes.byref(need)), 'vnd_spec_kernel_source')
     buf = ctypes.create_string_buffer(need.value)
     _check(lib.vnd_spec_kernel_source(*args, buf, need.value, ctypes.byref(need)), 'vnd_spec_kernel_source')

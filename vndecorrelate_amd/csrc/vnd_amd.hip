@@ -92,6 +92,7 @@ struct vnd_taps {
     // fast mode, specialised per table (vnd_spec.hpp): modules are compiled on first use
     SpecTable spec_table;          // effective weights (segment gain folded in)
     bool spec_ok = false;          // the table is within the specialised kernel's scope
+    bool spec_exact_ok = false;    // ... also in VND_MODE_EXACT (no empty segment)
     std::mutex spec_mutex;
     std::map<SpecConfig, std::unique_ptr<SpecModule>> spec_modules;
 };
@@ -395,9 +396,16 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
 {
     SpecPlan p;
     const int v = ctx->variant;
-    if (mode != VND_MODE_FAST) { p.why = "not the fast mode"; return p; }
+    if (mode != VND_MODE_FAST && mode != VND_MODE_EXACT) { p.why = "neither the fast nor the exact mode"; return p; }
     if (epi || Cx != C) { p.why = "fused epilogue or fan-out launch"; return p; }
-    if (!t->spec_ok) { p.why = "table outside the specialised kernel's scope"; return p; }
+    if (!(mode == VND_MODE_EXACT ? t->spec_exact_ok : t->spec_ok)) { p.why = "table outside the specialised kernel's scope"; return p; }
+    // The exact arithmetic (two VALU instructions and 1.5 LDS reads per tap) gains 2 % from specialisation
+    // (tools/exact_try.py: 0.298 vs 0.304 ms on the cfg2 pool): not worth a hipRTC build by default.  Opt in
+    // with VND_SPEC_EXACT=1 or variant bit 15; the parity tests do.
+    if (mode == VND_MODE_EXACT && !(v >= 0 && ((v >> 15) & 1))) {
+        static const bool on = [] { const char *e = getenv("VND_SPEC_EXACT"); return e && e[0] == '1'; }();
+        if (!on) { p.why = "exact mode specialises on request only"; return p; }
+    }
     const bool force = v >= 0 && ((v >> 23) & 1);
     // Wider signals stage 8 bytes per frame and channel pair: measured slower than the generic kernel
     // on the 8-channel config (bench.py secondary cfg5), so only stereo specialises by default.
@@ -449,6 +457,9 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     spans = (tiles_total + per_span - 1) / per_span;
     if (units * spans > 0x7fffffffLL) { p.why = "grid too large"; return p; }
     p.cfg.nt_stores = (batch * n * C * (int64_t)sizeof(float) >= ((int64_t)64 << 20)) ? 1 : 0;
+    p.cfg.exact = mode == VND_MODE_EXACT ? 1 : 0;
+    // exact mode counts VS_LA in steps of RR to 2*RR reads: the LDS queue holds 15, three steps fill it
+    if (p.cfg.exact && !getenv("VND_SPEC_LA")) p.cfg.la = 3;
     p.tiles_total = (int)tiles_total; p.tiles_per_span = (int)per_span; p.spans = (int)spans;
     // one round of workgroups: at most the resident slots, each walking units w, w + nblocks, ...
     p.units = (uint32_t)(units * spans);
@@ -758,6 +769,20 @@ vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, 
         t->spec_table.w = eff;
         t->spec_table.max_index = max_index;
         t->spec_ok = t->lds_images && !t->nonfinite && !t->has_flags && C % 2 == 0 && C <= 64 && total > 0;
+        t->spec_table.w_raw.assign(tap_weight, tap_weight + total);
+        t->spec_table.has_seg = has_seg;
+        t->spec_table.apply_gain = t->apply_gain != 0;
+        t->spec_exact_ok = t->spec_ok;
+        if (has_seg) {
+            t->spec_table.seg_off = t->seg_off; t->spec_table.seg_end = t->seg_end; t->spec_table.seg_gain = t->seg_gain;
+            for (int c = 0; c < C; ++c) {
+                int32_t prev = tap_offsets[c];
+                for (int32_t sg = seg_offsets[c]; sg < seg_offsets[c + 1]; ++sg) {
+                    if (seg_end[sg] == prev) t->spec_exact_ok = false;      // an empty segment still adds +0: generic kernel
+                    prev = seg_end[sg];
+                }
+            }
+        }
     }
     if (e == hipSuccess) e = upload(&t->d_taps_fast, fast.data(), fast.size());
     {   // ordered image: table order, weight first (SGPR pair layout), byte offsets, padded
@@ -1023,8 +1048,10 @@ vnd_status vnd_host_free(void *ptr)
 }
 
 vnd_status vnd_spec_kernel_source(int32_t C, const int32_t *tap_offsets, const int32_t *tap_index,
-                                  const float *tap_weight, char *text, int64_t capacity, int64_t *bytes)
+                                  const float *tap_weight, int32_t mode, char *text, int64_t capacity, int64_t *bytes)
 {
+    if (mode != VND_MODE_FAST && mode != VND_MODE_EXACT)
+        return fail(VND_ERR_INVALID, "the specialised kernel exists for VND_MODE_FAST and VND_MODE_EXACT");
     if (!bytes) return fail(VND_ERR_INVALID, "null bytes pointer");
     if (C <= 0 || C % 2 != 0 || C > 64 || !tap_offsets || tap_offsets[0] != 0)
         return fail(VND_ERR_INVALID, "the specialised kernel takes an even channel count (2..64) and a CSR tap table");
@@ -1040,8 +1067,10 @@ vnd_status vnd_spec_kernel_source(int32_t C, const int32_t *tap_offsets, const i
     }
     t.idx.assign(tap_index, tap_index + total);
     t.w.assign(tap_weight, tap_weight + total);
+    t.w_raw = t.w;
     SpecConfig cfg;
     if (!spec_pick_config(t, 160 * 1024, 0, 0, &cfg)) return fail(VND_ERR_UNSUPPORTED, "halo does not fit the LDS ring");
+    cfg.exact = mode == VND_MODE_EXACT ? 1 : 0;
     const std::string src = spec_prologue(t, cfg) + kSpecKernelSource;
     *bytes = (int64_t)src.size() + 1;
     if (!text) return VND_OK;                    // size query
@@ -1071,10 +1100,10 @@ static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64
         SpecModule *m = spec_module(ctx, t, sp.cfg);
         if (m && !m->failed) {
             snprintf(text, (size_t)len,
-                     "conv_spec (hipRTC, per table) pairs_per_lane=%d tile=%d ring_slots=%d prefetch=%d reads_ahead=%d "
+                     "conv_spec%s (hipRTC, per table) pairs_per_lane=%d tile=%d ring_slots=%d prefetch=%d reads_ahead=%d "
                      "nt_stores=%d mode=%d lds=%zuB workgroups=%u (%u units: %d spans x %d tiles per stream) threads=%d",
-                     sp.cfg.rr, sp.cfg.tile(), sp.cfg.pp, sp.cfg.dd, sp.cfg.la, sp.cfg.nt_stores, mode, sp.cfg.lds_bytes(),
-                     sp.nblocks, sp.units, sp.spans, sp.tiles_per_span, sp.cfg.nt);
+                     sp.cfg.exact ? "_exact" : "", sp.cfg.rr, sp.cfg.tile(), sp.cfg.pp, sp.cfg.dd, sp.cfg.la, sp.cfg.nt_stores, mode,
+                     sp.cfg.lds_bytes(), sp.nblocks, sp.units, sp.spans, sp.tiles_per_span, sp.cfg.nt);
             return VND_OK;
         }
         if (m && getenv("VND_SPEC_VERBOSE")) fprintf(stderr, "vnd: specialised kernel unavailable: %s\n", m->log.c_str());

@@ -35,6 +35,7 @@ struct SpecConfig {
     int dd = 1;        // tiles prefetched ahead
     int la = 8;        // LDS reads in flight ahead of the FMAs
     int nt_stores = 0; // non-temporal output stores
+    int exact = 0;     // VND_MODE_EXACT arithmetic: table order, separately rounded products and sums
     int tile() const { return 2 * nt * rr; }
     size_t lds_bytes() const
     {
@@ -43,7 +44,7 @@ struct SpecConfig {
     }
     bool operator<(const SpecConfig &o) const
     {
-        return std::tie(nt, rr, pp, dd, la, nt_stores) < std::tie(o.nt, o.rr, o.pp, o.dd, o.la, o.nt_stores);
+        return std::tie(nt, rr, pp, dd, la, nt_stores, exact) < std::tie(o.nt, o.rr, o.pp, o.dd, o.la, o.nt_stores, o.exact);
     }
 };
 
@@ -52,8 +53,13 @@ struct SpecTable {
     int C = 0;
     std::vector<int32_t> tap_off;   // [C + 1]
     std::vector<int32_t> idx;
-    std::vector<float> w;
+    std::vector<float> w;           // fast mode: weight * segment gain
     int max_index = 0;
+    // exact mode: the table as the reference consumes it (table order, raw weights, segments)
+    std::vector<float> w_raw;
+    bool has_seg = false, apply_gain = false;
+    std::vector<int32_t> seg_off, seg_end;      // per channel CSR of segments; exclusive tap ends
+    std::vector<float> seg_gain;
 };
 
 // Smallest ring that holds one tile's window (tile + halo) plus the slot being refilled.
@@ -126,11 +132,70 @@ inline std::string spec_prologue(const SpecTable &t, const SpecConfig &c)
     std::string s;
     spec_append(s, "#define VS_NT %d\n#define VS_RR %d\n#define VS_PP %d\n#define VS_DD %d\n#define VS_LA %d\n", c.nt, c.rr,
                 c.pp, c.dd, c.la);
-    spec_append(s, "#define VS_C %d\n#define VS_GROUPS %d\n#define VS_NT_STORES %d\n", t.C, groups, c.nt_stores);
+    spec_append(s, "#define VS_C %d\n#define VS_GROUPS %d\n#define VS_NT_STORES %d\n#define VS_EXACT %d\n", t.C, groups,
+                c.nt_stores, c.exact);
     {   // resident workgroups per CU (LDS-bound, at most 32 waves) -> waves per SIMD the register budget must allow
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, 2048 / c.nt), (160 * 1024) / c.lds_bytes()));
         const int waves = (per_cu * (c.nt / 64) + 3) / 4;
         spec_append(s, "#define VS_WAVES_PER_EU %d\n", std::max(1, std::min(waves, 8)));
+    }
+    if (c.exact) {
+        // the step program: channels alternate, each in table order; END marks a tap that closes a segment
+        // (1: function-path table, the sum is the output; 2: out += segment; 3: segment *= gain first)
+        struct Step { int ch, off, end; float w, gain; };
+        std::vector<std::vector<Step>> prog(groups);
+        size_t width = 1;
+        int max_off = 0;
+        for (int g = 0; g < groups; ++g) {
+            std::vector<Step> per[2];
+            for (int cc = 0; cc < 2; ++cc) {
+                const int ch = 2 * g + cc;
+                for (int32_t k = t.tap_off[ch]; k < t.tap_off[ch + 1]; ++k) per[cc].push_back(Step{cc, t.idx[k], 0, t.w_raw[k], 1.0f});
+                if (per[cc].empty()) continue;
+                if (!t.has_seg) {
+                    per[cc].back().end = 1;
+                } else {
+                    for (int32_t sg = t.seg_off[ch]; sg < t.seg_off[ch + 1]; ++sg) {
+                        const int32_t last = t.seg_end[sg] - 1 - t.tap_off[ch];      // spec scope: no empty segment
+                        per[cc][last].end = t.apply_gain ? 3 : 2;
+                        per[cc][last].gain = t.seg_gain[sg];
+                    }
+                }
+            }
+            for (size_t k = 0; k < std::max(per[0].size(), per[1].size()); ++k)
+                for (int cc = 0; cc < 2; ++cc)
+                    if (k < per[cc].size()) prog[g].push_back(per[cc][k]);
+            width = std::max(width, prog[g].size());
+            for (const Step &st : prog[g]) max_off = std::max(max_off, st.off + (st.off & 1) + 2 * c.nt * (c.rr - 1));
+        }
+        spec_append(s, "#define VS_MAX_OFF %d\n", max_off);
+        spec_append(s, "__device__ constexpr int VS_EX_N[%d] = {", groups);
+        for (int g = 0; g < groups; ++g) spec_append(s, "%zu,", prog[g].size());
+        s += "};\n";
+        auto emit = [&](const char *type, const char *name, int what) {
+            spec_append(s, "__device__ constexpr %s %s[%d][%zu] = {", type, name, groups, width);
+            for (int g = 0; g < groups; ++g) {
+                s += "{";
+                for (size_t k = 0; k < width; ++k) {
+                    const bool in = k < prog[g].size();
+                    if (what == 0) spec_append(s, "%d,", in ? prog[g][k].ch : 0);
+                    else if (what == 1) spec_append(s, "%d,", in ? prog[g][k].off : 0);
+                    else if (what == 2) spec_append(s, "%d,", in ? prog[g][k].end : 0);
+                    else { s += spec_float(in ? (what == 3 ? prog[g][k].w : prog[g][k].gain) : 0.0f); s += ","; }
+                }
+                s += "},";
+            }
+            s += "};\n";
+        };
+        emit("int", "VS_EX_CH", 0);
+        emit("int", "VS_EX_OFF", 1);
+        emit("int", "VS_EX_END", 2);
+        emit("float", "VS_EX_W", 3);
+        emit("float", "VS_EX_GAIN", 4);
+        s += "#define VS_DISPATCH(g) switch (g) {";
+        for (int g = 0; g < groups; ++g) spec_append(s, " case %d: vs_span<%d>(a, lds, stream, span); break;", g, g);
+        s += " default: break; }\n";
+        return s;
     }
     struct Read { int plane, off; std::vector<int> set, row; std::vector<float> w; };
     std::vector<std::vector<Read>> sched(groups);
