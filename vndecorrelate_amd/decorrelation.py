@@ -528,7 +528,8 @@ class VelvetNoise(Decorrelator):
         return table
 
     # ---- the hot path --------------------------------------------------------
-    def _tap_arrays(self) -> TapArrays:
+    def _tap_member(self):
+        """``(channels, envelope, apply_gain)`` as ``taps.class_path_arrays`` / ``class_path_bank_arrays`` take them."""
         apply_gain = self.segment_envelope != IDENTITY_ENVELOPE
         channels = []
         for sequence in self.velvet_noise:
@@ -537,7 +538,10 @@ class VelvetNoise(Decorrelator):
             else:
                 channels.append([(seg.negative_impulse_indexes, seg.positive_impulse_indexes)
                                  for seg in sequence])
-        return class_path_arrays(channels, self.segment_envelope, apply_gain)
+        return channels, self.segment_envelope, apply_gain
+
+    def _tap_arrays(self) -> TapArrays:
+        return class_path_arrays(*self._tap_member())
 
     def _device_table(self) -> _native.TapTable:
         """Device image of the current impulse table + envelope, uploaded once.  The

@@ -144,6 +144,40 @@ def class_path_arrays(channels: Sequence, envelope: Sequence[float], apply_gain:
                      np.asarray(flags, np.uint8), bool(apply_gain))
 
 
+def class_path_bank_arrays(members: Sequence) -> TapArrays:
+    """The class-path bank of ``concat_tap_arrays([class_path_arrays(*m) for m in members])`` built in
+    one pass over plain Python lists (``members``: ``(channels, envelope, apply_gain)`` triples): the
+    candidate scan concatenates hundreds of small tables, and per-table NumPy calls were most of its
+    host time."""
+    tap_offsets, seg_offsets = [0], [0]
+    idx, w, seg_end, seg_gain, flags = [], [], [], [], []
+    any_gain = False
+    count = 0
+    for channels, envelope, apply_gain in members:
+        any_gain = any_gain or bool(apply_gain)
+        for segs in channels:
+            if segs is None:
+                flags.append(1)
+                tap_offsets.append(count)
+                seg_offsets.append(len(seg_end))
+                continue
+            flags.append(0)
+            for s, (neg, pos) in enumerate(segs):
+                idx += neg
+                idx += pos
+                w += [-1.0] * len(neg)
+                w += [1.0] * len(pos)
+                count += len(neg) + len(pos)
+                seg_end.append(count)
+                seg_gain.append(float(envelope[s]) if apply_gain else 1.0)
+            tap_offsets.append(count)
+            seg_offsets.append(len(seg_end))
+    out = TapArrays(np.asarray(tap_offsets, np.int32), np.asarray(idx, np.int32), np.asarray(w, np.float32),
+                    np.asarray(seg_offsets, np.int32), np.asarray(seg_end, np.int32), np.asarray(seg_gain, np.float32),
+                    np.asarray(flags, np.uint8) if any(flags) else None, any_gain)
+    return out
+
+
 def concat_tap_arrays(tables: Sequence[TapArrays]) -> TapArrays:
     """Channel-wise concatenation: a bank of F tables of C channels each becomes one table
     of F*C channels (table f owns channels ``f*C .. f*C+C-1``), the shape the fan-out
