@@ -16,6 +16,9 @@ if which == 'cfg3':
     fir = vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=128, num_outs=2, sample_rate_hz=48000,
                                     log_distribution_strength=0.0, seed=1)
     pool, n = 24, 2880000
+elif which == 'cfg4':
+    fir = vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1)
+    pool, n = 1024, 48000
 else:
     fir = vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1)
     pool, n = 128, 480000
@@ -74,7 +77,7 @@ def env_rate(label, **env):
     rate(-1, f'{label} err={err:.1e}')
 
 
-configs = [dict(), dict(dd=1), dict(nt=128, rr=4), dict(nt=256, rr=4), dict(nt=128, rr=8), dict(nt=64, rr=8), dict(nt=192, rr=4, la=12)]
+configs = [dict(), dict(nt=192, rr=4), dict(nt=192, rr=4, dd=2), dict(nt=128, rr=4, la=4), dict(nt=256, rr=2), dict(nt=256, rr=4), dict(nt=128, rr=4, dd=1)]
 for rep in range(2):
     rate(GENERIC, 'generic fast')
     for c in configs:

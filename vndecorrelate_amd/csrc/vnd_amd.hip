@@ -407,9 +407,6 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
         if (!on) { p.why = "exact mode specialises on request only"; return p; }
     }
     const bool force = v >= 0 && ((v >> 23) & 1);
-    // Wider signals stage 8 bytes per frame and channel pair: measured slower than the generic kernel
-    // on the 8-channel config (bench.py secondary cfg5), so only stereo specialises by default.
-    if (C != 2 && !force) { p.why = "more than two channels"; return p; }
     if (spec_disabled_by_env() || (v >= 0 && ((v >> 25) & 1))) { p.why = "disabled"; return p; }
     // access shape: 16 bytes per frame pair (stereo) or 8 per frame, from every stream's first sample
     const uintptr_t align = C == 2 ? 16 : 8;
@@ -419,7 +416,8 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     const int dd_hint = v >= 0 ? ((v >> 26) & 3) : 0;
     // 1536-frame tiles unless a span would be shorter than 36 of them (cfg4's 1 s streams): then 1024-frame ones
     for (int attempt = 0; attempt < 2; ++attempt) {
-    if (!spec_pick_config(t->spec_table, (size_t)ctx->lds_limit, rr_hint, dd_hint, &p.cfg, attempt == 1)) { p.why = "halo does not fit the ring"; return p; }
+    // (wider signals - a workgroup per channel pair, 8 bytes per frame - measured best with the 1024-frame tiles)
+    if (!spec_pick_config(t->spec_table, (size_t)ctx->lds_limit, rr_hint, dd_hint, &p.cfg, attempt == 1 || C != 2)) { p.why = "halo does not fit the ring"; return p; }
     const int64_t T = p.cfg.tile();
     const int64_t tiles_total = (n + T - 1) / T;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
@@ -457,6 +455,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     spans = (tiles_total + per_span - 1) / per_span;
     if (units * spans > 0x7fffffffLL) { p.why = "grid too large"; return p; }
     p.cfg.nt_stores = (batch * n * C * (int64_t)sizeof(float) >= ((int64_t)64 << 20)) ? 1 : 0;
+    if (C != 2 && !getenv("VND_FORCE_NT")) p.cfg.nt_stores = 0;      // a channel pair is a piece of a frame: let L2 merge the pieces
     p.cfg.exact = mode == VND_MODE_EXACT ? 1 : 0;
     // exact mode counts VS_LA in steps of RR to 2*RR reads: the LDS queue holds 15, three steps fill it
     if (p.cfg.exact && !getenv("VND_SPEC_LA")) p.cfg.la = 3;
@@ -538,7 +537,10 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
     a.chan_flags = t->has_flags ? t->d_flags : nullptr;
     a.n = n; a.C = C; a.Cx = Cx; a.apply_gain = t->apply_gain;
     // an output beyond what the L2 + Infinity Cache could hand to a consumer is streamed past them
-    a.stream_out = (batch * n * C * (int64_t)sizeof(float) >= ((int64_t)64 << 20)) ? 1 : 0;
+    // (only where a workgroup writes whole frames: pieces of a frame written past the caches by different
+    // workgroups reach HBM as separate partial writes)
+    a.stream_out = (batch * n * C * (int64_t)sizeof(float) >= ((int64_t)64 << 20) && !getenv("VND_NO_NT")) ? 1 : 0;
+    if (!p.direct && p.cg != C && !getenv("VND_FORCE_NT")) a.stream_out = 0;
     a.nblocks = p.nblocks;
     if (p.direct) {
         a.tiles = (int32_t)batch; a.groups = 1; a.W = 0;
