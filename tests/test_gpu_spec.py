@@ -114,6 +114,17 @@ def test_out_of_scope_launches_take_the_generic_kernel(env, golden):
     x = np.random.default_rng(5).uniform(-1, 1, (3, 50001, 2)).astype(np.float32)
     want = np.stack([O.convolve_velvet_noise(x[b], golden.fir('g48k_k30')) for b in range(3)])
     _check(t2.convolve_host(x, d.MODE_FAST), want, 'odd streams')
+    # a base address that is not 16-byte aligned: the per-table kernel declines, the generic one runs on dword accesses
+    import torch
+    flat = torch.empty(4 * 60000 * 2 + 8, dtype=torch.float32, device='cuda').uniform_(-1, 1)
+    out = torch.empty_like(flat)
+    xs, ys = flat[1:1 + 4 * 60000 * 2], out[1:1 + 4 * 60000 * 2]
+    assert xs.data_ptr() % 16 == 4
+    t2.convolve_device(xs.data_ptr(), ys.data_ptr(), 4, 60000, 2, mode=d.MODE_FAST, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    xh = xs.cpu().numpy().reshape(4, 60000, 2)
+    want = np.stack([O.convolve_velvet_noise(xh[b], golden.fir('g48k_k30')) for b in range(4)])
+    _check(ys.cpu().numpy().reshape(4, 60000, 2), want, 'misaligned base')
     ctx.set_variant(-1)
     t2.close(); t3.close()
 
@@ -244,3 +255,30 @@ def test_exact_mode_real_size_equals_the_generic_kernel(env, golden):
     offs, idx, w = O.fir_to_taps(fir)
     assert np.array_equal(y[7].cpu().numpy(), c_oracle.convolve(x[7].cpu().numpy(), offs, idx, w))
     table.close()
+
+
+def test_failed_runtime_build_falls_back_to_the_generic_kernel(env, golden, monkeypatch):
+    """If hipRTC cannot build the per-table kernel (here: an injected #error), the launch silently takes the
+    generic HIP kernel - never a CPU path - the result is still right, and vnd_describe_launch says so."""
+    d, native, ctx = env
+    fir = golden.fir('g44k_55ms')                        # a table no other test has built a module for
+    monkeypatch.setenv('VND_SPEC_BREAK', '1')
+    table = _table(native, ctx, fir)
+    ctx.set_variant(FORCE)
+    try:
+        x = np.random.default_rng(8).uniform(-1, 1, (2, 40000, 2)).astype(np.float32)
+        want = np.stack([O.convolve_velvet_noise(x[b], fir) for b in range(2)])
+        got = table.convolve_host(x, d.MODE_FAST)
+        _check(got, want, 'fallback')
+        assert table.describe(2, 40000, 2, d.MODE_FAST).startswith('conv_fast')
+    finally:
+        ctx.set_variant(-1)
+        table.close()
+    monkeypatch.delenv('VND_SPEC_BREAK')
+    table = _table(native, ctx, fir)                     # a new table builds its module afresh
+    ctx.set_variant(FORCE)
+    try:
+        assert table.describe(2, 40000, 2, d.MODE_FAST).startswith('conv_spec')
+    finally:
+        ctx.set_variant(-1)
+        table.close()

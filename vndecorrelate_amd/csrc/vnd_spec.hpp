@@ -333,6 +333,7 @@ inline bool spec_compile(const SpecTable &t, const SpecConfig &cfg, int device, 
     m->cfg = cfg;
     std::string src = spec_prologue(t, cfg);
     src += kSpecKernelSource;
+    if (getenv("VND_SPEC_BREAK")) src += "\n#error VND_SPEC_BREAK: injected build failure (fallback test)\n";
     if (const char *dump = getenv("VND_SPEC_DUMP")) {
         if (FILE *f = fopen(dump, "w")) { fputs(src.c_str(), f); fclose(f); }
     }
