@@ -282,3 +282,24 @@ def test_failed_runtime_build_falls_back_to_the_generic_kernel(env, golden, monk
     finally:
         ctx.set_variant(-1)
         table.close()
+
+
+@pytest.mark.parametrize('name', sorted(__import__('json').loads((__import__('pathlib').Path(__file__).parent / 'golden' / 'manifest.json').read_text())['cls_convolve']))
+def test_fast_mode_specialised_class_path(env, golden, name):
+    """Class-path tables (segment gains folded into the weights, duplicate indices summed) through the
+    per-table fast kernel: the reference's VelvetNoise.convolve within the fast mode's tolerance; tables
+    with a pass-through channel are outside its scope and must still come out right (generic kernel)."""
+    from conftest import make_input
+    d, native, ctx = env
+    meta = golden.manifest['cls_convolve'][name]
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in golden.manifest['class_taps'][meta['class']]['kwargs'].items()}
+    vn = d.VelvetNoise(**kw)
+    x = make_input(meta['input'])
+    ctx.set_variant(FORCE | span_bits(1, 3))
+    d.set_default_mode(d.MODE_FAST)
+    try:
+        y = vn.convolve(x)
+    finally:
+        d.set_default_mode(d.MODE_EXACT)
+        ctx.set_variant(-1)
+    golden.expect(name, y, exact=False, rtol_peak=2e-6 if 'k128' in name else TOL_PEAK)
