@@ -303,3 +303,25 @@ def test_fast_mode_specialised_class_path(env, golden, name):
         d.set_default_mode(d.MODE_EXACT)
         ctx.set_variant(-1)
     golden.expect(name, y, exact=False, rtol_peak=2e-6 if 'k128' in name else TOL_PEAK)
+
+
+def test_lopsided_tables(env):
+    """A channel without taps, a channel with one tap, taps at index 0 and at the very end of a long filter."""
+    d, native, ctx = env
+    rng = np.random.default_rng(31)
+    x = rng.uniform(-1, 1, (2, 20000, 2)).astype(np.float32)
+    firs = []
+    f = np.zeros((1500, 2), np.float32); f[[0, 3, 700, 1499], 0] = [0.5, -0.25, 1.0, 0.125]; firs.append(f)          # channel 1 silent
+    f = np.zeros((1500, 2), np.float32); f[0, 0] = 1.0; f[1, 1] = -1.0; firs.append(f)                              # identity and a one-frame advance
+    f = np.zeros((6000, 2), np.float32); f[[1, 5999], 0] = [1.0, 0.5]; f[[2, 5998], 1] = [0.25, -0.5]; firs.append(f)  # a 5999-frame halo
+    for k, fir in enumerate(firs):
+        table = _table(native, ctx, fir)
+        want = np.stack([O.convolve_velvet_noise(x[b], fir) for b in range(2)])
+        ctx.set_variant(FORCE | span_bits(1, 4))
+        # (the 5999-frame halo does not fit a ring under 64 KiB: that table takes the generic kernels)
+        assert table.describe(2, x.shape[1], 2, d.MODE_FAST).startswith('conv_spec' if k < 2 else 'conv_fast'), k
+        _check(table.convolve_host(x, d.MODE_FAST), want, f'lopsided table {k}')
+        ctx.set_variant(FORCE | EXACT_TOO | span_bits(1, 4))
+        assert np.array_equal(table.convolve_host(x, d.MODE_EXACT), want), k
+        ctx.set_variant(-1)
+        table.close()

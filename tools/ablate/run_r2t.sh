@@ -1,0 +1,3 @@
+set -o pipefail
+timeout -k 10 600 python -m pytest tests/test_gpu_spec.py tests/test_gpu_parity.py -x -q -m gpu -k "lopsided or rms or parallel_sums or epilogue" > gpurun_out/pytest_r2_lop.log 2>&1; echo "pytest exit $?"; tail -3 gpurun_out/pytest_r2_lop.log
+timeout -k 10 500 python tools/big_stream_check.py > gpurun_out/big_r2.log 2>&1; echo "big exit $?"; grep -v amdgpu gpurun_out/big_r2.log | tail -3

@@ -1228,7 +1228,7 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
     // (up to 64 streams: beyond that the one-workgroup-per-stream kernel fills the chip by itself and
     // reads the data once instead of twice; bit 17 forces the block-parallel form for any batch)
     const bool par_sums = sums_pending && C == 2 && !(ctx->variant >= 0 && ((ctx->variant >> 19) & 1)) &&
-                          par_blocks(n) <= 0x7fffffff && (batch <= 64 || (ctx->variant >= 0 && ((ctx->variant >> 17) & 1)));
+                          par_blocks(n) <= kParMaxBlocks && (batch <= 64 || (ctx->variant >= 0 && ((ctx->variant >> 17) & 1)));
     if (par_sums) {
         e.rows = 1;
         e.exact_rms = 1;
@@ -1243,14 +1243,17 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
         r.first = (float *)(r.grp + batch * 4 * (int64_t)r.nblocks);
         r.partials = e.partials;
         r.debug_skip_slow = (ctx->variant >= 0 && ((ctx->variant >> 18) & 1)) ? 1 : 0;
+        r.prefixed = r.nblocks > kParPrefixBlocks ? 1 : 0;
         const dim3 pgrid((unsigned)r.nblocks, (unsigned)batch), tgrid((unsigned)(r.nblocks - 1), (unsigned)batch);
         const dim3 sgrid((unsigned)(batch * 4));
         if (Cx == 1) {
             hipLaunchKernelGGL(rms_par_sum_kernel<true>, pgrid, dim3(kParThreads), 0, stream, r);
+            if (r.prefixed) hipLaunchKernelGGL(rms_par_prefix_kernel, dim3((unsigned)(batch * 4)), dim3(kParThreads), 0, stream, r);
             if (r.nblocks > 1) hipLaunchKernelGGL(rms_par_tally_kernel<true>, tgrid, dim3(kParThreads), 0, stream, r);
             hipLaunchKernelGGL(rms_par_stitch_kernel<true>, sgrid, dim3(64), 0, stream, r);
         } else {
             hipLaunchKernelGGL(rms_par_sum_kernel<false>, pgrid, dim3(kParThreads), 0, stream, r);
+            if (r.prefixed) hipLaunchKernelGGL(rms_par_prefix_kernel, dim3((unsigned)(batch * 4)), dim3(kParThreads), 0, stream, r);
             if (r.nblocks > 1) hipLaunchKernelGGL(rms_par_tally_kernel<false>, tgrid, dim3(kParThreads), 0, stream, r);
             hipLaunchKernelGGL(rms_par_stitch_kernel<false>, sgrid, dim3(64), 0, stream, r);
         }

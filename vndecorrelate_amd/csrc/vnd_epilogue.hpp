@@ -388,6 +388,7 @@ struct RArgs {
     ParRec *__restrict__ rec;        // [batch][4][nblocks]
     ParGrp *__restrict__ grp;        // [batch][4][nblocks]
     float *__restrict__ first;       // [batch][4]: the sum after block 0
+    int32_t prefixed;                // blk_sum already holds EXCLUSIVE prefix sums (rms_par_prefix_kernel ran)
     double *__restrict__ partials;   // [batch][4]: the sums, as the sequential kernel writes them
     int32_t debug_skip_slow;
 };
@@ -462,6 +463,34 @@ __global__ __launch_bounds__(kParThreads) void rms_par_sum_kernel(const RArgs a)
     }
 }
 
+// Long streams (more than kParPrefixBlocks blocks): the block sums are turned into exclusive prefix sums in
+// place by one workgroup per chain - every block adding up its own predecessors is quadratic, 1.3 s for a
+// 300 M-frame stream.  Each thread scans a contiguous stretch; the stretch totals are scanned by thread 0.
+constexpr int kParPrefixBlocks = 2048;
+// Streams beyond 4096 blocks (8.4 M frames) keep the sequential kernel: past ~2^24 frames NumPy's float32
+// running sum stops growing (every square is below half an ulp) while the float64 prediction keeps climbing,
+// and a stitch that mispredicts every block costs far more than it saves (300 M frames: 1.47 s against 0.2 s).
+constexpr int kParMaxBlocks = 4096;
+
+__global__ __launch_bounds__(kParThreads) void rms_par_prefix_kernel(const RArgs a)
+{
+    __shared__ double totals[kParThreads];
+    double *sums = a.blk_sum + (int64_t)blockIdx.x * a.nblocks;
+    const int per = (a.nblocks + kParThreads - 1) / kParThreads;
+    const int lo = min((int)threadIdx.x * per, a.nblocks), hi = min(lo + per, a.nblocks);
+    double t = 0.0;
+    for (int j = lo; j < hi; ++j) t += sums[j];
+    totals[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double run = 0.0;
+        for (int k = 0; k < kParThreads; ++k) { const double v = totals[k]; totals[k] = run; run += v; }
+    }
+    __syncthreads();
+    double run = totals[threadIdx.x];
+    for (int j = lo; j < hi; ++j) { const double v = sums[j]; sums[j] = run; run += v; }
+}
+
 // sum of round(s / ulp) over the groups [g0, g1) of a staged row, with the flags of seq_settle
 __device__ __forceinline__ uint32_t par_tally_groups(const float *row, int g0, int g1, int eb, int lane, bool *bad, bool *zero)
 {
@@ -491,8 +520,12 @@ __global__ __launch_bounds__(kParThreads) void rms_par_tally_kernel(const RArgs 
     // binade matters, and a wrong guess merely sends the block down the sequential path
     const double *sums = a.blk_sum + (b * 4 + chain) * a.nblocks;
     double pre = 0.0;
-    for (int j = lane; j < blk; j += 64) pre += sums[j];
-    pre = wave_sum_f64(pre);
+    if (a.prefixed) {
+        pre = sums[blk];
+    } else {                                               // short streams: every block adds up its predecessors itself
+        for (int j = lane; j < blk; j += 64) pre += sums[j];
+        pre = wave_sum_f64(pre);
+    }
     const int eb = (int)(__float_as_uint((float)pre) >> 23);
     __syncthreads();
     const float *row = sq + chain * kParFrames;
@@ -603,8 +636,9 @@ __global__ __launch_bounds__(64) void rms_par_stitch_kernel(const RArgs a)
 
     // the blocks in which the sum is expected to cross a binade: start the loads of their group g* and of
     // their group tallies now, so that the walk below never waits for memory there
+    // (the first 4096 blocks only: later crossings - a sum doubles ever more slowly - are fetched on demand)
     int slots = 0;
-    for (int base = 1; base < a.nblocks && slots < kParSlots; base += 64) {
+    for (int base = 1; base < min(a.nblocks, 4097) && slots < kParSlots; base += 64) {
         const int mine = base + lane;
         const uint32_t tag = mine < a.nblocks ? rec[mine].tag : 0u;
         uint64_t m = __ballot((tag & kParHint) != 0);
