@@ -325,3 +325,27 @@ def test_lopsided_tables(env):
         assert np.array_equal(table.convolve_host(x, d.MODE_EXACT), want), k
         ctx.set_variant(-1)
         table.close()
+
+
+def test_compiled_kernels_are_cached_on_disk(env, golden, tmp_path, monkeypatch):
+    """The code object of a table's kernel is written under VND_SPEC_CACHE_DIR and loaded from there by the
+    next table object with the same content (the second build must not need hipRTC: VND_SPEC_BREAK would fail it)."""
+    d, native, ctx = env
+    monkeypatch.setenv('VND_SPEC_CACHE_DIR', str(tmp_path / 'cache'))
+    fir = golden.fir('g44k_20ms')
+    x = np.random.default_rng(2).uniform(-1, 1, (2, 30000, 2)).astype(np.float32)
+    want = np.stack([O.convolve_velvet_noise(x[b], fir) for b in range(2)])
+    ctx.set_variant(FORCE)
+    try:
+        t1 = _table(native, ctx, fir)
+        _check(t1.convolve_host(x, d.MODE_FAST), want, 'first build')
+        files = list((tmp_path / 'cache').glob('*.co'))
+        assert len(files) == 1 and files[0].stat().st_size > 1000, (files, t1.describe(2, 30000, 2, d.MODE_FAST))
+        t1.close()
+        t2 = _table(native, ctx, fir)
+        assert t2.describe(2, 30000, 2, d.MODE_FAST).startswith('conv_spec')
+        _check(t2.convolve_host(x, d.MODE_FAST), want, 'from the cache')
+        assert len(list((tmp_path / 'cache').glob('*.co'))) == 1
+        t2.close()
+    finally:
+        ctx.set_variant(-1)

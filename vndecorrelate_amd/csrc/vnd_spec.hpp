@@ -12,8 +12,13 @@
 #include <hip/hiprtc.h>
 #include <stdint.h>
 
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdarg>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -328,6 +333,62 @@ struct SpecModule {
     std::string log;
 };
 
+// ---- code-object cache on disk -----------------------------------------------------------------
+// A table's kernel is a pure function of its generated source, the compile options and the hipRTC
+// version: the compiled code object is kept under $VND_SPEC_CACHE_DIR (default ~/.cache/vndecorrelate_amd;
+// "off" disables) under a 64-bit FNV-1a key, so only the first process that meets a table pays the
+// 1.5-5 s of hipRTC.  Any I/O problem just means compiling.
+inline std::string spec_cache_dir()
+{
+    if (const char *e = getenv("VND_SPEC_CACHE_DIR")) return std::string(e) == "off" ? std::string() : std::string(e);
+    const char *home = getenv("HOME");
+    return home && *home ? std::string(home) + "/.cache/vndecorrelate_amd" : std::string();
+}
+
+inline std::string spec_cache_key(const std::string &src, const char *const *opts, int nopts)
+{
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const char *p, size_t n) { for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; } };
+    mix(src.data(), src.size());
+    for (int i = 0; i < nopts; ++i) mix(opts[i], strlen(opts[i]) + 1);
+    int major = 0, minor = 0;
+    (void)hiprtcVersion(&major, &minor);
+    mix((const char *)&major, sizeof major);
+    mix((const char *)&minor, sizeof minor);
+    char buf[32];
+    snprintf(buf, sizeof buf, "%016llx", (unsigned long long)h);
+    return buf;
+}
+
+inline bool spec_cache_load(const std::string &path, std::vector<char> *code)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    bool ok = false;
+    if (fseek(f, 0, SEEK_END) == 0) {
+        const long n = ftell(f);
+        if (n > 64 && fseek(f, 0, SEEK_SET) == 0) {
+            code->resize((size_t)n);
+            ok = fread(code->data(), 1, (size_t)n, f) == (size_t)n && memcmp(code->data(), "\177ELF", 4) == 0;
+        }
+    }
+    fclose(f);
+    return ok;
+}
+
+inline void spec_cache_store(const std::string &dir, const std::string &path, const std::vector<char> &code)
+{
+    std::string cmd_dir = dir;
+    for (size_t i = 1; i <= cmd_dir.size(); ++i)                     // mkdir -p
+        if (i == cmd_dir.size() || cmd_dir[i] == '/') { const std::string part = cmd_dir.substr(0, i); (void)mkdir(part.c_str(), 0755); }
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+    fclose(f);
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());     // rename is atomic: readers never see half a file
+}
+
 inline bool spec_compile(const SpecTable &t, const SpecConfig &cfg, int device, int lds_limit, SpecModule *m)
 {
     m->cfg = cfg;
@@ -337,29 +398,37 @@ inline bool spec_compile(const SpecTable &t, const SpecConfig &cfg, int device, 
     if (const char *dump = getenv("VND_SPEC_DUMP")) {
         if (FILE *f = fopen(dump, "w")) { fputs(src.c_str(), f); fclose(f); }
     }
-    hiprtcProgram prog = nullptr;
-    if (hiprtcCreateProgram(&prog, src.c_str(), "vnd_spec_kernel.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
-        m->failed = true; m->log = "hiprtcCreateProgram failed";
-        return false;
-    }
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
-    const hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
-    size_t log_size = 0;
-    hiprtcGetProgramLogSize(prog, &log_size);
-    if (log_size > 1) { m->log.resize(log_size); hiprtcGetProgramLog(prog, &m->log[0]); }
-    if (rc != HIPRTC_SUCCESS) {
+    std::vector<char> code;
+    const std::string dir = spec_cache_dir();
+    const std::string path = dir.empty() ? std::string() : dir + "/" + spec_cache_key(src, opts, 4) + ".co";
+    if (path.empty() || !spec_cache_load(path, &code)) {
+        hiprtcProgram prog = nullptr;
+        if (hiprtcCreateProgram(&prog, src.c_str(), "vnd_spec_kernel.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+            m->failed = true; m->log = "hiprtcCreateProgram failed";
+            return false;
+        }
+        const hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
+        size_t log_size = 0;
+        hiprtcGetProgramLogSize(prog, &log_size);
+        if (log_size > 1) { m->log.resize(log_size); hiprtcGetProgramLog(prog, &m->log[0]); }
+        if (rc != HIPRTC_SUCCESS) {
+            hiprtcDestroyProgram(&prog);
+            m->failed = true;
+            return false;
+        }
+        size_t code_size = 0;
+        hiprtcGetCodeSize(prog, &code_size);
+        code.resize(code_size);
+        hiprtcGetCode(prog, code.data());
         hiprtcDestroyProgram(&prog);
-        m->failed = true;
-        return false;
+        if (!path.empty()) spec_cache_store(dir, path, code);
     }
-    size_t code_size = 0;
-    hiprtcGetCodeSize(prog, &code_size);
-    std::vector<char> code(code_size);
-    hiprtcGetCode(prog, code.data());
-    hiprtcDestroyProgram(&prog);
     (void)device;
     if (hipModuleLoadData(&m->module, code.data()) != hipSuccess ||
         hipModuleGetFunction(&m->fn, m->module, "vnd_spec_kernel") != hipSuccess) {
+        (void)hipGetLastError();
+        if (!path.empty()) (void)remove(path.c_str());        // a cached object this runtime cannot load: next time, compile
         m->failed = true; m->log += " (module load failed)";
         return false;
     }
