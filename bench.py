@@ -445,7 +445,10 @@ def main():
             line['cfg4_strong'] = strong
         if world == 1 and not args.no_secondary:
             line['secondary'] = secondary_configs(torch, vnd, _native, ctx, mode)
-            line['end_to_end'] = end_to_end(torch, vnd, mode)
+            try:
+                line['end_to_end'] = end_to_end(torch, vnd, mode)
+            except Exception as exc:                    # as above: never at the headline's expense
+                line['end_to_end'] = {'error': repr(exc)}
         if world == 1 and not args.no_cpu:
             line['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)
