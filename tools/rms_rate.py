@@ -20,7 +20,7 @@ for pool in (1, 128):
     ws_bytes = _native.decorrelate_workspace_bytes(pool, n, 2)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device='cuda')
     outs = {}
-    for name, variant in (('sequential', SEQ), ('parallel', -1), ('par-noslow', 1 << 18), ('sequential', SEQ), ('parallel', -1), ('par-noslow', 1 << 18)):
+    for name, variant in (('sequential', SEQ), ('parallel', -1), ('sequential', SEQ), ('parallel', -1)):
         ctx.set_variant(variant)
         def run():
             table.decorrelate_device(x.data_ptr(), y.data_ptr(), pool, n, 2, mode=0, ms_encode=True, width=None,

@@ -1242,7 +1242,6 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
         r.grp = (ParGrp *)(r.rec + batch * 4 * (int64_t)r.nblocks);
         r.first = (float *)(r.grp + batch * 4 * (int64_t)r.nblocks);
         r.partials = e.partials;
-        r.debug_skip_slow = (ctx->variant >= 0 && ((ctx->variant >> 18) & 1)) ? 1 : 0;
         r.prefixed = r.nblocks > kParPrefixBlocks ? 1 : 0;
         const dim3 pgrid((unsigned)r.nblocks, (unsigned)batch), tgrid((unsigned)(r.nblocks - 1), (unsigned)batch);
         const dim3 sgrid((unsigned)(batch * 4));

@@ -226,6 +226,32 @@ __device__ __forceinline__ bool seq_settle(const SeqTally &t, float &acc, int eb
     return ab == 0 && __ballot(t.any_bits != 0) == 0;               // +0 + +0 ... : still +0
 }
 
+// the 256 dependent float32 additions of one group (every lane runs the chain on broadcast reads; the reads
+// of the next 32 squares are in flight while the current 32 are added, so only the adds' own latency is paid)
+__device__ __forceinline__ float seq_add_group(const float *sqs, float t)
+{
+    float4 v[2][8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[0][u] = *(const float4 *)(sqs + 4 * u);
+#pragma unroll
+    for (int i = 0; i < kSeqGroup / 32; ++i) {
+        if (i + 1 < kSeqGroup / 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[(i + 1) & 1][u] = *(const float4 *)(sqs + 32 * (i + 1) + 4 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 q = v[i & 1][u];
+            t = t + q.x; t = t + q.y; t = t + q.z; t = t + q.w;
+        }
+    }
+    return t;
+}
+
+// PIPELINED: the wave has the CU to itself (block-parallel kernels) and pays 64 registers for the reads in
+// flight; the one-workgroup-per-stream kernel keeps the short form (its other waves hide the LDS latency,
+// and the registers would spill under its 256-thread bound)
+template <bool PIPELINED>
 __device__ __forceinline__ float seq_sum_group(const float *row, float acc, int lane)
 {
     const int eb = (int)(__float_as_uint(acc) >> 23);   // acc is a sum of squares: sign 0 (a NaN may set it: eb > 255)
@@ -233,25 +259,29 @@ __device__ __forceinline__ float seq_sum_group(const float *row, float acc, int 
     seq_tally(t, *(const float4 *)(row + 4 * lane), seq_scale(eb));
     if (seq_settle(t, acc, eb)) return acc;
     // one after the other; every lane does the same adds on the same (broadcast) LDS words
+    if constexpr (PIPELINED) {
+        return seq_add_group(row, acc);
+    } else {
 #pragma unroll 1
-    for (int i = 0; i < kSeqGroup; i += 16) {
-        float4 v[4];
+        for (int i = 0; i < kSeqGroup; i += 16) {
+            float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *(const float4 *)(row + i + 4 * u);
+            for (int u = 0; u < 4; ++u) v[u] = *(const float4 *)(row + i + 4 * u);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc = acc + v[u].x;
-            acc = acc + v[u].y;
-            acc = acc + v[u].z;
-            acc = acc + v[u].w;
+            for (int u = 0; u < 4; ++u) {
+                acc = acc + v[u].x;
+                acc = acc + v[u].y;
+                acc = acc + v[u].z;
+                acc = acc + v[u].w;
+            }
         }
+        return acc;
     }
-    return acc;
 }
 
 // A whole staged block at once when nothing in it needs care (one reduction per 2048 squares),
 // else group by group.
-template <int FRAMES>
+template <int FRAMES, bool PIPELINED = false>
 __device__ __forceinline__ float seq_sum_block(const float *row, float acc, int lane)
 {
     const int eb = (int)(__float_as_uint(acc) >> 23);
@@ -261,7 +291,7 @@ __device__ __forceinline__ float seq_sum_block(const float *row, float acc, int 
     for (int g = 0; g < FRAMES; g += kSeqGroup) seq_tally(t, *(const float4 *)(row + g + 4 * lane), scale);
     if (seq_settle(t, acc, eb)) return acc;
 #pragma unroll 1
-    for (int g = 0; g < FRAMES; g += kSeqGroup) acc = seq_sum_group(row + g, acc, lane);
+    for (int g = 0; g < FRAMES; g += kSeqGroup) acc = seq_sum_group<PIPELINED>(row + g, acc, lane);
     return acc;
 }
 
@@ -367,14 +397,14 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
 constexpr int kParFrames = 2048;
 constexpr int kParThreads = 256;
 constexpr int kParGroups = kParFrames / kSeqGroup;       // 8
-constexpr int kParSlots = 16;                            // binade crossings prefetched per chain (a sum crosses each binade once)
+constexpr int kParSlots = 24;                            // groups prefetched per chain: binade crossings (a sum crosses each binade once) and ties
 constexpr uint32_t kParZero = 1u << 9, kParBad = 1u << 10, kParHint = 1u << 12;
 
 struct ParRec {                       // 16 bytes per (chain, block)
     uint32_t tag;                     // bits 0-8 predicted biased exponent e; flags; bits 16-18 g* (with kParHint)
     uint32_t qtot;                    // the whole block's tally against ulp(e) (valid unless kParBad)
     uint32_t bad;                     // bit g: group g cannot be settled against ulp(e); bit 8 + g: against ulp(e + 1)
-    uint32_t pad;
+    uint32_t need;                    // bit g: group g is expected to take the 256 dependent additions (g*, or bad in its binade)
 };
 struct ParGrp { uint32_t qe[kParGroups], qf[kParGroups]; };      // per-group tallies against ulp(e) and ulp(e + 1)
 
@@ -390,7 +420,6 @@ struct RArgs {
     float *__restrict__ first;       // [batch][4]: the sum after block 0
     int32_t prefixed;                // blk_sum already holds EXCLUSIVE prefix sums (rms_par_prefix_kernel ran)
     double *__restrict__ partials;   // [batch][4]: the sums, as the sequential kernel writes them
-    int32_t debug_skip_slow;
 };
 
 // squares of block `blk` of stream b into sq[4][2048] (chains: x ch0, x ch1, y ch0, y ch1); frames
@@ -458,7 +487,7 @@ __global__ __launch_bounds__(kParThreads) void rms_par_sum_kernel(const RArgs a)
     s = wave_sum_f64(s);
     if (lane == 0) a.blk_sum[(b * 4 + chain) * a.nblocks + blk] = s;
     if (blk == 0) {                                       // the chain's start: the recurrence itself, from +0
-        const float acc = seq_sum_block<kParFrames>(row, 0.0f, lane);
+        const float acc = seq_sum_block<kParFrames, true>(row, 0.0f, lane);
         if (lane == 0) a.first[b * 4 + chain] = acc;
     }
 }
@@ -565,9 +594,31 @@ __global__ __launch_bounds__(kParThreads) void rms_par_tally_kernel(const RArgs 
         if (all_zero) r.tag |= kParZero;
         if ((bad_bits & 0xffu) != 0 || qtot >= (1u << 24)) r.tag |= kParBad;
         if (gstar < kParGroups) r.tag |= kParHint | ((uint32_t)gstar << 16);
-        r.qtot = qtot; r.bad = bad_bits; r.pad = 0;
+        r.qtot = qtot; r.bad = bad_bits;
+        // the groups the stitch will most likely have to add one by one: g* itself, before it the groups
+        // that cannot be settled against ulp(e), after it those that cannot against ulp(e + 1)
+        r.need = gstar < kParGroups ? ((1u << gstar) | (bad_bits & ((1u << gstar) - 1u)) | ((bad_bits >> 8) & 0xffu & ~((2u << gstar) - 1u)))
+                                    : (bad_bits & 0xffu);
         a.rec[at] = r;
     }
+}
+
+// four consecutive samples of one chain for this lane: frames f0 + 4*lane .. + 3 of stream b (0 past the end)
+template <bool MONO>
+__device__ __forceinline__ float4 par_fetch4(const RArgs &a, int64_t b, int chain, int64_t f0, int lane)
+{
+    const bool from_x = chain < 2;
+    const int ch = chain & 1;
+    const int fr = 4 * lane;
+    if (from_x && MONO) {
+        const v4i rs = make_rsrc(a.x + b * a.n + f0, (a.n - f0) * 4);
+        return make_float4(buf_load1(rs, (fr + 0) * 4, 0, 0), buf_load1(rs, (fr + 1) * 4, 0, 0),
+                           buf_load1(rs, (fr + 2) * 4, 0, 0), buf_load1(rs, (fr + 3) * 4, 0, 0));
+    }
+    const float *src = (from_x ? a.x : a.y) + (b * a.n + f0) * 2 + ch;
+    const v4i rs = make_rsrc(src, ((a.n - f0) * 2 - ch) * 4);
+    return make_float4(buf_load1(rs, (fr + 0) * 8, 0, 0), buf_load1(rs, (fr + 1) * 8, 0, 0),
+                       buf_load1(rs, (fr + 2) * 8, 0, 0), buf_load1(rs, (fr + 3) * 8, 0, 0));
 }
 
 // squares of `count` frames of one chain, starting at frame f0 of stream b, into dst (4 per lane and round)
@@ -596,36 +647,24 @@ __device__ __forceinline__ void par_load_squares(const RArgs &a, int64_t b, int 
     }
 }
 
-// inclusive prefix sum over the wave's lanes (DPP row shifts, then the row totals)
-__device__ __forceinline__ uint32_t wave_prefix_u32(uint32_t x, int lane)
+// inclusive prefix sum over the wave's lanes: Hillis-Steele inside each row of 16 (DPP row_shr, lanes
+// without a source add 0), then the row totals (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2-3)
+__device__ __forceinline__ uint32_t wave_prefix_u32(uint32_t x, int)
 {
-#pragma unroll
-    for (int sh = 1; sh < 64; sh <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)x, sh);
-        if (lane >= sh) x += up;
-    }
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
     return x;
-}
-
-// the 256 dependent float32 additions of one group (every lane runs the chain on broadcast reads)
-__device__ __forceinline__ float par_add_group(const float *sqs, float t)
-{
-#pragma unroll 1
-    for (int i = 0; i < kSeqGroup; i += 16) {
-        float4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *(const float4 *)(sqs + i + 4 * u);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { t = t + v[u].x; t = t + v[u].y; t = t + v[u].z; t = t + v[u].w; }
-    }
-    return t;
 }
 
 // one wave per (stream, chain): blockIdx.x = stream * 4 + chain
 template <bool MONO>
 __global__ __launch_bounds__(64) void rms_par_stitch_kernel(const RArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float crossing[kParSlots][kSeqGroup];      // squares of the hinted groups g*
+    __shared__ __attribute__((aligned(16))) float crossing[kParSlots][kSeqGroup];      // squares of the foreseen groups
     __shared__ uint32_t grp_lds[kParSlots][2 * kParGroups];                            // and their blocks' group tallies
     __shared__ __attribute__((aligned(16))) float scratch[kSeqGroup];                  // a group fetched on demand
     const int lane = threadIdx.x;
@@ -634,26 +673,55 @@ __global__ __launch_bounds__(64) void rms_par_stitch_kernel(const RArgs a)
     const ParRec *rec = a.rec + (b * 4 + chain) * a.nblocks;
     const ParGrp *grp = a.grp + (b * 4 + chain) * a.nblocks;
 
-    // the blocks in which the sum is expected to cross a binade: start the loads of their group g* and of
-    // their group tallies now, so that the walk below never waits for memory there
-    // (the first 4096 blocks only: later crossings - a sum doubles ever more slowly - are fetched on demand)
+    // the groups the walk is expected to add one by one (binade crossings, ties: ParRec::need): fetch them
+    // and their blocks' group tallies before the walk, all in flight together, so that the walk does not
+    // wait for memory there; anything not foreseen is fetched on demand
+    __shared__ int slot_key[kParSlots];                    // block * 8 + group, ascending
     int slots = 0;
-    for (int base = 1; base < min(a.nblocks, 4097) && slots < kParSlots; base += 64) {
-        const int mine = base + lane;
-        const uint32_t tag = mine < a.nblocks ? rec[mine].tag : 0u;
-        uint64_t m = __ballot((tag & kParHint) != 0);
-        while (m != 0 && slots < kParSlots) {
-            const int i = __builtin_ctzll(m);
-            m &= m - 1;
-            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tag, i);
-            const int64_t f0 = (int64_t)(base + i) * kParFrames + (int64_t)((t >> 16) & 7u) * kSeqGroup;
-            par_load_squares<MONO>(a, b, chain, f0, kSeqGroup, crossing[slots], lane);
-            if (lane < 2 * kParGroups) grp_lds[slots][lane] = ((const uint32_t *)&grp[base + i])[lane];
-            ++slots;
+    for (int base = 1; base < a.nblocks && slots < kParSlots; base += 256) {
+        uint32_t need[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int mine = base + 64 * u + lane;
+            need[u] = mine < a.nblocks ? rec[mine].need : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t cnt = (uint32_t)__builtin_popcount(need[u]);
+            const uint32_t incl = wave_prefix_u32(cnt, lane);
+            int at = slots + (int)(incl - cnt);
+            for (uint32_t nm = need[u]; nm != 0; nm &= nm - 1, ++at)
+                if (at < kParSlots) slot_key[at] = (base + 64 * u + lane) * 8 + (int)__builtin_ctz(nm);
+            slots += __builtin_amdgcn_readlane((int)incl, 63);
         }
     }
+    slots = min(slots, kParSlots);
+    __syncthreads();
+    {
+        float4 raw[kParSlots];
+        uint32_t tally[kParSlots];
+#pragma unroll
+        for (int s = 0; s < kParSlots; ++s) {
+            raw[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            tally[s] = 0u;
+            if (s < slots) {
+                const int key = slot_key[s];
+                raw[s] = par_fetch4<MONO>(a, b, chain, (int64_t)(key >> 3) * kParFrames + (int64_t)(key & 7) * kSeqGroup, lane);
+                if (lane < 2 * kParGroups) tally[s] = ((const uint32_t *)&grp[key >> 3])[lane];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < kParSlots; ++s) {
+            if (s < slots) {
+                const float4 v = raw[s];
+                *(float4 *)(crossing[s] + 4 * lane) = make_float4(v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w);
+                if (lane < 2 * kParGroups) grp_lds[s][lane] = tally[s];
+            }
+        }
+    }
+    __syncthreads();
+    const int my_key = lane < slots ? slot_key[lane] : -1;         // lane s knows slot s (kParSlots <= 64)
     float acc = a.first[b * 4 + chain];
-    int hints_before = 0;                                  // hinted blocks in earlier chunks (slots are in block order)
     ParRec nxt = {kParZero, 0u, 0u, 0u};
     if (1 + lane < a.nblocks) nxt = rec[1 + lane];
     for (int base = 1; base < a.nblocks; base += 64) {
@@ -661,7 +729,6 @@ __global__ __launch_bounds__(64) void rms_par_stitch_kernel(const RArgs a)
         nxt = ParRec{kParZero, 0u, 0u, 0u};
         if (base + 64 + lane < a.nblocks) nxt = rec[base + 64 + lane];     // in flight while this chunk is walked
         const int count = min(64, a.nblocks - base);
-        const uint64_t hint_mask = __ballot((r.tag & kParHint) != 0);      // a hinted block may also be accepted in a run
         int cur = 0;
         while (cur < count) {
             // every block from `cur` on that can be settled against acc's binade, as far as the integer
@@ -688,14 +755,11 @@ __global__ __launch_bounds__(64) void rms_par_stitch_kernel(const RArgs a)
             const uint32_t tag = (uint32_t)__builtin_amdgcn_readlane((int)r.tag, cur);
             const uint32_t bad = (uint32_t)__builtin_amdgcn_readlane((int)r.bad, cur);
             const int blk = base + cur;
-            const bool hinted = (tag & kParHint) != 0;
-            const int slot = hinted ? hints_before + (int)__builtin_popcountll(hint_mask & ((1ull << cur) - 1ull)) : -1;
             ++cur;
-            if (a.debug_skip_slow) continue;              // timing experiments only (variant bit 18): wrong sums
             const int e0 = (int)(tag & 0x1ffu);
-            const int gstar = (int)((tag >> 16) & 7u);
+            const uint64_t of_block = __ballot((my_key >> 3) == blk);       // the slots holding groups of this block
             uint32_t gq = 0;                               // lane g: qe[g], lane 8 + g: qf[g]
-            if (slot >= 0 && slot < slots) { if (lane < 2 * kParGroups) gq = grp_lds[slot][lane]; }
+            if (of_block != 0) { if (lane < 2 * kParGroups) gq = grp_lds[__builtin_ctzll(of_block)][lane]; }
             else if (lane < 2 * kParGroups) gq = ((const uint32_t *)&grp[blk])[lane];
             for (int g = 0; g < kParGroups; ++g) {
                 const uint32_t cb = __float_as_uint(acc);
@@ -708,15 +772,16 @@ __global__ __launch_bounds__(64) void rms_par_stitch_kernel(const RArgs a)
                         continue;
                     }
                 }
-                const float *sqs = crossing[slot >= 0 && slot < slots ? slot : 0];
-                if (!(slot >= 0 && slot < slots && g == gstar)) {
+                const uint64_t held = __ballot(my_key == blk * 8 + g);
+                const float *sqs = scratch;
+                if (held != 0) {
+                    sqs = crossing[__builtin_ctzll(held)];
+                } else {
                     par_load_squares<MONO>(a, b, chain, (int64_t)blk * kParFrames + (int64_t)g * kSeqGroup, kSeqGroup, scratch, lane);
-                    sqs = scratch;
                 }
-                acc = par_add_group(sqs, acc);
+                acc = seq_add_group(sqs, acc);
             }
         }
-        hints_before += (int)__builtin_popcountll(hint_mask);
     }
     if (lane == 0) a.partials[b * 4 + chain] = (double)acc;
 }
