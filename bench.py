@@ -169,10 +169,11 @@ def secondary_configs(torch, vnd, _native, ctx, mode) -> dict:
         ('cfg3', dict(duration_seconds=0.03, num_impulses=128, num_outs=2, sample_rate_hz=48000,
                       log_distribution_strength=0.0, seed=1), (24, 2880000, 2), 1,
          '48 kHz stereo, 60 s, 128 taps (segmented decay, kappa 0); pool of 24',
-         'LDS reads + VALU (128 taps per sample: 4 x the LDS bytes and FMAs of cfg2 per HBM byte)'),
+         'LDS bandwidth: 870 B of LDS reads per 16 B of HBM traffic, LDS busy 0.74 of CU-cycles (profiles/r02_cfg3_cfg5_pmc.txt)'),
         ('cfg5', dict(duration_seconds=0.03, num_impulses=64, num_outs=8, sample_rate_hz=96000, seed=1),
          (16, 960000, 8), 1, '96 kHz 8-channel, 10 s, 64 log-distributed taps; pool of 16',
-         'LDS reads + VALU (64 taps per sample)'),
+         'L2 request rate: a workgroup owns one channel pair, so lanes load/store 8 B of each 32-B frame - 77 M requests per launch, '
+         '12.7 B each; LDS busy 0.47 (profiles/r02_cfg3_cfg5_pmc.txt)'),
         ('cfg4', dict(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1),
          (1024, 48000, 2), 2, '1024 independent 1 s stereo streams, 30 taps, one launch; 2 rotating pools',
          'board power cap, as cfg2'),
