@@ -139,6 +139,7 @@ inline std::string spec_prologue(const SpecTable &t, const SpecConfig &c)
                 c.pp, c.dd, c.la);
     spec_append(s, "#define VS_C %d\n#define VS_GROUPS %d\n#define VS_NT_STORES %d\n#define VS_EXACT %d\n", t.C, groups,
                 c.nt_stores, c.exact);
+    spec_append(s, "#define VS_NT_STORE_AUX %d\n", spec_env("VND_SPEC_STORE_AUX", 2));   // cache policy bits of the non-temporal stores (tuning)
     spec_append(s, "#define VS_LOAD_AUX %d\n", spec_env("VND_SPEC_LOAD_AUX", 2));     // input is read once: non-temporal loads (+1-2 % on cfg2)
     {   // resident workgroups per CU (LDS-bound, at most 32 waves) -> waves per SIMD the register budget must allow
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, 2048 / c.nt), (160 * 1024) / c.lds_bytes()));
