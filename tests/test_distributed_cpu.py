@@ -109,3 +109,45 @@ def test_two_rank_sharded_run(tmp_path):
     assert np.array_equal(y, c_oracle.convolve(x, offs, idx, w))
     for b in range(7):                                                  # streams are independent
         assert np.array_equal(y[b], O.convolve_velvet_noise(x[b], fir))
+
+
+def _time_shard_worker(rank, world, port, out_dir, cuts):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import sys
+        import pathlib
+        sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+        from oracle import c_oracle
+        from oracle import vnd_oracle as O
+        from vndecorrelate_amd.distributed import ShardedDecorrelator
+
+        def checker_backend(arrays):
+            return lambda x_local, mode: c_oracle.convolve(x_local, arrays.tap_offsets, arrays.tap_index, arrays.tap_weight)
+
+        fir = O.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, sample_rate_hz=48000, seed=1)
+        sharded = ShardedDecorrelator(function_path_arrays(fir) if rank == 0 else None, src=0, backend=checker_backend)
+        x = np.random.default_rng(5).uniform(-1, 1, (cuts[-1], 2)).astype(np.float32)
+        y_local = sharded.convolve_time_shard(x[cuts[rank]:cuts[rank + 1]])
+        assert y_local.shape == (cuts[rank + 1] - cuts[rank], 2)
+        np.save(os.path.join(out_dir, f't{rank}.npy'), y_local)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('cuts', [
+    (0, 9000, 20000),                 # two ranks, slices longer than the 1260-frame halo
+    (0, 5000, 5400, 5401, 12000),     # four ranks: the halo of rank 0 spans ranks 1, 2 and 3
+    (0, 4000, 4000, 7000),            # an empty slice in the middle
+    (0, 6000, 6800),                  # the last slice is shorter than the halo: the stream's true end
+])
+def test_one_stream_cut_in_time_over_ranks(tmp_path, cuts):
+    """A long stream cut over the ranks with one forward-halo exchange equals the unsharded call, bit for bit."""
+    from oracle import vnd_oracle as O
+    world = len(cuts) - 1
+    mp.spawn(_time_shard_worker, args=(world, _free_port(), str(tmp_path), cuts), nprocs=world, join=True)
+    y = np.concatenate([np.load(tmp_path / f't{r}.npy') for r in range(world)])
+    fir = O.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, sample_rate_hz=48000, seed=1)
+    x = np.random.default_rng(5).uniform(-1, 1, (cuts[-1], 2)).astype(np.float32)
+    assert np.array_equal(y, O.convolve_velvet_noise(x, fir))

@@ -60,6 +60,13 @@ def _rank_main(rank, world, port, backend, n_devices, result_dir):
             ok &= bool(np.max(np.abs(y_fast[i].cpu().numpy() - want)) <= 1e-6 * np.max(np.abs(want)))
         # host-array form agrees
         ok &= bool(np.array_equal(sharded.convolve_local(x_all[start:start + count], vnd.MODE_EXACT), y_exact.cpu().numpy()))
+        # ONE long stream cut in time over the ranks (forward-halo send/recv), GPU kernels per rank:
+        # rank 0 takes 50 000 frames, rank 1 the last 900 - shorter than the 1260-frame halo
+        long_x = np.random.default_rng(23).uniform(-1, 1, (50900, 2)).astype(np.float32)
+        cut = (0, 50000, 50900)
+        y_time = sharded.convolve_time_shard(long_x[cut[rank]:cut[rank + 1]], vnd.MODE_EXACT,
+                                             device=device if backend == 'nccl' else None)
+        ok &= bool(np.array_equal(y_time, O.convolve_velvet_noise(long_x, fir)[cut[rank]:cut[rank + 1]]))
         with open(os.path.join(result_dir, f'rank{rank}.txt'), 'w') as f:
             f.write(f'{int(ok)} {start} {count} {backend} {device_index}')
     finally:

@@ -4,7 +4,9 @@ The hot path shards by *independent streams* (reference: the channel loop and
 nothing else couples samples, decorrelation.py:649): every rank
 owns a contiguous block of the batch, runs the same kernels on its own GPU, and
 no collective sits on the data path.  The only communication is one broadcast of
-the shared tap-table image (8*K*C bytes + header) from the rank that built it -
+the shared tap-table image (8*K*C bytes + header) from the rank that built it
+(and, when ONE long stream is cut over the ranks in time, one forward-halo
+send/recv per rank: ``ShardedDecorrelator.convolve_time_shard``) -
 ``torch.distributed`` with backend ``nccl`` is RCCL over xGMI on ROCm; ``gloo``
 works too (that is what the CPU tests use).
 
@@ -116,6 +118,59 @@ class ShardedDecorrelator:
                 s = torch.cuda.current_stream().cuda_stream if stream is None else stream
                 table.convolve_device(x_local.data_ptr(), y_local.data_ptr(), b_local, n, c, mode, s)
         return y_local
+
+    def convolve_time_shard(self, x_local: np.ndarray, mode: int = 2, device=None) -> np.ndarray:
+        """ONE long stream cut over the ranks in time: rank r holds the contiguous frames
+        ``x_local`` ``(n_r, C)`` that follow rank r-1's.  Output frame n reads input frames
+        n .. n + max_index (``x[n + i]``, decorrelation.py:656-658), so every rank needs the first
+        ``max_index`` frames that FOLLOW its slice: one forward-halo exchange (point-to-point
+        send/recv, RCCL over xGMI with backend ``nccl``: 11.5 KB at cfg2) and no other traffic
+        (SURVEY.md 8e).  Slices shorter than the halo are handled (the halo then comes from
+        several ranks); the stream's true end keeps the reference's dropped terms.  Returns this
+        rank's ``(n_r, C)`` outputs - in exact mode bit-identical to the unsharded call."""
+        import torch
+        import torch.distributed as dist
+        if x_local.ndim != 2:
+            raise ValueError(f'expected (frames, C), got {x_local.shape}')
+        x_local = np.ascontiguousarray(x_local, dtype=np.float32)
+        n_local, channels = x_local.shape
+        if not dist.is_initialized() or self.world_size == 1:
+            return self._convolve(x_local[None], mode)[0] if n_local else np.zeros_like(x_local)
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device()) \
+                if dist.get_backend(self.group) == 'nccl' else torch.device('cpu')
+        counts = torch.zeros(self.world_size, dtype=torch.int64, device=device)
+        counts[self.rank] = n_local
+        dist.all_reduce(counts, group=self.group)                       # every rank learns every slice length
+        counts = [int(v) for v in counts.cpu()]
+        starts = np.concatenate([[0], np.cumsum(counts)])
+        halo = int(self.arrays.tap_index.max()) if len(self.arrays.tap_index) else 0
+
+        def wanted(r):                                                  # the frames rank r needs past its own
+            return int(starts[r + 1]), int(min(starts[r + 1] + halo, starts[-1]))
+
+        mine = torch.from_numpy(x_local).to(device)
+        ops, pieces = [], []
+        lo, hi = wanted(self.rank)
+        for s in range(self.rank + 1, self.world_size):                 # receive: prefixes of later slices
+            a, b = max(lo, int(starts[s])), min(hi, int(starts[s + 1]))
+            if b > a:
+                buf = torch.empty((b - a, channels), dtype=torch.float32, device=device)
+                pieces.append(buf)
+                ops.append(dist.P2POp(dist.irecv, buf, s, group=self.group))
+        for r in range(self.rank):                                      # send: what earlier ranks need of mine
+            rlo, rhi = wanted(r)
+            a, b = max(rlo, int(starts[self.rank])), min(rhi, int(starts[self.rank + 1]))
+            if b > a:
+                part = mine[a - int(starts[self.rank]):b - int(starts[self.rank])].contiguous()
+                ops.append(dist.P2POp(dist.isend, part, r, group=self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if n_local == 0:
+            return np.zeros_like(x_local)
+        window = np.concatenate([x_local] + [p.cpu().numpy() for p in pieces]) if pieces else x_local
+        return self._convolve(window[None], mode)[0, :n_local]
 
     def convolve_global(self, x_all: np.ndarray, mode: int = 2) -> np.ndarray:
         """Convenience for small jobs: every rank passes the same full batch and gets
