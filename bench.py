@@ -170,6 +170,11 @@ def secondary_configs(torch, vnd, _native, ctx, mode) -> dict:
                       log_distribution_strength=0.0, seed=1), (24, 2880000, 2), 1,
          '48 kHz stereo, 60 s, 128 taps (segmented decay, kappa 0); pool of 24',
          'LDS bandwidth: 870 B of LDS reads per 16 B of HBM traffic, LDS busy 0.74 of CU-cycles (profiles/r02_cfg3_cfg5_pmc.txt)'),
+        ('cfg3_kappa1', dict(duration_seconds=0.03, num_impulses=128, num_outs=2, sample_rate_hz=48000,
+                             log_distribution_strength=1.0, seed=1), (24, 2880000, 2), 1,
+         '48 kHz stereo, 60 s, 128 impulses log-distributed (kappa 1): the function path keeps 123 distinct taps per channel '
+         '(last write wins on duplicate indices, SURVEY 8d); pool of 24',
+         'LDS bandwidth, as cfg3'),
         ('cfg5', dict(duration_seconds=0.03, num_impulses=64, num_outs=8, sample_rate_hz=96000, seed=1),
          (16, 960000, 8), 1, '96 kHz 8-channel, 10 s, 64 log-distributed taps; pool of 16',
          'L2 request rate: a workgroup owns one channel pair, so lanes load/store 8 B of each 32-B frame - 77 M requests per launch, '

@@ -133,9 +133,10 @@ vnd_status vnd_convolve_promote_host(vnd_ctx *ctx, int32_t num_channels, const i
  *   use_width  apply_stereo_width(y, width)             utils/dsp.py:21-37   (2 channels)
  *   normalize  rms_normalize(x, y), DUAL_MONO           utils/dsp.py:87-109  (eps = 1e-10 upstream)
  * The pointwise steps are bit-identical to NumPy.  The normaliser's sums of squares:
- *   VND_MODE_EXACT, or normalize = VND_NORMALIZE_RMS_REFERENCE_ORDER in any mode (2+ channels):
- *     NumPy's own sequential float32 recurrence, reproduced bit for bit - in exact mode the
- *     whole stage is bit-identical to the reference;
+ *   VND_MODE_EXACT, or normalize = VND_NORMALIZE_RMS_REFERENCE_ORDER in any mode:
+ *     NumPy's own float32 summation order, reproduced bit for bit - the sequential row-by-row
+ *     recurrence of an (n, C >= 2) array, the pairwise sums (8192-element chunks) of an (n, 1)
+ *     one; in exact mode the whole stage is bit-identical to the reference;
  *   otherwise (normalize = VND_NORMALIZE_RMS): exactly rounded float64 sums, fused into the
  *     fast kernel - the fastest form, ~1e-4 relative from NumPy's RMS on long signals.
  * `workspace` is device memory of >= vnd_decorrelate_workspace_bytes().          */

@@ -182,6 +182,7 @@ CLS = {  # VelvetNoise kwargs by name
     'v96k_c8':    dict(sample_rate_hz=96000, seed=1, num_impulses=64, num_outs=8, mode='LR',
                        filtered_channels=tuple(range(8))),
     'v44k_55ms':  dict(sample_rate_hz=44100, duration_seconds=0.055, num_impulses=45, seed=11),
+    'v44k_c1':    dict(sample_rate_hz=44100, seed=1, num_outs=1, filtered_channels=(0,), mode='LR'),
 }
 
 CLS_CONV_CASES = [  # VelvetNoise.convolve
@@ -210,6 +211,10 @@ CLS_DEC_CASES = [  # VelvetNoise.decorrelate
     ('dec_nonorm',     'v44k_nonorm', dict(seed=0, shape=[20000, 2])),
     ('dec_c8_lr',      'v96k_c8',     dict(seed=0, shape=[30000, 8])),
     ('dec_zeros_mono', 'v44k',        dict(seed=0, shape=[1000], dist='zeros', dtype='float64')),
+    # a single-channel table on an (n, 1) signal: NumPy sums that array pairwise (8192-sample chunks)
+    ('dec_c1',         'v44k_c1',     dict(seed=0, shape=[20000, 1])),
+    ('dec_c1_long',    'v44k_c1',     dict(seed=2, shape=[100001, 1])),
+    ('dec_c1_tiny',    'v44k_c1',     dict(seed=3, shape=[5, 1])),
 ]
 
 

@@ -589,6 +589,70 @@ def test_exact_rms_sums_are_numpys(vnd, name, x):
     assert np.array_equal(yd.cpu().numpy(), ref, equal_nan=True), name
 
 
+def _single_channel_signals():
+    rng = np.random.default_rng(78)
+    for n in (1, 5, 8, 9, 127, 128, 129, 135, 8191, 8192, 8193, 16385, 70001, 480000):
+        yield f'uniform_{n}', rng.uniform(-1, 1, (n, 1)).astype(np.float32)
+    yield 'int16_valued', rng.integers(-32768, 32767, (50000, 1)).astype(np.float32)
+    yield 'quiet', (rng.uniform(-1, 1, (30000, 1)) * 1e-4).astype(np.float32)
+    late = np.zeros((40000, 1), np.float32)
+    late[9000:] = rng.uniform(-1, 1, (31000, 1))
+    yield 'silent_start', late
+    bad = rng.uniform(-1, 1, (20000, 1)).astype(np.float32)
+    bad[12345, 0] = np.nan
+    yield 'nan', bad
+
+
+@pytest.mark.parametrize('name,x', list(_single_channel_signals()), ids=lambda v: v if isinstance(v, str) else '')
+def test_single_channel_sums_are_numpys_pairwise_ones(vnd, name, x):
+    """A single-channel table: NumPy sums the (n, 1) arrays pairwise in 8192-element chunks; the device
+    (rms_pairwise_kernel) must give the same float32 sums and so the same normalised output, bit for bit,
+    for several streams at once (each its own length class: a batch shares n, so the streams differ in data)."""
+    import torch
+    from vndecorrelate_amd import _native
+    from vndecorrelate_amd.utils.dsp import rms_normalize
+    ctx = _native.default_context()
+    n = x.shape[0]
+    table = _native.TapTable.create(ctx, np.arange(2, dtype=np.int32), np.zeros(1, np.int32), np.ones(1, np.float32))
+    batch = 3
+    xs = np.stack([x, x[::-1].copy(), (x * np.float32(0.37)).astype(np.float32)])
+    xd = torch.from_numpy(xs).cuda()
+    yd = torch.empty_like(xd)
+    ws_bytes = _native.decorrelate_workspace_bytes(batch, n, 1)
+    ws = torch.zeros(ws_bytes // 8 + 1, dtype=torch.float64, device='cuda')
+    table.decorrelate_device(xd.data_ptr(), yd.data_ptr(), batch, n, 1, mode=vnd.MODE_EXACT, ms_encode=False,
+                             width=None, normalize=True, workspace_ptr=ws.data_ptr(), workspace_bytes=ws_bytes,
+                             stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = ws[:2 * batch].cpu().numpy().astype(np.float32).reshape(batch, 2)       # per stream: sum x^2, sum y^2
+    for b in range(batch):
+        with np.errstate(all='ignore'):
+            want = np.add.reduce(np.square(xs[b]), axis=0)[0]
+            ref = xs[b].copy()
+            rms_normalize(xs[b], ref)
+        assert np.array_equal(got[b], np.array([want, want], np.float32), equal_nan=True), (name, b, got[b], want)
+        assert np.array_equal(yd[b].cpu().numpy(), ref, equal_nan=True), (name, b)
+    table.close()
+
+
+def test_single_channel_decorrelate_runs_its_epilogue_on_the_device(vnd, golden):
+    """VelvetNoise(num_outs=1) on an (n, 1) signal: the default (device) epilogue equals the reference's
+    stored output and the host epilogue, and the launch goes through the pairwise sums (no host fallback)."""
+    meta = golden.manifest['cls_decorrelate']['dec_c1_long']
+    kw = _kw(golden.manifest['class_taps'][meta['class']]['kwargs'])
+    x = make_input(meta['input'])
+    vn = vnd.VelvetNoise(**kw)
+    assert vnd._use_device_epilogue(1, True, len(x), True) and vn._device_epilogue_applies(x)
+    y_dev = vn.decorrelate(x.copy())
+    vnd.set_device_epilogue(False)
+    try:
+        y_host = vn.decorrelate(x.copy())
+    finally:
+        vnd.set_device_epilogue(None)
+    assert y_dev.shape == (len(x), 1) and np.array_equal(y_dev, y_host)
+    golden.expect('dec_c1_long', y_dev, exact=True)
+
+
 def test_block_parallel_sums_equal_the_sequential_kernel(vnd):
     """The block-parallel exact sums (rms_par_*: predicted binades, prefix-summed runs, prefetched crossing
     groups) against the one-workgroup-per-stream kernel and NumPy, on batches whose streams cross binades

@@ -84,3 +84,51 @@ def test_shard_range_is_a_partition(total, world):
         covered[start:start + count] += 1
     assert np.all(covered == 1)
     assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def _numpy_pairwise_model(sq: np.ndarray) -> np.float32:
+    """The order in which NumPy adds a contiguous float32 vector (what rms_pairwise_kernel repeats on the
+    device for single-channel tables): 8192-element chunks left to right, each summed pairwise down to
+    leaves of at most 128 elements with eight strided accumulators."""
+    def leaf(a):
+        n = len(a)
+        if n < 8:
+            r = np.float32(0.0)
+            for v in a:
+                r = np.float32(r + v)
+            return r
+        m = n - n % 8
+        acc = a[:8].copy()
+        for row in a[8:m].reshape(-1, 8):
+            acc = (acc + row).astype(np.float32)
+        res = np.float32(np.float32(np.float32(acc[0] + acc[1]) + np.float32(acc[2] + acc[3])) +
+                         np.float32(np.float32(acc[4] + acc[5]) + np.float32(acc[6] + acc[7])))
+        for v in a[m:]:
+            res = np.float32(res + v)
+        return res
+
+    def tree(a):
+        n = len(a)
+        if n <= 128:
+            return leaf(a)
+        half = n // 2
+        half -= half % 8
+        return np.float32(tree(a[:half]) + tree(a[half:]))
+
+    acc = None
+    for i in range(0, len(sq), 8192):
+        part = tree(sq[i:i + 8192])
+        acc = part if acc is None else np.float32(acc + part)
+    return acc
+
+
+def test_numpy_sums_a_single_channel_pairwise_in_8192_chunks():
+    """The summation order the device repeats for (n, 1) signals is this box's NumPy's."""
+    rng = np.random.default_rng(11)
+    lengths = list(range(1, 20)) + [127, 128, 129, 135, 263, 1000, 8191, 8192, 8193, 16384, 20000, 100001] + \
+        [int(v) for v in rng.integers(20, 60000, 25)]
+    for n in lengths:
+        sq = np.square((rng.uniform(-1, 1, n) * 10.0 ** rng.uniform(-3, 2)).astype(np.float32))
+        want = np.add.reduce(sq.reshape(n, 1), axis=0)[0]
+        assert _numpy_pairwise_model(sq) == want == np.add.reduce(sq), n
+        assert np.float32(want / np.float32(n)) == np.mean(sq.reshape(n, 1), axis=0)[0], n

@@ -1142,12 +1142,16 @@ static int64_t epi_rows_max(int64_t n) { return std::max<int64_t>(epi_chunks(n),
 
 static int64_t par_blocks(int64_t n) { return std::max<int64_t>((n + kParFrames - 1) / kParFrames, 1); }
 
+static int64_t pw_chunks(int64_t n) { return std::max<int64_t>((n + kPwChunk - 1) / kPwChunk, 1); }
+
 vnd_status vnd_decorrelate_workspace_bytes(int64_t batch, int64_t n, int32_t C, int64_t *bytes)
 {
     if (!bytes || batch < 0 || n < 0 || C <= 0) return fail(VND_ERR_INVALID, "bad workspace query");
     *bytes = batch * epi_rows_max(n) * 2 * C * (int64_t)sizeof(double) + batch * C * (int64_t)sizeof(float) + 16;
     // the parallel exact sums of a stereo table: per stream and chain, a float64 sum and a record per block
     if (C == 2) *bytes += 32 + batch * 4 * (par_blocks(n) * (int64_t)(sizeof(double) + sizeof(ParRec) + sizeof(ParGrp)) + (int64_t)sizeof(float));
+    // the pairwise sums of a single-channel table: one float per (stream, array, 8192-sample chunk)
+    if (C == 1) *bytes += 32 + batch * 2 * pw_chunks(n) * (int64_t)sizeof(float);
     return VND_OK;
 }
 
@@ -1189,7 +1193,9 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
                          : ((size_t)2 * C * kSeqFrames * sizeof(float) <= (size_t)ctx->lds_limit ? kSeqFrames : kSeqFramesWide);
     const bool seq_ok = normalize && C >= 2 && 2 * C <= 64 &&
                         (size_t)2 * C * seq_frames * sizeof(float) <= (size_t)ctx->lds_limit;
-    const bool want_seq = seq_ok && (mode == VND_MODE_EXACT || normalize == VND_NORMALIZE_RMS_REFERENCE_ORDER);
+    // a single-channel table: NumPy sums that array pairwise (rms_pairwise_kernel); the flow is the same
+    const bool pair_ok = normalize && C == 1 && Cx == 1;
+    const bool want_seq = (seq_ok || pair_ok) && (mode == VND_MODE_EXACT || normalize == VND_NORMALIZE_RMS_REFERENCE_ORDER);
     const bool fused = any && mode == VND_MODE_FAST && ctx->variant_nofuse == 0 && fast_epi_kernel(p) != nullptr &&
                        (!(ms_encode || use_width) || p.cg == 2) && !(want_seq && !(ms_encode || use_width));
     bool sums_pending = false;                             // the sequential sums still have to run
@@ -1256,6 +1262,18 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
             if (r.nblocks > 1) hipLaunchKernelGGL(rms_par_tally_kernel<false>, tgrid, dim3(kParThreads), 0, stream, r);
             hipLaunchKernelGGL(rms_par_stitch_kernel<false>, sgrid, dim3(64), 0, stream, r);
         }
+    } else if (sums_pending && C == 1) {
+        e.rows = 1;
+        e.exact_rms = 1;
+        e.normalize = 1;
+        PwArgs q{};
+        q.x = x; q.y = y; q.n = n; q.nchunks = (int32_t)pw_chunks(n);
+        char *extra = (char *)(e.scales + batch * C);
+        extra += (16 - ((uintptr_t)extra & 15)) & 15;
+        q.chunk_sums = (float *)extra;
+        q.partials = e.partials;
+        hipLaunchKernelGGL(rms_pairwise_kernel, dim3((unsigned)q.nchunks, (unsigned)batch), dim3(2 * kPwThreads), 0, stream, q);
+        hipLaunchKernelGGL(rms_pairwise_fold_kernel, dim3((unsigned)batch), dim3(64), 0, stream, q);
     } else if (sums_pending) {
         e.rows = 1;
         e.exact_rms = 1;

@@ -786,6 +786,104 @@ __global__ __launch_bounds__(64) void rms_par_stitch_kernel(const RArgs a)
     if (lane == 0) a.partials[b * 4 + chain] = (double)acc;
 }
 
+// ---- NumPy's sum of squares of a SINGLE-channel float32 signal, bit for bit ------------------------
+// np.mean(np.square(a), axis=0) on an (n, 1) (or 1-D) float32 array is not the row-by-row recurrence
+// above: the reduction runs over contiguous memory, which NumPy's add loop sums PAIRWISE, 8192 elements
+// (its buffer size) at a time (utils/dsp.py:107-109; numpy loops_utils: pairwise_sum):
+//   sum   = p(chunk 0) + p(chunk 1) + ...                       left to right, float32
+//   p(m)  = m < 8:     0 + a0 + a1 + ...
+//           m <= 128:  eight strided accumulators r_j = a_j + a_(8+j) + ..., ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)),
+//                      then the m % 8 leftovers one by one
+//           else:      p(first h) + p(rest),  h = m/2 rounded down to a multiple of 8
+// (tests/test_properties_cpu.py holds this model against np.add.reduce for many lengths).  The tree of one chunk
+// is at most 7 levels deep; thread t of a chain walks it by the bits of t, the threads that arrive at
+// a leaf first sum it exactly as NumPy does, and the inner nodes are formed level by level in LDS.
+constexpr int kPwChunk = 8192, kPwLeaf = 128, kPwDepth = 7, kPwThreads = 1 << kPwDepth;
+
+struct PwArgs {
+    const float *__restrict__ x;       // [batch][n], one channel
+    const float *__restrict__ y;
+    int64_t n;
+    int32_t nchunks;
+    float *__restrict__ chunk_sums;    // [batch][2][nchunks]
+    double *__restrict__ partials;     // [batch][2]: sum x^2, sum y^2 (as the reduce kernel reads them with one row)
+};
+
+// the node reached from the root of an m-element chunk along the top `steps` bits of `path` (kPwDepth bits,
+// most significant first); stops at a leaf.  Returns the depth reached.
+__device__ __forceinline__ int pw_walk(int m, int path, int steps, int &off, int &len)
+{
+    off = 0;
+    len = m;
+    int d = 0;
+    for (; d < steps && len > kPwLeaf; ++d) {
+        int half = len / 2;
+        half -= half % 8;
+        if ((path >> (kPwDepth - 1 - d)) & 1) { off += half; len -= half; }
+        else len = half;
+    }
+    return d;
+}
+
+__device__ __forceinline__ float pw_leaf(const float *__restrict__ a, int len)
+{
+    if (len < 8) {
+        float r = 0.0f;
+        for (int i = 0; i < len; ++i) r = r + a[i] * a[i];
+        return r;
+    }
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = a[j] * a[j];
+    int i = 8;
+    for (; i < len - (len % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = r[j] + a[i + j] * a[i + j];
+    }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < len; ++i) res = res + a[i] * a[i];
+    return res;
+}
+
+// grid (chunks, batch), 2 * kPwThreads threads: the x chain and the y chain of one 8192-sample chunk
+__global__ __launch_bounds__(2 * kPwThreads) void rms_pairwise_kernel(const PwArgs a)
+{
+    __shared__ float heap[2][2 << kPwDepth];              // node (depth d, path p) at (1 << d) + p
+    const int chain = threadIdx.x >> kPwDepth, t = threadIdx.x & (kPwThreads - 1);
+    const int64_t b = blockIdx.y;
+    const int chunk = blockIdx.x;
+    const int64_t first = (int64_t)chunk * kPwChunk;
+    const float *src = (chain == 0 ? a.x : a.y) + b * a.n + first;
+    const int m = (int)min((int64_t)kPwChunk, a.n - first);
+    int off, len;
+    const int d = pw_walk(m, t, kPwDepth, off, len);
+    // the threads sharing the leaf's path prefix all arrive at it: the one whose unused bits are zero sums it
+    if ((t & ((1 << (kPwDepth - d)) - 1)) == 0) heap[chain][(1 << d) + (t >> (kPwDepth - d))] = pw_leaf(src + off, len);
+    __syncthreads();
+    for (int lvl = kPwDepth - 1; lvl >= 0; --lvl) {
+        if (t < (1 << lvl)) {
+            const int reached = pw_walk(m, t << (kPwDepth - lvl), lvl, off, len);
+            if (reached == lvl && len > kPwLeaf)           // an inner node: its children sit one level down
+                heap[chain][(1 << lvl) + t] = heap[chain][(2 << lvl) + 2 * t] + heap[chain][(2 << lvl) + 2 * t + 1];
+        }
+        __syncthreads();
+    }
+    if (t == 0) a.chunk_sums[(b * 2 + chain) * a.nchunks + chunk] = heap[chain][1];
+}
+
+// the chunks' sums, left to right (one lane per chain; a 10 s signal has 59 of them)
+__global__ __launch_bounds__(64) void rms_pairwise_fold_kernel(const PwArgs a)
+{
+    const int64_t b = blockIdx.x;
+    const int chain = threadIdx.x;
+    if (chain < 2) {
+        const float *cs = a.chunk_sums + (b * 2 + chain) * a.nchunks;
+        float acc = cs[0];
+        for (int k = 1; k < a.nchunks; ++k) acc = acc + cs[k];
+        a.partials[b * 2 + chain] = (double)acc;
+    }
+}
+
 // Pass 2: y[:, c] *= scale[c]
 __global__ __launch_bounds__(kEpiThreads) void epilogue_scale_kernel(const EArgs a)
 {

@@ -83,8 +83,8 @@ def set_device_epilogue(enabled: Optional[bool]) -> None:
     squares in NumPy's own order (a sequential float32 recurrence for ``(n, C >= 2)`` arrays,
     reproduced bit for bit).  In MODE_EXACT the whole stage is then bit-identical to the
     reference; in the other modes it differs from it only through the convolution
-    (~1e-6 of peak).  Single-channel tables, whose sums NumPy forms pairwise, and custom
-    normalisers keep the host epilogue.
+    (~1e-6 of peak).  A single-channel table's sums are NumPy's pairwise ones (8192-sample
+    chunks, 128-sample leaves), reproduced the same way; custom normalisers keep the host epilogue.
     ``True``: on the GPU in its fastest form - in MODE_FAST everything fused into the fast
     kernel with exactly rounded float64 sums, which puts the normalised output ~1e-4
     relative from the reference's on long signals (NumPy's sequential sum is that far off).
@@ -100,8 +100,8 @@ def _use_device_epilogue(num_outs: int, has_normalizer: bool, frames: int = 0, c
     if not has_normalizer:
         return True                                       # the pointwise steps are always NumPy's
     # NumPy's row-by-row float32 sums are repeated on the device for 2 to 32 channels of a C-contiguous
-    # signal (a single channel, and other memory layouts, are summed pairwise by NumPy)
-    return 2 <= num_outs <= 32 and c_contiguous
+    # signal, and so are the pairwise sums it forms for a single channel (other memory layouts: host)
+    return 1 <= num_outs <= 32 and c_contiguous
 
 
 def _normalize_flag(has_normalizer: bool) -> int:
