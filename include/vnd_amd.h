@@ -104,6 +104,20 @@ vnd_status vnd_taps_info(const vnd_taps *taps, int32_t *num_channels, int32_t *t
 vnd_status vnd_taps_serialize(const vnd_taps *taps, void *buf, int64_t capacity, int64_t *bytes);
 vnd_status vnd_taps_deserialize(vnd_ctx *ctx, const void *buf, int64_t bytes, vnd_taps **taps);
 
+/* Sharding helpers for hosts that do not use torch.distributed (the many-stream mode of
+ * decorrelation.py:649-658's loop over independent streams):
+ * vnd_shard_range: rank `rank` of `world_size` owns streams [first, first + count) of `total` -
+ *   contiguous blocks, the remainder one each to the lowest ranks (what distributed.shard_range cuts).
+ * vnd_taps_broadcast_rccl: the one exchange of the path - the shared impulse table goes from `root` to
+ *   every rank of an RCCL communicator the HOST created (ncclComm_t, passed as void*; one rank per GPU,
+ *   the context's device being the communicator's).  On `root` *taps is the table to send and is left
+ *   alone; on the other ranks *taps receives a new table the caller destroys.  Collective: every rank
+ *   calls it, with the same root.  Synchronous (returns after the stream has drained).  librccl.so is
+ *   loaded at first use: VND_ERR_UNSUPPORTED when it is not there.                                    */
+vnd_status vnd_shard_range(int64_t total, int32_t world_size, int32_t rank, int64_t *first, int64_t *count);
+vnd_status vnd_taps_broadcast_rccl(vnd_ctx *ctx, vnd_taps **taps, int32_t root, int32_t rank, void *rccl_comm,
+                                   void *hip_stream);
+
 /* ---- the hot path ------------------------------------------------------------
  * y[b,n,c] = sum_k w[c,k] * x[b, n + i[c,k], c]   (terms with n+i >= n_frames drop)
  * Replaces convolve_velvet_noise (decorrelation.py:630-660) and

@@ -151,3 +151,15 @@ def test_one_stream_cut_in_time_over_ranks(tmp_path, cuts):
     fir = O.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, sample_rate_hz=48000, seed=1)
     x = np.random.default_rng(5).uniform(-1, 1, (cuts[-1], 2)).astype(np.float32)
     assert np.array_equal(y, O.convolve_velvet_noise(x, fir))
+
+
+def test_c_abi_shard_range_matches_the_python_one():
+    """vnd_shard_range (for hosts that shard without torch.distributed) cuts what shard_range cuts."""
+    from vndecorrelate_amd import _native
+    for total in (0, 1, 7, 8, 1024, 1027, 70000):
+        for world in (1, 2, 3, 8):
+            for rank in range(world):
+                assert _native.shard_range(total, world, rank) == shard_range(total, world, rank)
+    for bad in ((4, 2, 2), (4, 0, 0), (-1, 2, 0), (4, 2, -1)):
+        with pytest.raises(ValueError):                    # VND_ERR_INVALID, as the Python shard_range raises
+            _native.shard_range(*bad)

@@ -108,3 +108,103 @@ def test_cfg4_full_size_is_bit_exact_per_stream():
     # the pipelined host path returns page-locked result arrays; they behave like any other ndarray
     assert fast.flags.writeable and fast.dtype == np.float32 and fast.shape == x.shape
     del got, fast
+
+
+def _rccl():
+    import ctypes
+    for name in ('librccl.so.1', 'librccl.so'):
+        try:
+            return ctypes.CDLL(name)
+        except OSError:
+            continue
+    return None
+
+
+def test_table_broadcast_through_the_c_abi_over_rccl():
+    """vnd_taps_broadcast_rccl on a communicator this test creates straight from librccl (no torch):
+    with one GPU a communicator of one rank - the root keeps its table, the call drives RCCL and returns;
+    with two or more GPUs see test_two_rank_rccl_broadcast."""
+    import ctypes
+    import vndecorrelate_amd.decorrelation as vnd
+    from vndecorrelate_amd import _native
+    from vndecorrelate_amd.taps import function_path_arrays
+    rccl = _rccl()
+    if rccl is None:
+        pytest.skip('librccl.so not found')
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [('internal', ctypes.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        ctx = _native.default_context()
+        arrays = function_path_arrays(vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2,
+                                                                sample_rate_hz=48000, seed=1))
+        table = _native.TapTable.create(ctx, arrays.tap_offsets, arrays.tap_index, arrays.tap_weight)
+        same = _native.TapTable.broadcast_rccl(ctx, table, root=0, rank=0, comm=comm.value)
+        assert same is table and same.to_bytes() == arrays.to_bytes()
+        with pytest.raises(ValueError):                    # the root must have a table to send
+            _native.TapTable.broadcast_rccl(ctx, None, root=0, rank=0, comm=comm.value)
+        table.close()
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
+
+
+def _rccl_rank(rank, world, uid_bytes, result_dir):
+    import ctypes
+    os.environ['VND_DEVICE'] = str(rank)
+    import sys
+    import pathlib
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+    import torch
+    torch.cuda.set_device(rank)
+    import vndecorrelate_amd.decorrelation as vnd
+    from vndecorrelate_amd import _native
+    from vndecorrelate_amd.taps import function_path_arrays
+    rccl = _rccl()
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [('internal', ctypes.c_char * 128)]
+
+    uid = UniqueId.from_buffer_copy(uid_bytes)
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), world, uid, rank) == 0
+    ctx = _native.default_context()
+    arrays = function_path_arrays(vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2,
+                                                            sample_rate_hz=48000, seed=1))
+    table = _native.TapTable.create(ctx, arrays.tap_offsets, arrays.tap_index, arrays.tap_weight) if rank == 0 else None
+    got = _native.TapTable.broadcast_rccl(ctx, table, root=0, rank=rank, comm=comm.value)
+    ok = got.to_bytes() == arrays.to_bytes()
+    first, count = _native.shard_range(7, world, rank)
+    x = np.random.default_rng(17).uniform(-1, 1, (7, 20000, 2)).astype(np.float32)[first:first + count]
+    from oracle import vnd_oracle as O
+    fir = O.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1)
+    y = got.convolve_host(x, vnd.MODE_EXACT)
+    ok &= all(np.array_equal(y[i], O.convolve_velvet_noise(x[i], fir)) for i in range(count))
+    with open(os.path.join(result_dir, f'rccl{rank}.txt'), 'w') as f:
+        f.write(str(int(ok)))
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    rccl.ncclCommDestroy(comm)
+
+
+def test_two_rank_rccl_broadcast(tmp_path):
+    """Two GPUs, two processes, no torch.distributed: RCCL communicator from librccl, table built on rank 0
+    only, vnd_taps_broadcast_rccl, vnd_shard_range, exact convolution per shard."""
+    import ctypes
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs (RCCL does not put two ranks on one device)')
+    rccl = _rccl()
+    if rccl is None:
+        pytest.skip('librccl.so not found')
+    uid = (ctypes.c_char * 128)()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    mp.spawn(_rccl_rank, args=(2, bytes(uid), str(tmp_path)), nprocs=2, join=True)
+    assert [(tmp_path / f'rccl{r}.txt').read_text() for r in range(2)] == ['1', '1']

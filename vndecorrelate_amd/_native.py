@@ -48,6 +48,10 @@ SIGNATURES = {
                                           ctypes.POINTER(ctypes.c_int64)]),
     'vnd_taps_deserialize': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                             ctypes.POINTER(ctypes.c_void_p)]),
+    'vnd_shard_range': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                       ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    'vnd_taps_broadcast_rccl': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32,
+                                               ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     'vnd_convolve_f32_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
@@ -167,6 +171,14 @@ def load_library():
             raise NativeError(f'{LIB_PATH} has ABI {got}, expected {ABI_VERSION}: rebuild it')
         _lib = lib
         return lib
+
+
+def shard_range(total: int, world_size: int, rank: int):
+    """``vnd_shard_range``: ``(first, count)`` of ``rank``'s contiguous block of ``total`` streams."""
+    first, count = ctypes.c_int64(), ctypes.c_int64()
+    _check(load_library().vnd_shard_range(total, world_size, rank, ctypes.byref(first), ctypes.byref(count)),
+           'vnd_shard_range')
+    return first.value, count.value
 
 
 def _check(rc: int, what: str):
@@ -342,6 +354,17 @@ class TapTable:
         _check(ctx._lib.vnd_taps_deserialize(ctx.handle, buf, len(image), ctypes.byref(h)),
                'vnd_taps_deserialize')
         return cls(ctx, h)
+
+    @classmethod
+    def broadcast_rccl(cls, ctx: 'Context', table: Optional['TapTable'], root: int, rank: int, comm: int,
+                       stream: int = 0) -> 'TapTable':
+        """The C ABI's own table broadcast over an RCCL communicator (``ncclComm_t`` as an integer) - for
+        hosts that shard without torch.distributed.  ``table`` is needed on ``root`` only; every rank
+        returns a table on its device (the root its own)."""
+        h = ctypes.c_void_p((table._h.value if isinstance(table._h, ctypes.c_void_p) else table._h) if (table is not None and rank == root) else None)
+        _check(ctx._lib.vnd_taps_broadcast_rccl(ctx.handle, ctypes.byref(h), root, rank, ctypes.c_void_p(comm),
+                                                ctypes.c_void_p(stream)), 'vnd_taps_broadcast_rccl')
+        return table if rank == root else cls(ctx, h)
 
     def to_bytes(self) -> bytes:
         need = ctypes.c_int64()
