@@ -333,6 +333,8 @@ def main():
     def timed(m, steps, warmup):
         """warmup, barrier+sync, `steps` back-to-back steps, sync+barrier; wall seconds and the
         mean kernel time between two events on the launch stream."""
+        run(m)                           # the first launch of a table may compile its kernel (hipRTC): not warm-up time
+        torch.cuda.synchronize()
         done, t_w = 0, time.perf_counter()
         while done < warmup or (time.perf_counter() - t_w) * 1e3 < args.min_warmup_ms:
             run(m)

@@ -104,7 +104,7 @@ vnd_status vnd_taps_info(const vnd_taps *taps, int32_t *num_channels, int32_t *t
 vnd_status vnd_taps_serialize(const vnd_taps *taps, void *buf, int64_t capacity, int64_t *bytes);
 vnd_status vnd_taps_deserialize(vnd_ctx *ctx, const void *buf, int64_t bytes, vnd_taps **taps);
 
-/* Sharding helpers for hosts that do not use torch.distributed (the many-stream mode of
+/* Sharding helpers for hosts that bring their own process group (the many-stream mode of
  * decorrelation.py:649-658's loop over independent streams):
  * vnd_shard_range: rank `rank` of `world_size` owns streams [first, first + count) of `total` -
  *   contiguous blocks, the remainder one each to the lowest ranks (what distributed.shard_range cuts).
