@@ -43,14 +43,20 @@ def sampler():
 
 
 ctx = _native.default_context()
-fir = vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1)
+import os
+CONFIGS = {     # VND_PROBE_CFG: the workload (default cfg2)
+    'cfg2': (dict(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1), 128, 480000, 2),
+    'cfg3': (dict(duration_seconds=0.03, num_impulses=128, num_outs=2, sample_rate_hz=48000, log_distribution_strength=0.0, seed=1), 24, 2880000, 2),
+    'cfg5': (dict(duration_seconds=0.03, num_impulses=64, num_outs=8, sample_rate_hz=96000, seed=1), 16, 960000, 8),
+}
+kw, pool, n, chans = CONFIGS[os.environ.get('VND_PROBE_CFG', 'cfg2')]
+fir = vnd.generate_velvet_noise(**kw)
 arr = function_path_arrays(fir)
 table = _native.TapTable.create(ctx, arr.tap_offsets, arr.tap_index, arr.tap_weight)
-pool, n = 128, 480000
-x = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1)
+x = torch.empty((pool, n, chans), dtype=torch.float32, device='cuda').uniform_(-1, 1)
 y = torch.empty_like(x)
 stream = torch.cuda.current_stream().cuda_stream
-print(table.describe(pool, n, 2, mode))
+print(table.describe(pool, n, chans, mode))
 print('idle:', read_sysfs())
 th = threading.Thread(target=sampler); th.start()
 time.sleep(1.0)
@@ -65,14 +71,14 @@ while time.perf_counter() - t_start < seconds:
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 200
     else:
-        ms = table.time_device(x.data_ptr(), y.data_ptr(), pool, n, 2, mode=mode, n_buffers=1, stride_elems=0,
-                               iters=200, stream=stream)
+        ms = table.time_device(x.data_ptr(), y.data_ptr(), pool, n, chans, mode=mode, n_buffers=1, stride_elems=0,
+                               iters=200 if chans == 2 and n <= 480000 else 60, stream=stream)
     rates.append((time.perf_counter() - t_start, ms))
 t_end = time.perf_counter()
 time.sleep(1.0)
 stop = True; th.join()
 for t, ms in rates[::4]:
-    print(f't={t:5.2f}s  {ms:.4f} ms/launch  {983.04/ms:.0f} GB/s')
+    print(f't={t:5.2f}s  {ms:.4f} ms/launch  {8e-6 * pool * n * chans / ms:.0f} GB/s')
 for t, fs, smi in samples:
     tag = 'RUN ' if t_start <= t <= t_end else 'idle'
     print(tag, f'{t - t_start:6.2f}', fs)

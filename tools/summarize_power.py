@@ -20,4 +20,4 @@ for sec, samples in runs.items():
     pw = [s[hot + ':power1_input'] / 1e6 for s in samples[1:]] or [samples[0][hot + ':power1_input'] / 1e6]
     fq = [s[hot + ':freq1_input'] / 1e6 for s in samples[1:]] or [samples[0][hot + ':freq1_input'] / 1e6]
     ms = sum(rates[sec]) / max(1, len(rates[sec]))
-    print(f'{sec:10s} {ms:.4f} ms/launch  {983.04 / ms:5.0f} GB/s   power {sum(pw) / len(pw):6.0f} W   sclk {sum(fq) / len(fq):5.0f} MHz  ({hot})')
+    print(f'{sec:10s} {ms:.4f} ms/launch  {983.04 / ms:5.0f} GB/s(cfg2 bytes)   power {sum(pw) / len(pw):6.0f} W   sclk {sum(fq) / len(fq):5.0f} MHz  ({hot})')
