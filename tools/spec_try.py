@@ -78,6 +78,9 @@ def env_rate(label, **env):
 
 
 configs = [dict(), dict(nt=192, rr=4), dict(nt=192, rr=4, dd=2), dict(nt=128, rr=4, la=4), dict(nt=256, rr=2), dict(nt=256, rr=4), dict(nt=128, rr=4, dd=1)]
+if len(sys.argv) > 3 and sys.argv[3] == 'wide':       # the round-2 closing sweep: every shape the library would consider, and read depths
+    configs = [dict(), dict(nt=192, rr=4, la=12), dict(nt=192, rr=4, la=6), dict(nt=256, rr=4), dict(nt=256, rr=4, la=12), dict(nt=128, rr=4),
+               dict(nt=128, rr=8), dict(nt=192, rr=2), dict(nt=256, rr=2, dd=2), dict(nt=384, rr=2), dict(nt=64, rr=8), dict(nt=192, rr=4, dd=2)]
 for rep in range(2):
     rate(GENERIC, 'generic fast')
     for c in configs:
