@@ -551,6 +551,12 @@ def _adversarial_signals():
     big[50000, 1] = np.nan
     yield 'inf_and_nan', big
     yield 'uniform_long', rng.uniform(-1, 1, (480000, 2)).astype(np.float32)
+    # audio that came from 16-bit integers: ties in most 2048-frame blocks, several per block (the block-parallel sums
+    # settle those blocks from the tally kernel's two parity answers; a binade crossing inside one goes group by group)
+    t = np.arange(300000)
+    music = np.round(8000 * (np.sin(t * 0.01)[:, None] * np.array([1.0, 0.7]) + 0.3 * rng.standard_normal((300000, 2))))
+    yield 'int16_music_scaled', (music / 32768.0).astype(np.float32)
+    yield 'odd_multiples_of_a_power_of_two', (rng.integers(0, 8, (150000, 2)) * 2 + 1).astype(np.float32) * np.float32(2.0 ** -7)
     yield 'audio_like', (np.sin(np.arange(200000)[:, None] * np.array([0.01, 0.013])) * 0.2).astype(np.float32)
     yield 'three_channels', rng.uniform(-1, 1, (n, 3)).astype(np.float32)
     yield 'eight_channels_int', rng.integers(-500, 500, (n, 8)).astype(np.float32)

@@ -1337,17 +1337,17 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
         r.first = (float *)(r.grp + batch * 4 * (int64_t)r.nblocks);
         r.partials = e.partials;
         r.prefixed = r.nblocks > kParPrefixBlocks ? 1 : 0;
-        const dim3 pgrid((unsigned)r.nblocks, (unsigned)batch), tgrid((unsigned)(r.nblocks - 1), (unsigned)batch);
+        const dim3 pgrid((unsigned)r.nblocks, (unsigned)batch), tgrid((unsigned)r.nblocks, (unsigned)batch);     // tally: blocks 1.., plus block 0's chain
         const dim3 sgrid((unsigned)(batch * 4));
         if (Cx == 1) {
             hipLaunchKernelGGL(rms_par_sum_kernel<true>, pgrid, dim3(kParThreads), 0, stream, r);
             if (r.prefixed) hipLaunchKernelGGL(rms_par_prefix_kernel, dim3((unsigned)(batch * 4)), dim3(kParThreads), 0, stream, r);
-            if (r.nblocks > 1) hipLaunchKernelGGL(rms_par_tally_kernel<true>, tgrid, dim3(kParThreads), 0, stream, r);
+            hipLaunchKernelGGL(rms_par_tally_kernel<true>, tgrid, dim3(kParThreads), 0, stream, r);
             hipLaunchKernelGGL(rms_par_stitch_kernel<true>, sgrid, dim3(64), 0, stream, r);
         } else {
             hipLaunchKernelGGL(rms_par_sum_kernel<false>, pgrid, dim3(kParThreads), 0, stream, r);
             if (r.prefixed) hipLaunchKernelGGL(rms_par_prefix_kernel, dim3((unsigned)(batch * 4)), dim3(kParThreads), 0, stream, r);
-            if (r.nblocks > 1) hipLaunchKernelGGL(rms_par_tally_kernel<false>, tgrid, dim3(kParThreads), 0, stream, r);
+            hipLaunchKernelGGL(rms_par_tally_kernel<false>, tgrid, dim3(kParThreads), 0, stream, r);
             hipLaunchKernelGGL(rms_par_stitch_kernel<false>, sgrid, dim3(64), 0, stream, r);
         }
     } else if (sums_pending && C == 1) {

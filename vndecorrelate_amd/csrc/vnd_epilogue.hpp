@@ -177,6 +177,19 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x)
     return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }
 
+// inclusive prefix sum over the wave's lanes: Hillis-Steele inside each row of 16 (DPP row_shr, lanes
+// without a source add 0), then the row totals (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2-3)
+__device__ __forceinline__ uint32_t wave_prefix_u32(uint32_t x, int)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+
 struct SeqTally {                 // one lane's view of some squares against acc's binade
     v2f q = {0.f, 0.f};           // sum of round(s / ulp): integers, exact in float while below 2^24
     v2f smax = {0.f, 0.f};        // largest s / ulp seen
@@ -226,6 +239,82 @@ __device__ __forceinline__ bool seq_settle(const SeqTally &t, float &acc, int eb
     return ab == 0 && __ballot(t.any_bits != 0) == 0;               // +0 + +0 ... : still +0
 }
 
+// Squares that seq_settle turned away because of TIES, still in integers.
+// fl(acc + s) with acc = A * ulp rounds A + s/ulp to the nearest integer, and a tie (s/ulp = f + 1/2) to the EVEN
+// one: the square then counts f + [(A_at + f) odd], where A_at is the running sum's mantissa when its turn comes.
+// The 2^23 trick has already rounded the tie to even by itself (q = f for even f, remainder +1/2; q = f + 1 for odd f,
+// remainder -1/2), so against that tally a tie is off by delta = [A_at odd] * (+1 for even f, -1 for odd f), and
+// A_at's parity is that of A + (tallies before the element) + (the deltas before it) - only the PARITY of the
+// mantissa the scan starts from matters.  A TieScan therefore carries both answers (start even / start odd) over
+// any number of 256-square groups (four squares per lane, in order): the lanes form their tallies and a wave prefix
+// sum per group, and the ties are walked in order with scalar bit operations - a handful per tie instead of 256
+// dependent additions per group.  Valid while the sum stays inside its binade (the caller checks the final mantissa:
+// the running sum never decreases) and every square is inside the trick's range (tie_scan_group returns false).
+struct TieScan {
+    uint32_t total = 0;               // sum of the round-to-even tallies
+    int delta0 = 0, delta1 = 0;       // what the ties add to it when the scan starts from an even / odd mantissa
+    uint32_t flip0 = 0, flip1 = 0;    // (scalars, not arrays: a run-time index would send them to scratch memory)
+    bool ties = false;
+};
+
+__device__ __forceinline__ bool tie_scan_group(TieScan &sc, const float4 &v4, float scale, int lane)
+{
+    const float sq[4] = {v4.x, v4.y, v4.z, v4.w};
+    uint32_t lane_q = 0, ties = 0, minus = 0, par = 0;     // bit i: element i ties / its remainder is -1/2 / parity of this lane's tallies before it
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float scaled = sq[i] * scale;
+        const float whole = (scaled + 8388608.0f) - 8388608.0f;
+        const float rem = scaled - whole;
+        bad |= !(scaled < 4194304.0f);                     // also NaN and inf
+        ties |= (uint32_t)(rem == 0.5f || rem == -0.5f) << i;
+        minus |= (uint32_t)(rem == -0.5f) << i;
+        par |= (lane_q & 1u) << i;
+        lane_q += bad ? 0u : (uint32_t)whole;
+    }
+    if (__ballot(bad) != 0) return false;
+    const uint32_t incl = wave_prefix_u32(lane_q, lane);
+    const uint32_t info = ties | (minus << 4) | (par << 8) | (((incl - lane_q) & 1u) << 12);
+    const uint32_t base = sc.total & 1u;                   // parity of the tallies of the groups before
+    uint64_t tmask = __ballot(ties != 0);
+    sc.ties |= tmask != 0;
+    while (tmask != 0) {
+        const int l = __builtin_ctzll(tmask);
+        tmask &= tmask - 1;
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)info, l);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if ((w >> i) & 1u) {
+                const uint32_t before = (base ^ (w >> 12) ^ (w >> (8 + i))) & 1u;
+                const int sign = ((w >> (4 + i)) & 1u) ? -1 : 1;
+                if ((before ^ sc.flip0) & 1u) { sc.delta0 += sign; sc.flip0 ^= 1u; }
+                if ((1u ^ before ^ sc.flip1) & 1u) { sc.delta1 += sign; sc.flip1 ^= 1u; }
+            }
+        }
+    }
+    sc.total += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    return true;
+}
+
+// acc over the scanned squares, if the sum stayed inside its binade
+__device__ __forceinline__ bool tie_scan_apply(const TieScan &sc, float &acc, int eb)
+{
+    const uint32_t mant = (__float_as_uint(acc) & 0x7fffffu) | 0x800000u;
+    const uint32_t grown = mant + sc.total + (uint32_t)((mant & 1u) ? sc.delta1 : sc.delta0);
+    if (grown >= (1u << 24)) return false;
+    acc = __uint_as_float(((uint32_t)eb << 23) | (grown & 0x7fffffu));
+    return true;
+}
+
+// one group of 256 squares
+__device__ __forceinline__ bool seq_settle_ties(const float4 &v4, float &acc, int eb, int lane)
+{
+    if (eb < 23 || eb >= 255) return false;
+    TieScan sc;
+    return tie_scan_group(sc, v4, seq_scale(eb), lane) && tie_scan_apply(sc, acc, eb);
+}
+
 // the 256 dependent float32 additions of one group (every lane runs the chain on broadcast reads; the reads
 // of the next 32 squares are in flight while the current 32 are added, so only the adds' own latency is paid)
 __device__ __forceinline__ float seq_add_group(const float *sqs, float t)
@@ -256,8 +345,10 @@ __device__ __forceinline__ float seq_sum_group(const float *row, float acc, int 
 {
     const int eb = (int)(__float_as_uint(acc) >> 23);   // acc is a sum of squares: sign 0 (a NaN may set it: eb > 255)
     SeqTally t;
-    seq_tally(t, *(const float4 *)(row + 4 * lane), seq_scale(eb));
+    const float4 mine = *(const float4 *)(row + 4 * lane);
+    seq_tally(t, mine, seq_scale(eb));
     if (seq_settle(t, acc, eb)) return acc;
+    if (seq_settle_ties(mine, acc, eb, lane)) return acc;
     // one after the other; every lane does the same adds on the same (broadcast) LDS words
     if constexpr (PIPELINED) {
         return seq_add_group(row, acc);
@@ -290,6 +381,17 @@ __device__ __forceinline__ float seq_sum_block(const float *row, float acc, int 
 #pragma unroll
     for (int g = 0; g < FRAMES; g += kSeqGroup) seq_tally(t, *(const float4 *)(row + g + 4 * lane), scale);
     if (seq_settle(t, acc, eb)) return acc;
+    // ties (audio that came from integers is full of them): the whole block in integers - when ties are what
+    // turned the block away (a sum about to leave its binade goes group by group at once)
+    const bool in_range = (t.q.x + t.q.y) < 16777216.0f && fmaxf(t.smax.x, t.smax.y) < 4194304.0f;
+    const bool tie_seen = fmaxf(t.rmax.x, t.rmax.y) == 0.5f || fminf(t.rmin.x, t.rmin.y) == -0.5f;
+    if (eb >= 23 && eb < 255 && __ballot(!in_range) == 0 && __ballot(tie_seen) != 0) {
+        TieScan sc;
+        bool ok = true;
+#pragma unroll 1
+        for (int g = 0; g < FRAMES && ok; g += kSeqGroup) ok = tie_scan_group(sc, *(const float4 *)(row + g + 4 * lane), scale, lane);
+        if (ok && tie_scan_apply(sc, acc, eb)) return acc;
+    }
 #pragma unroll 1
     for (int g = 0; g < FRAMES; g += kSeqGroup) acc = seq_sum_group<PIPELINED>(row + g, acc, lane);
     return acc;
@@ -398,13 +500,15 @@ constexpr int kParFrames = 2048;
 constexpr int kParThreads = 256;
 constexpr int kParGroups = kParFrames / kSeqGroup;       // 8
 constexpr int kParSlots = 24;                            // groups prefetched per chain: binade crossings (a sum crosses each binade once) and ties
-constexpr uint32_t kParZero = 1u << 9, kParBad = 1u << 10, kParHint = 1u << 12;
+constexpr uint32_t kParZero = 1u << 9, kParBad = 1u << 10, kParTies = 1u << 11, kParHint = 1u << 12;
 
 struct ParRec {                       // 16 bytes per (chain, block)
     uint32_t tag;                     // bits 0-8 predicted biased exponent e; flags; bits 16-18 g* (with kParHint)
     uint32_t qtot;                    // the whole block's tally against ulp(e) (valid unless kParBad)
     uint32_t bad;                     // bit g: group g cannot be settled against ulp(e); bit 8 + g: against ulp(e + 1)
-    uint32_t need;                    // bit g: group g is expected to take the 256 dependent additions (g*, or bad in its binade)
+    uint32_t need;                    // bit g: group g is expected to take the 256 dependent additions (g*, or bad in its binade);
+                                      // with kParTies, bits 8-19 / 20-31: what the block's ties add to qtot when the sum's mantissa is
+                                      // even / odd as the block starts (signed 12 bits each, TieScan)
 };
 struct ParGrp { uint32_t qe[kParGroups], qf[kParGroups]; };      // per-group tallies against ulp(e) and ulp(e + 1)
 
@@ -486,10 +590,6 @@ __global__ __launch_bounds__(kParThreads) void rms_par_sum_kernel(const RArgs a)
     }
     s = wave_sum_f64(s);
     if (lane == 0) a.blk_sum[(b * 4 + chain) * a.nblocks + blk] = s;
-    if (blk == 0) {                                       // the chain's start: the recurrence itself, from +0
-        const float acc = seq_sum_block<kParFrames, true>(row, 0.0f, lane);
-        if (lane == 0) a.first[b * 4 + chain] = acc;
-    }
 }
 
 // Long streams (more than kParPrefixBlocks blocks): the block sums are turned into exclusive prefix sums in
@@ -542,8 +642,18 @@ __global__ __launch_bounds__(kParThreads) void rms_par_tally_kernel(const RArgs 
 {
     __shared__ __attribute__((aligned(16))) float sq[4 * kParFrames];
     const int tid = threadIdx.x, lane = tid & 63, chain = tid >> 6;
-    const int blk = blockIdx.x + 1;                       // block 0 was summed by rms_par_sum
     const int64_t b = blockIdx.y;
+    if ((int)blockIdx.x == a.nblocks - 1) {
+        // the extra workgroup: the chains' START - block 0 by the recurrence itself, from +0 (its first groups
+        // are all ties and binade crossings) - runs beside the tallies of the other blocks instead of holding
+        // up the block sums that they wait for
+        par_stage<MONO>(a, b, 0, sq, tid);
+        __syncthreads();
+        const float acc = seq_sum_block<kParFrames, true>(sq + chain * kParFrames, 0.0f, lane);
+        if (lane == 0) a.first[b * 4 + chain] = acc;
+        return;
+    }
+    const int blk = blockIdx.x + 1;
     par_stage<MONO>(a, b, blk, sq, tid);
     // where the running sum stands when this block starts, to within float64 rounding: only its
     // binade matters, and a wrong guess merely sends the block down the sequential path
@@ -585,6 +695,16 @@ __global__ __launch_bounds__(kParThreads) void rms_par_tally_kernel(const RArgs 
         if (lane == g) mine_e = qe;
         if (lane == 8 + g) mine_f = qf;
     }
+    // a block whose only trouble is ties: its round-to-even tally and the two corrections (start even / odd), so that the
+    // stitch accepts it with three scalar operations (audio that came from integers has ties in most blocks)
+    TieScan sc;
+    bool scan_ok = eb >= 23 && eb < 255 && (bad_bits & 0xffu) != 0;
+    if (scan_ok) {
+        const float scale = seq_scale(eb);
+#pragma unroll 1
+        for (int g = 0; g < kParGroups && scan_ok; ++g) scan_ok = tie_scan_group(sc, *(const float4 *)(row + g * kSeqGroup + 4 * lane), scale, lane);
+        scan_ok = scan_ok && sc.ties && sc.total < (1u << 24) && abs(sc.delta0) < 2048 && abs(sc.delta1) < 2048;
+    }
     const int64_t at = (b * 4 + chain) * a.nblocks + blk;
     if (lane < kParGroups) a.grp[at].qe[lane] = mine_e;
     else if (lane < 2 * kParGroups) a.grp[at].qf[lane - kParGroups] = mine_f;
@@ -592,13 +712,15 @@ __global__ __launch_bounds__(kParThreads) void rms_par_tally_kernel(const RArgs 
         ParRec r;
         r.tag = (uint32_t)(eb & 0x1ff);
         if (all_zero) r.tag |= kParZero;
-        if ((bad_bits & 0xffu) != 0 || qtot >= (1u << 24)) r.tag |= kParBad;
+        if (scan_ok) { r.tag |= kParTies; qtot = sc.total; }
+        else if ((bad_bits & 0xffu) != 0 || qtot >= (1u << 24)) r.tag |= kParBad;
         if (gstar < kParGroups) r.tag |= kParHint | ((uint32_t)gstar << 16);
         r.qtot = qtot; r.bad = bad_bits;
         // the groups the stitch will most likely have to add one by one: g* itself, before it the groups
         // that cannot be settled against ulp(e), after it those that cannot against ulp(e + 1)
         r.need = gstar < kParGroups ? ((1u << gstar) | (bad_bits & ((1u << gstar) - 1u)) | ((bad_bits >> 8) & 0xffu & ~((2u << gstar) - 1u)))
-                                    : (bad_bits & 0xffu);
+                                    : (scan_ok ? 0u : (bad_bits & 0xffu));      // a ties-only block is settled without its squares
+        if (scan_ok) r.need |= (((uint32_t)sc.delta0 & 0xfffu) << 8) | (((uint32_t)sc.delta1 & 0xfffu) << 20);
         a.rec[at] = r;
     }
 }
@@ -647,19 +769,6 @@ __device__ __forceinline__ void par_load_squares(const RArgs &a, int64_t b, int 
     }
 }
 
-// inclusive prefix sum over the wave's lanes: Hillis-Steele inside each row of 16 (DPP row_shr, lanes
-// without a source add 0), then the row totals (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2-3)
-__device__ __forceinline__ uint32_t wave_prefix_u32(uint32_t x, int)
-{
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
-    return x;
-}
-
 // one wave per (stream, chain): blockIdx.x = stream * 4 + chain
 template <bool MONO>
 __global__ __launch_bounds__(64) void rms_par_stitch_kernel(const RArgs a)
@@ -683,7 +792,7 @@ __global__ __launch_bounds__(64) void rms_par_stitch_kernel(const RArgs a)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int mine = base + 64 * u + lane;
-            need[u] = mine < a.nblocks ? rec[mine].need : 0u;
+            need[u] = mine < a.nblocks ? (rec[mine].need & 0xffu) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -736,7 +845,8 @@ __global__ __launch_bounds__(64) void rms_par_stitch_kernel(const RArgs a)
             const uint32_t ab = __float_as_uint(acc);
             const uint32_t eb = ab >> 23;
             const bool zero = (r.tag & kParZero) != 0;
-            const bool plain = zero || ((r.tag & kParBad) == 0 && (r.tag & 0x1ffu) == eb);
+            const bool settled = (r.tag & kParBad) == 0 && (r.tag & 0x1ffu) == eb;      // tallied against the binade acc is in
+            const bool plain = zero || (settled && (r.tag & kParTies) == 0);
             const uint32_t q = (lane >= cur && plain && !zero) ? r.qtot : 0u;
             const uint32_t pfx = wave_prefix_u32(q, lane);
             const uint32_t mant = (ab & 0x7fffffu) | 0x800000u;
@@ -749,6 +859,27 @@ __global__ __launch_bounds__(64) void rms_par_stitch_kernel(const RArgs a)
                 if (add != 0) acc = __uint_as_float((eb << 23) | ((mant + add) & 0x7fffffu));
                 cur = f;
                 continue;
+            }
+            // blocks whose only trouble is ties: the tally kernel left both answers (TieScan), the parity of the
+            // mantissa picks one - a few scalar operations per block, as many blocks in a row as there are
+            {
+                const uint64_t tied = __ballot(settled && !zero && (r.tag & kParTies) != 0);
+                uint32_t m = mant;
+                int c = cur;
+                while (c < count && ((tied >> c) & 1ull) != 0 && eb >= 23 && eb < 255) {
+                    const uint32_t qt = (uint32_t)__builtin_amdgcn_readlane((int)r.qtot, c);
+                    const uint32_t nd = (uint32_t)__builtin_amdgcn_readlane((int)r.need, c);
+                    const int d = (m & 1u) ? ((int)nd >> 20) : ((int)(nd << 12) >> 20);          // signed 12-bit fields
+                    const uint32_t grown = m + qt + (uint32_t)d;
+                    if (grown >= (1u << 24)) break;           // the sum leaves its binade inside this block: group by group below
+                    m = grown;
+                    ++c;
+                }
+                if (c > cur) {
+                    acc = __uint_as_float((eb << 23) | (m & 0x7fffffu));
+                    cur = c;
+                    continue;
+                }
             }
             // block `cur` needs care: group by group, each either one integer add (its tally against the
             // binade acc is really in) or its 256 dependent additions - exact whatever the data
@@ -779,7 +910,9 @@ __global__ __launch_bounds__(64) void rms_par_stitch_kernel(const RArgs a)
                 } else {
                     par_load_squares<MONO>(a, b, chain, (int64_t)blk * kParFrames + (int64_t)g * kSeqGroup, kSeqGroup, scratch, lane);
                 }
-                acc = seq_add_group(sqs, acc);
+                // ties are settled in integers; a group in which the sum crosses a binade takes the additions
+                if (!seq_settle_ties(*(const float4 *)(sqs + 4 * lane), acc, (int)(__float_as_uint(acc) >> 23), lane))
+                    acc = seq_add_group(sqs, acc);
             }
         }
     }
