@@ -251,7 +251,8 @@ __device__ __forceinline__ bool seq_settle(const SeqTally &t, float &acc, int eb
 // dependent additions per group.  Valid while the sum stays inside its binade (the caller checks the final mantissa:
 // the running sum never decreases) and every square is inside the trick's range (tie_scan_group returns false).
 struct TieScan {
-    uint32_t total = 0;               // sum of the round-to-even tallies
+    uint32_t lane_total = 0;          // this lane's share of the round-to-even tallies (tie_scan_total adds the wave's)
+    uint32_t parity = 0;              // parity of the tallies so far (a ballot per group: no prefix sum is needed, only parities)
     int delta0 = 0, delta1 = 0;       // what the ties add to it when the scan starts from an even / odd mantissa
     uint32_t flip0 = 0, flip1 = 0;    // (scalars, not arrays: a run-time index would send them to scratch memory)
     bool ties = false;
@@ -259,49 +260,71 @@ struct TieScan {
 
 __device__ __forceinline__ bool tie_scan_group(TieScan &sc, const float4 &v4, float scale, int lane)
 {
-    const float sq[4] = {v4.x, v4.y, v4.z, v4.w};
-    uint32_t lane_q = 0, ties = 0, minus = 0, par = 0;     // bit i: element i ties / its remainder is -1/2 / parity of this lane's tallies before it
-    bool bad = false;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float scaled = sq[i] * scale;
-        const float whole = (scaled + 8388608.0f) - 8388608.0f;
-        const float rem = scaled - whole;
-        bad |= !(scaled < 4194304.0f);                     // also NaN and inf
-        ties |= (uint32_t)(rem == 0.5f || rem == -0.5f) << i;
-        minus |= (uint32_t)(rem == -0.5f) << i;
-        par |= (lane_q & 1u) << i;
-        lane_q += bad ? 0u : (uint32_t)whole;
-    }
+    // every lane: its four tallies, packed as in seq_tally (two squares per instruction)
+    const v2f scl = {scale, scale}, magic = {8388608.0f, 8388608.0f};
+    const v2f s01 = v2f{v4.x, v4.y} * scl, s23 = v2f{v4.z, v4.w} * scl;
+    const v2f w01 = (s01 + magic) - magic, w23 = (s23 + magic) - magic;
+    const v2f r01 = s01 - w01, r23 = s23 - w23;
+    const v2f smax = __builtin_elementwise_max(s01, s23);
+    const float lane_qf = (w01.x + w01.y) + (w23.x + w23.y);             // integers below 2^24: exact; NaN if a square was NaN
+    // (max ignores a NaN operand, the sum does not; an infinite square fails the range test)
+    const bool bad = !(fmaxf(smax.x, smax.y) < 4194304.0f) || !(lane_qf < 16777216.0f);
+    const v2f rmax = __builtin_elementwise_max(r01, r23), rmin = __builtin_elementwise_min(r01, r23);
+    const bool tied = fmaxf(rmax.x, rmax.y) == 0.5f || fminf(rmin.x, rmin.y) == -0.5f;
     if (__ballot(bad) != 0) return false;
-    const uint32_t incl = wave_prefix_u32(lane_q, lane);
-    const uint32_t info = ties | (minus << 4) | (par << 8) | (((incl - lane_q) & 1u) << 12);
-    const uint32_t base = sc.total & 1u;                   // parity of the tallies of the groups before
-    uint64_t tmask = __ballot(ties != 0);
-    sc.ties |= tmask != 0;
-    while (tmask != 0) {
-        const int l = __builtin_ctzll(tmask);
-        tmask &= tmask - 1;
-        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)info, l);
+    const uint32_t lane_q = (uint32_t)lane_qf;
+    const uint64_t odd_lanes = __ballot((lane_q & 1u) != 0);
+    uint64_t tmask = __ballot(tied);
+    if (tmask != 0) {
+        // the lanes that hold a tie describe their four squares: bit i: element i ties / its remainder is -1/2 /
+        // parity of this lane's tallies before it (few lanes do; the branch is taken by the whole wave)
+        const float wh[4] = {w01.x, w01.y, w23.x, w23.y}, rm[4] = {r01.x, r01.y, r23.x, r23.y};
+        uint32_t info = 0, run = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if ((w >> i) & 1u) {
-                const uint32_t before = (base ^ (w >> 12) ^ (w >> (8 + i))) & 1u;
-                const int sign = ((w >> (4 + i)) & 1u) ? -1 : 1;
-                if ((before ^ sc.flip0) & 1u) { sc.delta0 += sign; sc.flip0 ^= 1u; }
-                if ((1u ^ before ^ sc.flip1) & 1u) { sc.delta1 += sign; sc.flip1 ^= 1u; }
+            info |= (uint32_t)(rm[i] == 0.5f || rm[i] == -0.5f) << i;
+            info |= (uint32_t)(rm[i] == -0.5f) << (4 + i);
+            info |= (run & 1u) << (8 + i);
+            run += (uint32_t)wh[i];
+        }
+        const uint32_t base = sc.parity;                       // parity of the tallies of the groups before
+        sc.ties = true;
+        while (tmask != 0) {
+            const int l = __builtin_ctzll(tmask);
+            tmask &= tmask - 1;
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)info, l);
+            const uint32_t lanes_before = (uint32_t)__builtin_popcountll(odd_lanes & ((1ull << l) - 1ull));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if ((w >> i) & 1u) {
+                    const uint32_t before = (base ^ lanes_before ^ (w >> (8 + i))) & 1u;
+                    const int sign = ((w >> (4 + i)) & 1u) ? -1 : 1;
+                    if ((before ^ sc.flip0) & 1u) { sc.delta0 += sign; sc.flip0 ^= 1u; }
+                    if ((1u ^ before ^ sc.flip1) & 1u) { sc.delta1 += sign; sc.flip1 ^= 1u; }
+                }
             }
         }
     }
-    sc.total += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    sc.parity ^= (uint32_t)__builtin_popcountll(odd_lanes) & 1u;
+    sc.lane_total += lane_q;                                   // summed over the wave once, by tie_scan_total
     return true;
+}
+
+// the scan's tally: one wave reduction for all its groups (call once, after the last group)
+__device__ __forceinline__ uint32_t tie_scan_total(const TieScan &sc)
+{
+    // a lane's share beyond 2^24 means the sum has left its binade long ago (and 64 such shares could wrap): saturate
+    if (__ballot(sc.lane_total >= (1u << 24)) != 0) return 0xffffffffu;
+    return wave_sum_u32(sc.lane_total);
 }
 
 // acc over the scanned squares, if the sum stayed inside its binade
 __device__ __forceinline__ bool tie_scan_apply(const TieScan &sc, float &acc, int eb)
 {
     const uint32_t mant = (__float_as_uint(acc) & 0x7fffffu) | 0x800000u;
-    const uint32_t grown = mant + sc.total + (uint32_t)((mant & 1u) ? sc.delta1 : sc.delta0);
+    const uint32_t total = tie_scan_total(sc);
+    if (total >= (1u << 24)) return false;
+    const uint32_t grown = mant + total + (uint32_t)((mant & 1u) ? sc.delta1 : sc.delta0);
     if (grown >= (1u << 24)) return false;
     acc = __uint_as_float(((uint32_t)eb << 23) | (grown & 0x7fffffu));
     return true;
@@ -698,12 +721,14 @@ __global__ __launch_bounds__(kParThreads) void rms_par_tally_kernel(const RArgs 
     // a block whose only trouble is ties: its round-to-even tally and the two corrections (start even / odd), so that the
     // stitch accepts it with three scalar operations (audio that came from integers has ties in most blocks)
     TieScan sc;
+    uint32_t scan_total = 0;
     bool scan_ok = eb >= 23 && eb < 255 && (bad_bits & 0xffu) != 0;
     if (scan_ok) {
         const float scale = seq_scale(eb);
 #pragma unroll 1
         for (int g = 0; g < kParGroups && scan_ok; ++g) scan_ok = tie_scan_group(sc, *(const float4 *)(row + g * kSeqGroup + 4 * lane), scale, lane);
-        scan_ok = scan_ok && sc.ties && sc.total < (1u << 24) && abs(sc.delta0) < 2048 && abs(sc.delta1) < 2048;
+        if (scan_ok) scan_total = tie_scan_total(sc);
+        scan_ok = scan_ok && sc.ties && scan_total < (1u << 24) && abs(sc.delta0) < 2048 && abs(sc.delta1) < 2048;
     }
     const int64_t at = (b * 4 + chain) * a.nblocks + blk;
     if (lane < kParGroups) a.grp[at].qe[lane] = mine_e;
@@ -712,7 +737,7 @@ __global__ __launch_bounds__(kParThreads) void rms_par_tally_kernel(const RArgs 
         ParRec r;
         r.tag = (uint32_t)(eb & 0x1ff);
         if (all_zero) r.tag |= kParZero;
-        if (scan_ok) { r.tag |= kParTies; qtot = sc.total; }
+        if (scan_ok) { r.tag |= kParTies; qtot = scan_total; }
         else if ((bad_bits & 0xffu) != 0 || qtot >= (1u << 24)) r.tag |= kParBad;
         if (gstar < kParGroups) r.tag |= kParHint | ((uint32_t)gstar << 16);
         r.qtot = qtot; r.bad = bad_bits;
