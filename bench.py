@@ -221,7 +221,9 @@ def end_to_end(torch, vnd, mode) -> dict:
                          'GBs_in_plus_out': round(2 * x.nbytes / dt / 1e9, 2)}
         out[name] = rec
     out['note'] = ('host pointers in, host pointers out (H2D + kernel + D2H inside the call); the result array is '
-                   'allocated by the call as the reference does; never part of `value`')
+                   'allocated by the call as the reference does; never part of `value`.  A page-locked input is not faster '
+                   'for the large batch: page-locked uploads and downloads share the SDMA path (57 GB/s in total on this '
+                   'platform, tools/pcie_probe.py), a pageable upload is staged by the CPU beside the SDMA download')
     return out
 
 
