@@ -227,6 +227,82 @@ def end_to_end(torch, vnd, mode) -> dict:
     return out
 
 
+def next_rows(torch, vnd, _native) -> dict:
+    """SURVEY 8(f) rows on one GPU, host to host or device resident as stated (rates only; parity is tests/)."""
+    import contextlib
+    import io
+    out = {}
+    rng = np.random.default_rng(5)
+    n = SAMPLE_RATE * SECONDS
+
+    def best_of(fn, reps):
+        fn()
+        best = 1e9
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            best = min(best, time.perf_counter() - t0)
+        return best * 1e3
+
+    # f1: VelvetNoise.decorrelate (side-channel encode + exact RMS normaliser), bit-identical mode
+    try:
+        vn = vnd.VelvetNoise(sample_rate_hz=SAMPLE_RATE, seed=1)
+        table = vn._device_table()
+        st = torch.cuda.current_stream().cuda_stream
+        ws_bytes = _native.decorrelate_workspace_bytes(1, n, 2)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device='cuda')
+        rec = {}
+        music = np.round(8000 * (np.sin(np.arange(n) * 0.01)[:, None] * np.array([1.0, 0.7]) + 0.3 * rng.standard_normal((n, 2))))
+        for name, sig in (('uniform_float', rng.uniform(-1, 1, (n, 2)).astype(np.float32)),
+                          ('int16_music', (music / 32768.0).astype(np.float32))):
+            x = torch.from_numpy(sig[None]).cuda()
+            y = torch.empty_like(x)
+
+            def run():
+                table.decorrelate_device(x.data_ptr(), y.data_ptr(), 1, n, 2, mode=vnd.MODE_EXACT, ms_encode=True, width=None,
+                                         normalize=True, workspace_ptr=ws.data_ptr(), workspace_bytes=ws_bytes, stream=st)
+            for _ in range(10):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(100):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            rec[name + '_device_resident_ms'] = round(e0.elapsed_time(e1) / 100, 4)
+        host = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+        rec['uniform_float_host_to_host_ms'] = round(best_of(lambda: vn.decorrelate(host), 10), 3)
+        rec['what'] = ('VelvetNoise.decorrelate of one 10 s 48 kHz stereo signal, VND_MODE_EXACT: bit-identical to the reference, '
+                       'RMS normaliser in NumPy order (block-parallel sums, ties in integers)')
+        out['f1_decorrelate_exact'] = rec
+    except Exception as exc:
+        out['f1_decorrelate_exact'] = {'error': repr(exc)}
+    # f3: the optimiser's candidate scan, host to host
+    try:
+        import vndecorrelate_amd.optimization as opt
+        fs = 44100
+        sig = rng.uniform(-1, 1, (int(fs * 5.7), 2)).astype(np.float32)
+        cands = [vnd.VelvetNoise(sample_rate_hz=fs, duration_seconds=0.03, num_impulses=30, log_distribution_strength=k,
+                                 normalizer=None, filtered_channels=(0,), mode='LR', seed=1) for k in np.linspace(0, 1, 400)]
+        kw = dict(angle_limit=float(np.pi / 4), lambda_mean=5.0, lambda_skew=2.0, lambda_correlation=15.0, lambda_penalty=1e3)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ms = best_of(lambda: opt.grid_scan(sig, cands, **kw), 5)
+        out['f3_grid_scan'] = {'ms_host_to_host': round(ms, 3), 'what': 'grid_scan of 400 built candidates x 5.7 s of 44.1 kHz stereo'}
+    except Exception as exc:
+        out['f3_grid_scan'] = {'error': repr(exc)}
+    # f4: velvet noise -> Haas chain, device resident, host to host
+    try:
+        host = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+        chain = (vnd.SignalChain(sample_rate_hz=SAMPLE_RATE, device_resident=True).velvet_noise(seed=1)
+                 .haas_effect(delay_time_seconds=0.02, delayed_channel=1, mode='LR'))
+        out['f4_resident_chain'] = {'ms_host_to_host': round(best_of(lambda: chain(host), 5), 3),
+                                    'what': 'SignalChain(velvet noise -> Haas), 10 s stereo in, float64 (n + delay, 2) out, exact mode'}
+    except Exception as exc:
+        out['f4_resident_chain'] = {'error': repr(exc)}
+    return out
+
+
 def cfg4_strong(torch, dist, vnd, _native, ctx, table_image, mode, world, rank, device, backend) -> dict:
     """SURVEY 8(d) scaling leg: 1024 x 1 s stereo streams, contiguous shards, no data-path collective."""
     from vndecorrelate_amd.distributed import shard_range
@@ -459,6 +535,7 @@ def main():
                 line['end_to_end'] = end_to_end(torch, vnd, mode)
             except Exception as exc:                    # as above: never at the headline's expense
                 line['end_to_end'] = {'error': repr(exc)}
+            line['next_rows'] = next_rows(torch, vnd, _native)
         if world == 1 and not args.no_cpu:
             line['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)
