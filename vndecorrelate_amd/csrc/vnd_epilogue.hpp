@@ -503,19 +503,21 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
 // The recurrence itself cannot be split, but what it needs per block can: whether a run of squares
 // can be settled in integers depends only on the BINADE of the running sum when the run starts, and
 // that is predictable from a float64 prefix of the block sums.  So:
-//   rms_par_sum     one workgroup per block of 2048 frames: float64 sum of each chain's squares
-//                   (block 0, whose starting sum is known - zero - is summed for good, sequentially);
+//   rms_par_sum     one workgroup per block of 2048 frames: float64 sum of each chain's squares;
 //   rms_par_tally   one workgroup per block: predicts the binade e at the block's start from the
 //                   prefix of those sums and, where the sum is about to leave the binade, the group
-//                   g* of 256 squares in which it will; computes the integer tallies QA (groups
-//                   before g*, against ulp(e)) and QB (groups after g*, against ulp(e + 1)) with their
-//                   tie / range flags;
+//                   g* of 256 squares in which it will; computes the integer tallies per group against
+//                   ulp(e) and against ulp(e + 1) with their tie / range flags, and for a block whose
+//                   only trouble is TIES its tally plus the two corrections for an even / odd mantissa
+//                   at its start (TieScan).  An extra workgroup sums block 0, whose starting sum is
+//                   known - zero -, for good with the sequential code;
 //   rms_par_stitch  one wave per chain walks the blocks in order.  Runs of blocks whose prediction
 //                   holds are accepted 64 at a time (a wave prefix sum of their tallies finds the
-//                   first one that does not fit); a block that crosses a binade costs two integer
-//                   adds and the 256 dependent float additions of its group g* (prefetched when the
-//                   kernel starts); only what defeats the prediction - ties, a sum that crosses where
-//                   it was not expected to - is re-read and summed by the sequential code above.
+//                   first one that does not fit); ties-only blocks take a few scalar operations each
+//                   (the mantissa's low bit picks the correction); a block that crosses a binade goes
+//                   group by group: integer adds, an integer tie scan, or - in the group where the
+//                   sum really leaves its binade - the 256 dependent float additions (its squares
+//                   prefetched when the kernel starts); what defeats the prediction is re-read.
 // Every accepted step is exactly what the dependent float32 additions produce, every prediction
 // is verified against the actual running sum, so the result is the sequential kernel's (NumPy's,
 // utils/dsp.py:87-109) bit for bit.
