@@ -949,7 +949,7 @@ struct RcclApi {
     const char *(*error_string)(int) = nullptr;
     bool tried = false;
 };
-RcclApi &rccl_api()
+RcclApi *rccl_api()
 {
     static RcclApi api;
     static std::mutex m;
@@ -963,7 +963,7 @@ RcclApi &rccl_api()
             api.error_string = (decltype(api.error_string))dlsym(h, "ncclGetErrorString");
         }
     }
-    return api;
+    return &api;
 }
 constexpr int kNcclUint8 = 1;         // rccl.h: ncclDataType_t
 }  // namespace
@@ -973,7 +973,7 @@ vnd_status vnd_taps_broadcast_rccl(vnd_ctx *ctx, vnd_taps **taps, int32_t root, 
 {
     if (!ctx || !taps || !rccl_comm) return fail(VND_ERR_INVALID, "null context, table slot or communicator");
     if (rank == root && !*taps) return fail(VND_ERR_INVALID, "the root rank has no table to send");
-    RcclApi &api = rccl_api();
+    RcclApi &api = *rccl_api();
     if (!api.broadcast) return fail(VND_ERR_UNSUPPORTED, "librccl.so could not be loaded");
     DeviceScope on(ctx->device);
     hipStream_t stream = (hipStream_t)stream_;
