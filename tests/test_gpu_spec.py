@@ -229,6 +229,12 @@ def test_exact_mode_specialised_class_path(env, golden, name):
     ctx.set_variant(FORCE | EXACT_TOO | span_bits(1, 3))
     try:
         y = vn.convolve(x)
+        # a table whose channels are all filtered really takes the per-table kernel (one with a copied-through
+        # channel is outside its scope and comes out of the generic kernel)
+        every = len(kw.get('filtered_channels', (0, 1))) == vn.num_outs and vn.num_outs % 2 == 0 and \
+            vn._device_table().max_index < 3000                      # (a 0.5 s filter's history does not fit the LDS ring)
+        launch = vn._device_table().describe(1, len(x), vn.num_outs, d.MODE_EXACT)
+        assert launch.startswith('conv_spec_exact') == every, (name, launch)
     finally:
         ctx.set_variant(-1)
     golden.expect(name, y, exact=x.dtype == np.float32, rtol_peak=TOL_PEAK)
@@ -255,6 +261,37 @@ def test_exact_mode_real_size_equals_the_generic_kernel(env, golden):
     offs, idx, w = O.fir_to_taps(fir)
     assert np.array_equal(y[7].cpu().numpy(), c_oracle.convolve(x[7].cpu().numpy(), offs, idx, w))
     table.close()
+
+
+def test_class_path_exact_takes_the_specialised_kernel_by_default(env, golden):
+    """VelvetNoise.convolve's table (every weight +-1: one packed add per tap) gains 29 % from the per-table kernel in
+    VND_MODE_EXACT, so a large enough batch takes it WITHOUT the opt-in; bit-identical to the generic ordered kernel
+    and, on one stream, to the oracle's class-path association."""
+    import torch
+    d, native, ctx = env
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in golden.manifest['class_taps']['v48k']['kwargs'].items()}
+    vn = d.VelvetNoise(**kw)
+    table = vn._device_table()
+    pool, n = 32, 480000
+    x = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1)
+    y, yg = torch.empty_like(x), torch.empty_like(x)
+    s = torch.cuda.current_stream().cuda_stream
+    ctx.set_variant(-1)
+    assert table.describe(pool, n, 2, d.MODE_EXACT).startswith('conv_spec_exact')
+    table.convolve_device(x.data_ptr(), y.data_ptr(), pool, n, 2, mode=d.MODE_EXACT, stream=s)
+    ctx.set_variant(GENERIC)
+    assert table.describe(pool, n, 2, d.MODE_EXACT).startswith('conv_ordered')
+    table.convolve_device(x.data_ptr(), yg.data_ptr(), pool, n, 2, mode=d.MODE_EXACT, stream=s)
+    torch.cuda.synchronize()
+    ctx.set_variant(-1)
+    assert torch.equal(y, yg)
+    taps = golden.class_taps('v48k', 2)
+    env_gains = tuple(golden.manifest['class_taps']['v48k']['envelope'])
+    assert np.array_equal(y[5].cpu().numpy(), O.class_convolve(x[5].cpu().numpy(), taps, env_gains, 2))
+    # a function-path table (arbitrary weights: multiply + add per tap, 2 % to gain) still specialises on request only
+    fn = _table(native, ctx, golden.fir('g48k_k30'))
+    assert fn.describe(pool, n, 2, d.MODE_EXACT).startswith('conv_ordered')
+    fn.close()
 
 
 def test_failed_runtime_build_falls_back_to_the_generic_kernel(env, golden, monkeypatch):
@@ -299,6 +336,10 @@ def test_fast_mode_specialised_class_path(env, golden, name):
     d.set_default_mode(d.MODE_FAST)
     try:
         y = vn.convolve(x)
+        every = len(kw.get('filtered_channels', (0, 1))) == vn.num_outs and vn.num_outs % 2 == 0 and \
+            vn._device_table().max_index < 3000
+        launch = vn._device_table().describe(1, len(x), vn.num_outs, d.MODE_FAST)
+        assert launch.startswith('conv_spec') == every, (name, launch)
     finally:
         d.set_default_mode(d.MODE_EXACT)
         ctx.set_variant(-1)

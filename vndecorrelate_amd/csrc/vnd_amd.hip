@@ -95,6 +95,7 @@ struct vnd_taps {
     SpecTable spec_table;          // effective weights (segment gain folded in)
     bool spec_ok = false;          // the table is within the specialised kernel's scope
     bool spec_exact_ok = false;    // ... also in VND_MODE_EXACT (no empty segment)
+    bool spec_exact_pays = false;  // ... and worth a build there: every weight +-1 (class path: adds only, +29 % on cfg2)
     std::mutex spec_mutex;
     std::map<SpecConfig, std::unique_ptr<SpecModule>> spec_modules;
 };
@@ -401,10 +402,12 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     if (mode != VND_MODE_FAST && mode != VND_MODE_EXACT) { p.why = "neither the fast nor the exact mode"; return p; }
     if (epi || Cx != C) { p.why = "fused epilogue or fan-out launch"; return p; }
     if (!(mode == VND_MODE_EXACT ? t->spec_exact_ok : t->spec_ok)) { p.why = "table outside the specialised kernel's scope"; return p; }
-    // The exact arithmetic (two VALU instructions and 1.5 LDS reads per tap) gains 2 % from specialisation
-    // (tools/exact_try.py: 0.298 vs 0.304 ms on the cfg2 pool): not worth a hipRTC build by default.  Opt in
-    // with VND_SPEC_EXACT=1 or variant bit 15; the parity tests do.
-    if (mode == VND_MODE_EXACT && !(v >= 0 && ((v >> 15) & 1))) {
+    // The exact arithmetic of a function-path table (two VALU instructions and 1.5 LDS reads per tap) gains 2 %
+    // from specialisation (tools/exact_try.py: 0.298 vs 0.304 ms on the cfg2 pool): not worth a hipRTC build by
+    // default - opt in with VND_SPEC_EXACT=1 or variant bit 15; the parity tests do.  A class-path table
+    // (VelvetNoise.convolve: every weight +-1, one packed add per tap) gains 29 % (tools/exact_class_try.py:
+    // 0.269 vs 0.348 ms): built by default.
+    if (mode == VND_MODE_EXACT && !(t->spec_exact_ok && t->spec_exact_pays) && !(v >= 0 && ((v >> 15) & 1))) {
         static const bool on = [] { const char *e = getenv("VND_SPEC_EXACT"); return e && e[0] == '1'; }();
         if (!on) { p.why = "exact mode specialises on request only"; return p; }
     }
@@ -772,11 +775,15 @@ vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, 
         t->spec_table.idx = t->idx;
         t->spec_table.w = eff;
         t->spec_table.max_index = max_index;
-        t->spec_ok = t->lds_images && !t->nonfinite && !t->has_flags && C % 2 == 0 && C <= 64 && total > 0;
+        bool copy_through = false;                             // a channel that is copied, not filtered: generic kernels only
+        for (int c = 0; c < C && t->has_flags; ++c) copy_through |= (t->flags[c] & 1) != 0;
+        t->spec_ok = t->lds_images && !t->nonfinite && !copy_through && C % 2 == 0 && C <= 64 && total > 0;
         t->spec_table.w_raw.assign(tap_weight, tap_weight + total);
         t->spec_table.has_seg = has_seg;
         t->spec_table.apply_gain = t->apply_gain != 0;
         t->spec_exact_ok = t->spec_ok;
+        t->spec_exact_pays = true;
+        for (int32_t k = 0; k < total; ++k) t->spec_exact_pays &= (tap_weight[k] == 1.0f || tap_weight[k] == -1.0f);
         if (has_seg) {
             t->spec_table.seg_off = t->seg_off; t->spec_table.seg_end = t->seg_end; t->spec_table.seg_gain = t->seg_gain;
             for (int c = 0; c < C; ++c) {
