@@ -294,6 +294,43 @@ def test_class_path_exact_takes_the_specialised_kernel_by_default(env, golden):
     fn.close()
 
 
+@pytest.mark.parametrize('ms_encode,width', [(True, None), (True, 0.3), (False, 0.75)])
+def test_decorrelate_stage_through_the_specialised_kernel(env, golden, ms_encode, width, tmp_path, monkeypatch):
+    """The whole exact stage on a batch: the side-channel encode and stereo width ride in the per-table exact
+    kernel's store phase (VS_EPI) exactly as in the generic ordered kernel's - same bytes out, and the
+    reference's own stage (oracle) on one stream."""
+    import torch
+    d, native, ctx = env
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in golden.manifest['class_taps']['v48k']['kwargs'].items()}
+    kw['seed'] = 1000 + int(ms_encode) * 2 + int(width is not None) + int(100 * (width or 0))      # a table no other test has built
+    vn = d.VelvetNoise(**kw)
+    table = vn._device_table()
+    # proof that the per-table kernel with the fused steps is what runs: a fresh kernel cache receives exactly one
+    # code object, and the generated source says VS_EPI 1 / VS_EXACT 1
+    monkeypatch.setenv('VND_SPEC_CACHE_DIR', str(tmp_path / 'cache'))
+    monkeypatch.setenv('VND_SPEC_DUMP', str(tmp_path / 'kernel.hip'))
+    pool, n = 24, 300002                    # (an odd frame count puts every second stream off the 16-byte grid: generic kernel)
+    x = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1)
+    s = torch.cuda.current_stream().cuda_stream
+    ws_bytes = native.decorrelate_workspace_bytes(pool, n, 2)
+    outs = {}
+    for label, variant in (('spec', FORCE | span_bits(1, 2)), ('generic', GENERIC)):
+        ctx.set_variant(variant)
+        y = torch.empty_like(x)
+        ws = torch.zeros(ws_bytes // 8 + 1, dtype=torch.float64, device='cuda')
+        table.decorrelate_device(x.data_ptr(), y.data_ptr(), pool, n, 2, mode=d.MODE_EXACT, ms_encode=ms_encode, width=width,
+                                 normalize=True, workspace_ptr=ws.data_ptr(), workspace_bytes=ws_bytes, stream=s)
+        torch.cuda.synchronize()
+        outs[label] = y
+    ctx.set_variant(-1)
+    assert len(list((tmp_path / 'cache').glob('*.co'))) == 1
+    source = (tmp_path / 'kernel.hip').read_text()
+    assert '#define VS_EPI 1' in source and '#define VS_EXACT 1' in source
+    assert torch.equal(outs['spec'], outs['generic'])
+    want = O.decorrelate(x[3].cpu().numpy().copy(), sample_rate_hz=48000, seed=kw['seed'], width=width, mode='MS' if ms_encode else 'LR')
+    assert np.array_equal(outs['spec'][3].cpu().numpy(), want)
+
+
 def test_failed_runtime_build_falls_back_to_the_generic_kernel(env, golden, monkeypatch):
     """If hipRTC cannot build the per-table kernel (here: an injected #error), the launch silently takes the
     generic HIP kernel - never a CPU path - the result is still right, and vnd_describe_launch says so."""

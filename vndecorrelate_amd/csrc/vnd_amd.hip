@@ -390,17 +390,27 @@ static bool spec_disabled_by_env()
     return off;
 }
 
+struct EpiFuse {                 // non-null => launch the fused-epilogue instantiation
+    double *partials;
+    int ms_encode, use_width, normalize;
+    float w_mid, w_side;
+    double *sink = nullptr;      // moments sink: [tiles][groups][8]; the output is reduced, not written
+};
+
 // variant word, specialised kernel: bit 25 forces the generic kernel; bits 26-27 prefetch depth
 // (0 = auto), bits 28-30 spans per resident slot ("rounds", 0 = auto); bits 0-4 = pairs per lane as ever;
 // bits 20-22 shortest span in tiles (0 = auto, 8) and bit 23 "specialise however little work there
 // is" - the two that let the tests drive span seams and tiny signals through this kernel.
 static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const float *x, const float *y, int64_t batch,
-                               int64_t n, int C, int Cx, int mode, bool epi)
+                               int64_t n, int C, int Cx, int mode, const EpiFuse *epi)
 {
     SpecPlan p;
     const int v = ctx->variant;
     if (mode != VND_MODE_FAST && mode != VND_MODE_EXACT) { p.why = "neither the fast nor the exact mode"; return p; }
-    if (epi || Cx != C) { p.why = "fused epilogue or fan-out launch"; return p; }
+    // a fused epilogue is within scope when it is the pointwise steps alone (no sums, no moments sink), exact mode, stereo:
+    // they ride in the exact kernel's store phase (VS_EPI)
+    const bool pointwise = epi != nullptr && !epi->normalize && epi->sink == nullptr && mode == VND_MODE_EXACT && C == 2;
+    if ((epi != nullptr && !pointwise) || Cx != C) { p.why = "fused epilogue or fan-out launch"; return p; }
     if (!(mode == VND_MODE_EXACT ? t->spec_exact_ok : t->spec_ok)) { p.why = "table outside the specialised kernel's scope"; return p; }
     // The exact arithmetic of a function-path table (two VALU instructions and 1.5 LDS reads per tap) gains 2 %
     // from specialisation (tools/exact_try.py: 0.298 vs 0.304 ms on the cfg2 pool): not worth a hipRTC build by
@@ -462,6 +472,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     p.cfg.nt_stores = (batch * n * C * (int64_t)sizeof(float) >= ((int64_t)64 << 20)) ? 1 : 0;
     if (C != 2 && !getenv("VND_FORCE_NT")) p.cfg.nt_stores = 0;      // a channel pair is a piece of a frame: let L2 merge the pieces
     p.cfg.exact = mode == VND_MODE_EXACT ? 1 : 0;
+    p.cfg.epi = pointwise ? 1 : 0;
     // exact mode counts VS_LA in steps of RR to 2*RR reads: the LDS queue holds 15, three steps fill it
     if (p.cfg.exact && !getenv("VND_SPEC_LA")) p.cfg.la = 3;
     p.tiles_total = (int)tiles_total; p.tiles_per_span = (int)per_span; p.spans = (int)spans;
@@ -490,7 +501,7 @@ static SpecModule *spec_module(vnd_ctx *ctx, const vnd_taps *t_, const SpecConfi
 }
 
 static vnd_status launch_spec(vnd_ctx *ctx, const vnd_taps *t, const SpecPlan &p, const float *x, float *y, int64_t n,
-                              hipStream_t stream, bool *launched)
+                              hipStream_t stream, bool *launched, const EpiFuse *epi = nullptr)
 {
     *launched = false;
     SpecModule *m = spec_module(ctx, t, p.cfg);
@@ -499,6 +510,9 @@ static vnd_status launch_spec(vnd_ctx *ctx, const vnd_taps *t, const SpecPlan &p
     a.x = x; a.y = y; a.n = n;
     a.tiles_total = p.tiles_total; a.tiles_per_span = p.tiles_per_span; a.spans = p.spans; a.nblocks = p.nblocks;
     a.units = p.units;
+    if (epi != nullptr && p.cfg.epi) {
+        a.epi_ms_encode = epi->ms_encode; a.epi_use_width = epi->use_width; a.epi_w_mid = epi->w_mid; a.epi_w_side = epi->w_side;
+    }
     void *params[] = {&a};
     hipError_t e = hipModuleLaunchKernel(m->fn, p.nblocks, 1, 1, p.cfg.nt, 1, 1, (unsigned)p.cfg.lds_bytes(), stream, params,
                                          nullptr);
@@ -513,12 +527,6 @@ static vnd_status launch_spec(vnd_ctx *ctx, const vnd_taps *t, const SpecPlan &p
     return VND_OK;
 }
 
-struct EpiFuse {                 // non-null => launch the fused-epilogue instantiation
-    double *partials;
-    int ms_encode, use_width, normalize;
-    float w_mid, w_side;
-    double *sink = nullptr;      // moments sink: [tiles][groups][8]; the output is reduced, not written
-};
 
 static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
                          int64_t n, int32_t C, int32_t mode, hipStream_t stream, const EpiFuse *epi = nullptr,
@@ -527,10 +535,10 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
     if (batch == 0 || n == 0) return VND_OK;
     if (Cx == 0) Cx = C;
     {
-        const SpecPlan sp = make_spec_plan(ctx, t, x, y, batch, n, C, Cx, mode, epi != nullptr);
+        const SpecPlan sp = make_spec_plan(ctx, t, x, y, batch, n, C, Cx, mode, epi);
         if (sp.use) {
             bool launched = false;
-            vnd_status st = launch_spec(ctx, t, sp, x, y, n, stream, &launched);
+            vnd_status st = launch_spec(ctx, t, sp, x, y, n, stream, &launched, epi);
             if (st != VND_OK || launched) return st;
         }
     }
@@ -1191,7 +1199,7 @@ static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64
     if (st != VND_OK) return st;
     if (!text || len <= 0) return fail(VND_ERR_INVALID, "null text buffer");
     // the pointers only decide alignment: describe the launch of 256-byte-aligned buffers (hipMalloc's)
-    const SpecPlan sp = make_spec_plan(ctx, t, nullptr, nullptr, batch, n, C, Cx, mode, false);
+    const SpecPlan sp = make_spec_plan(ctx, t, nullptr, nullptr, batch, n, C, Cx, mode, nullptr);
     if (sp.use) {
         DeviceScope on(ctx->device);
         SpecModule *m = spec_module(ctx, t, sp.cfg);

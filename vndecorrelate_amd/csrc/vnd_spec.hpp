@@ -41,6 +41,7 @@ struct SpecConfig {
     int la = 8;        // LDS reads in flight ahead of the FMAs
     int nt_stores = 0; // non-temporal output stores
     int exact = 0;     // VND_MODE_EXACT arithmetic: table order, separately rounded products and sums
+    int epi = 0;       // exact mode, stereo: VelvetNoise.decorrelate's pointwise steps in the store phase
     int tile() const { return 2 * nt * rr; }
     size_t lds_bytes() const
     {
@@ -49,7 +50,7 @@ struct SpecConfig {
     }
     bool operator<(const SpecConfig &o) const
     {
-        return std::tie(nt, rr, pp, dd, la, nt_stores, exact) < std::tie(o.nt, o.rr, o.pp, o.dd, o.la, o.nt_stores, o.exact);
+        return std::tie(nt, rr, pp, dd, la, nt_stores, exact, epi) < std::tie(o.nt, o.rr, o.pp, o.dd, o.la, o.nt_stores, o.exact, o.epi);
     }
 };
 
@@ -137,8 +138,8 @@ inline std::string spec_prologue(const SpecTable &t, const SpecConfig &c)
     std::string s;
     spec_append(s, "#define VS_NT %d\n#define VS_RR %d\n#define VS_PP %d\n#define VS_DD %d\n#define VS_LA %d\n", c.nt, c.rr,
                 c.pp, c.dd, c.la);
-    spec_append(s, "#define VS_C %d\n#define VS_GROUPS %d\n#define VS_NT_STORES %d\n#define VS_EXACT %d\n", t.C, groups,
-                c.nt_stores, c.exact);
+    spec_append(s, "#define VS_C %d\n#define VS_GROUPS %d\n#define VS_NT_STORES %d\n#define VS_EXACT %d\n#define VS_EPI %d\n", t.C, groups,
+                c.nt_stores, c.exact, c.epi);
     spec_append(s, "#define VS_NT_STORE_AUX %d\n", spec_env("VND_SPEC_STORE_AUX", 2));   // cache policy bits of the non-temporal stores (tuning)
     spec_append(s, "#define VS_LOAD_AUX %d\n", spec_env("VND_SPEC_LOAD_AUX", 2));     // input is read once: non-temporal loads (+1-2 % on cfg2)
     {   // resident workgroups per CU (LDS-bound, at most 32 waves) -> waves per SIMD the register budget must allow
@@ -325,6 +326,8 @@ struct SpecArgs {
     long long n;
     int tiles_total, tiles_per_span, spans;
     unsigned nblocks, units;
+    int epi_ms_encode, epi_use_width;
+    float epi_w_mid, epi_w_side;
 };
 
 struct SpecModule {
