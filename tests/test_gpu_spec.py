@@ -110,7 +110,11 @@ def test_out_of_scope_launches_take_the_generic_kernel(env, golden):
     assert t3.describe(4, 50000, 3, d.MODE_FAST).startswith('conv_fast')
     t2 = _table(native, ctx, golden.fir('g48k_k30'))
     assert t2.describe(3, 50001, 2, d.MODE_FAST).startswith('conv_fast')  # odd streams: 8-byte aligned bases
-    assert t2.describe(4, 50000, 1, d.MODE_FAST).startswith('conv_fast')  # fan-out launch
+    assert t2.describe(4, 50000, 1, d.MODE_FAST).startswith('conv_spec')  # a mono input through the stereo table is in scope (VS_BC) ...
+    assert t2.describe(4, 50001, 1, d.MODE_FAST).startswith('conv_fast')  # ... unless its streams start off the 8-byte grid
+    t8 = _table(native, ctx, golden.fir('g96k_k64_c8'))
+    assert t8.describe(4, 50000, 2, d.MODE_FAST).startswith('conv_fast')  # wider fan-outs are not
+    t8.close()
     x = np.random.default_rng(5).uniform(-1, 1, (3, 50001, 2)).astype(np.float32)
     want = np.stack([O.convolve_velvet_noise(x[b], golden.fir('g48k_k30')) for b in range(3)])
     _check(t2.convolve_host(x, d.MODE_FAST), want, 'odd streams')
@@ -329,6 +333,74 @@ def test_decorrelate_stage_through_the_specialised_kernel(env, golden, ms_encode
     assert torch.equal(outs['spec'], outs['generic'])
     want = O.decorrelate(x[3].cpu().numpy().copy(), sample_rate_hz=48000, seed=kw['seed'], width=width, mode='MS' if ms_encode else 'LR')
     assert np.array_equal(outs['spec'][3].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('which', ['function_path', 'class_path'])
+def test_mono_fan_out_through_the_specialised_kernels(env, golden, which):
+    """A mono input through a stereo table (mono -> stereo decorrelation, decorrelation.py:431-432): the per-table
+    kernels stage ONE plane that both channels' taps read (VS_BC).  Fast mode within tolerance, exact mode bit for bit,
+    against the oracle on the replicated input; span seams and a ragged last tile included."""
+    d, native, ctx = env
+    pool, n = 20, 100002
+    x = np.random.default_rng(31).uniform(-1, 1, (pool, n, 1)).astype(np.float32)
+    stereo = np.ascontiguousarray(np.repeat(x, 2, axis=2))
+    if which == 'function_path':
+        fir = golden.fir('g48k_k30')
+        table = _table(native, ctx, fir)
+        offs, idx, w = O.fir_to_taps(fir)
+        want = c_oracle.convolve(stereo, offs, idx, w, threads=4)
+    else:
+        kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in golden.manifest['class_taps']['v48k']['kwargs'].items()}
+        table = d.VelvetNoise(**kw)._device_table()
+        taps = golden.class_taps('v48k', 2)
+        env_gains = tuple(golden.manifest['class_taps']['v48k']['envelope'])
+        want = np.stack([O.class_convolve(s, taps, env_gains, 2) for s in stereo])
+    try:
+        for spans in ((1, 2), (1, 5)):
+            ctx.set_variant(FORCE | EXACT_TOO | span_bits(*spans))
+            for mode in (d.MODE_FAST, d.MODE_EXACT):
+                launch = table.describe(pool, n, 1, mode)
+                assert launch.startswith('conv_spec'), launch
+                y = table.convolve_host(x, mode)
+                if mode == d.MODE_EXACT:
+                    assert np.array_equal(y, want), (which, spans)
+                else:
+                    assert np.max(np.abs(y - want)) <= TOL_PEAK * np.max(np.abs(want)), (which, spans)
+    finally:
+        ctx.set_variant(-1)
+    if which == 'function_path':
+        table.close()
+
+
+def test_mono_decorrelate_stage_through_the_specialised_kernel(env, golden, tmp_path, monkeypatch):
+    """VelvetNoise.decorrelate of MONO signals in a batch: fan-out, side-channel encode and width in the per-table exact
+    kernel's store phase - the same bytes as the generic kernels, and the oracle's stage on one signal."""
+    import torch
+    d, native, ctx = env
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in golden.manifest['class_taps']['v48k']['kwargs'].items()}
+    kw['seed'] = 2024
+    table = d.VelvetNoise(**kw)._device_table()
+    monkeypatch.setenv('VND_SPEC_CACHE_DIR', str(tmp_path / 'cache'))
+    monkeypatch.setenv('VND_SPEC_DUMP', str(tmp_path / 'kernel.hip'))
+    pool, n = 24, 200002
+    x = torch.empty((pool, n, 1), dtype=torch.float32, device='cuda').uniform_(-1, 1)
+    s = torch.cuda.current_stream().cuda_stream
+    ws_bytes = native.decorrelate_workspace_bytes(pool, n, 2)
+    outs = {}
+    for label, variant in (('spec', FORCE | EXACT_TOO | span_bits(1, 2)), ('generic', GENERIC)):
+        ctx.set_variant(variant)
+        y = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda')
+        ws = torch.zeros(ws_bytes // 8 + 1, dtype=torch.float64, device='cuda')
+        table.decorrelate_device(x.data_ptr(), y.data_ptr(), pool, n, 1, mode=d.MODE_EXACT, ms_encode=True, width=0.4,
+                                 normalize=True, workspace_ptr=ws.data_ptr(), workspace_bytes=ws_bytes, stream=s)
+        torch.cuda.synchronize()
+        outs[label] = y
+    ctx.set_variant(-1)
+    source = (tmp_path / 'kernel.hip').read_text()
+    assert '#define VS_EPI 1' in source and '#define VS_BC 1' in source and len(list((tmp_path / 'cache').glob('*.co'))) == 1
+    assert torch.equal(outs['spec'], outs['generic'])
+    want = O.decorrelate(x[5, :, 0].cpu().numpy().copy(), sample_rate_hz=48000, seed=2024, width=0.4, mode='MS')
+    assert np.array_equal(outs['spec'][5].cpu().numpy(), want)
 
 
 def test_failed_runtime_build_falls_back_to_the_generic_kernel(env, golden, monkeypatch):

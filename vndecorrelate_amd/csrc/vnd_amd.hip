@@ -410,29 +410,32 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     // a fused epilogue is within scope when it is the pointwise steps alone (no sums, no moments sink), exact mode, stereo:
     // they ride in the exact kernel's store phase (VS_EPI)
     const bool pointwise = epi != nullptr && !epi->normalize && epi->sink == nullptr && mode == VND_MODE_EXACT && C == 2;
-    if ((epi != nullptr && !pointwise) || Cx != C) { p.why = "fused epilogue or fan-out launch"; return p; }
+    // fan-out: a mono input through a stereo table is in scope (one LDS plane, VS_BC); wider fan-outs are not
+    const bool bc = Cx == 1 && C == 2;
+    if ((epi != nullptr && !pointwise) || (Cx != C && !bc)) { p.why = "fused epilogue or fan-out launch"; return p; }
     if (!(mode == VND_MODE_EXACT ? t->spec_exact_ok : t->spec_ok)) { p.why = "table outside the specialised kernel's scope"; return p; }
     // The exact arithmetic of a function-path table (two VALU instructions and 1.5 LDS reads per tap) gains 2 %
     // from specialisation (tools/exact_try.py: 0.298 vs 0.304 ms on the cfg2 pool): not worth a hipRTC build by
     // default - opt in with VND_SPEC_EXACT=1 or variant bit 15; the parity tests do.  A class-path table
     // (VelvetNoise.convolve: every weight +-1, one packed add per tap) gains 29 % (tools/exact_class_try.py:
     // 0.269 vs 0.348 ms): built by default.
-    if (mode == VND_MODE_EXACT && !(t->spec_exact_ok && t->spec_exact_pays) && !(v >= 0 && ((v >> 15) & 1))) {
+    // (not for a mono input fanned out: the generic ordered fan-out kernel is as fast there, tools/fanout_spec_try.py)
+    if (mode == VND_MODE_EXACT && !(t->spec_exact_ok && t->spec_exact_pays && Cx == C) && !(v >= 0 && ((v >> 15) & 1))) {
         static const bool on = [] { const char *e = getenv("VND_SPEC_EXACT"); return e && e[0] == '1'; }();
         if (!on) { p.why = "exact mode specialises on request only"; return p; }
     }
     const bool force = v >= 0 && ((v >> 23) & 1);
     if (spec_disabled_by_env() || (v >= 0 && ((v >> 25) & 1))) { p.why = "disabled"; return p; }
     // access shape: 16 bytes per frame pair (stereo) or 8 per frame, from every stream's first sample
-    const uintptr_t align = C == 2 ? 16 : 8;
-    if (((uintptr_t)x | (uintptr_t)y) & (align - 1)) { p.why = "unaligned base"; return p; }
-    if (batch > 1 && ((uint64_t)n * C * 4) % align != 0) { p.why = "unaligned streams"; return p; }
+    const uintptr_t align = C == 2 ? 16 : 8, align_x = bc ? 8 : align;
+    if (((uintptr_t)y & (align - 1)) || ((uintptr_t)x & (align_x - 1))) { p.why = "unaligned base"; return p; }
+    if (batch > 1 && (((uint64_t)n * C * 4) % align != 0 || ((uint64_t)n * Cx * 4) % align_x != 0)) { p.why = "unaligned streams"; return p; }
     const int rr_hint = (v >= 0 && (v & 31) != 0 && (v & 31) <= 8) ? (v & 31) : 0;
     const int dd_hint = v >= 0 ? ((v >> 26) & 3) : 0;
     // 1536-frame tiles (cfg4's 32-tile streams included: 0.167 vs 0.179 ms) unless a span would be shorter than 12 of them
     for (int attempt = 0; attempt < 2; ++attempt) {
     // (wider signals - a workgroup per channel pair, 8 bytes per frame - measured best with the 1024-frame tiles)
-    if (!spec_pick_config(t->spec_table, (size_t)ctx->lds_limit, rr_hint, dd_hint, &p.cfg, attempt == 1 || C != 2)) { p.why = "halo does not fit the ring"; return p; }
+    if (!spec_pick_config(t->spec_table, (size_t)ctx->lds_limit, rr_hint, dd_hint, &p.cfg, attempt == 1 || C != 2, bc)) { p.why = "halo does not fit the ring"; return p; }
     const int64_t T = p.cfg.tile();
     const int64_t tiles_total = (n + T - 1) / T;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
@@ -473,6 +476,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     if (C != 2 && !getenv("VND_FORCE_NT")) p.cfg.nt_stores = 0;      // a channel pair is a piece of a frame: let L2 merge the pieces
     p.cfg.exact = mode == VND_MODE_EXACT ? 1 : 0;
     p.cfg.epi = pointwise ? 1 : 0;
+    p.cfg.bc = bc ? 1 : 0;
     // exact mode counts VS_LA in steps of RR to 2*RR reads: the LDS queue holds 15, three steps fill it
     if (p.cfg.exact && !getenv("VND_SPEC_LA")) p.cfg.la = 3;
     p.tiles_total = (int)tiles_total; p.tiles_per_span = (int)per_span; p.spans = (int)spans;

@@ -42,15 +42,16 @@ struct SpecConfig {
     int nt_stores = 0; // non-temporal output stores
     int exact = 0;     // VND_MODE_EXACT arithmetic: table order, separately rounded products and sums
     int epi = 0;       // exact mode, stereo: VelvetNoise.decorrelate's pointwise steps in the store phase
+    int bc = 0;        // fan-out of a mono input through a stereo table: one LDS plane
     int tile() const { return 2 * nt * rr; }
     size_t lds_bytes() const
     {
         const size_t pl = (size_t)pp * tile() + 2 * nt;
-        return 2 * pl * 4 + (size_t)2 * (nt / 64) * rr * 2 * 4;
+        return (bc ? 1 : 2) * pl * 4 + (size_t)2 * (nt / 64) * rr * 2 * 4;
     }
     bool operator<(const SpecConfig &o) const
     {
-        return std::tie(nt, rr, pp, dd, la, nt_stores, exact, epi) < std::tie(o.nt, o.rr, o.pp, o.dd, o.la, o.nt_stores, o.exact, o.epi);
+        return std::tie(nt, rr, pp, dd, la, nt_stores, exact, epi, bc) < std::tie(o.nt, o.rr, o.pp, o.dd, o.la, o.nt_stores, o.exact, o.epi, o.bc);
     }
 };
 
@@ -77,7 +78,7 @@ inline int spec_env(const char *name, int fallback)
 }
 
 inline bool spec_pick_config(const SpecTable &t, size_t lds_limit, int rr_hint, int dd_hint, SpecConfig *out,
-                             bool small_tiles = false)
+                             bool small_tiles = false, bool bc = false)
 {
     const int reach = (t.max_index | 1) + 1;          // frames past a pair's first frame that an (aligned) read touches
     // (threads, pairs per lane), best first.  Measured on cfg2 and cfg3 (tools/spec_try.py, several boxes):
@@ -93,6 +94,7 @@ inline bool spec_pick_config(const SpecTable &t, size_t lds_limit, int rr_hint, 
     dd_hint = spec_env("VND_SPEC_DD", dd_hint);
     for (const auto &shape : kShapes) {
         SpecConfig c;
+        c.bc = bc ? 1 : 0;
         c.nt = nt_env > 0 ? nt_env : shape[0];
         c.rr = rr_hint > 0 ? rr_hint : shape[1];
         c.la = spec_env("VND_SPEC_LA", c.la);
@@ -138,8 +140,8 @@ inline std::string spec_prologue(const SpecTable &t, const SpecConfig &c)
     std::string s;
     spec_append(s, "#define VS_NT %d\n#define VS_RR %d\n#define VS_PP %d\n#define VS_DD %d\n#define VS_LA %d\n", c.nt, c.rr,
                 c.pp, c.dd, c.la);
-    spec_append(s, "#define VS_C %d\n#define VS_GROUPS %d\n#define VS_NT_STORES %d\n#define VS_EXACT %d\n#define VS_EPI %d\n", t.C, groups,
-                c.nt_stores, c.exact, c.epi);
+    spec_append(s, "#define VS_C %d\n#define VS_GROUPS %d\n#define VS_NT_STORES %d\n#define VS_EXACT %d\n#define VS_EPI %d\n#define VS_BC %d\n", t.C, groups,
+                c.nt_stores, c.exact, c.epi, c.bc);
     spec_append(s, "#define VS_NT_STORE_AUX %d\n", spec_env("VND_SPEC_STORE_AUX", 2));   // cache policy bits of the non-temporal stores (tuning)
     spec_append(s, "#define VS_LOAD_AUX %d\n", spec_env("VND_SPEC_LOAD_AUX", 2));     // input is read once: non-temporal loads (+1-2 % on cfg2)
     {   // resident workgroups per CU (LDS-bound, at most 32 waves) -> waves per SIMD the register budget must allow
@@ -235,7 +237,7 @@ inline std::string spec_prologue(const SpecTable &t, const SpecConfig &c)
                 ++pos[st];
                 any = true;
                 for (int j = 0; j < c.rr; ++j) {
-                    const int plane = st >> 1, at = off + 2 * c.nt * j;
+                    const int plane = c.bc ? 0 : (st >> 1), at = off + 2 * c.nt * j;      // fan-out: both channels read the one plane
                     Read *hit = nullptr;
                     for (Read &r : rd) if (r.plane == plane && r.off == at) { hit = &r; break; }
                     if (!hit) { rd.push_back(Read{plane, at, {}, {}, {}}); hit = &rd.back(); }
