@@ -403,6 +403,38 @@ def test_mono_decorrelate_stage_through_the_specialised_kernel(env, golden, tmp_
     assert np.array_equal(outs['spec'][5].cpu().numpy(), want)
 
 
+@pytest.mark.parametrize('mono', [False, True])
+def test_fast_decorrelate_stage_through_the_specialised_kernel(env, golden, tmp_path, monkeypatch, mono):
+    """The throughput mode's stage (reference-order RMS sums, the default normaliser flag): side-channel encode and width
+    in the per-table FAST kernel's store phase - the tile's last frame is completed one tile later, so its input frame
+    is carried along with its even part.  Within the fast mode's tolerance of the oracle's stage; span seams included."""
+    import torch
+    d, native, ctx = env
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in golden.manifest['class_taps']['v48k']['kwargs'].items()}
+    kw['seed'] = 3000 + int(mono)
+    table = d.VelvetNoise(**kw)._device_table()
+    monkeypatch.setenv('VND_SPEC_CACHE_DIR', str(tmp_path / 'cache'))
+    monkeypatch.setenv('VND_SPEC_DUMP', str(tmp_path / 'kernel.hip'))
+    pool, n, cx = 24, 200002, (1 if mono else 2)
+    x = torch.empty((pool, n, cx), dtype=torch.float32, device='cuda').uniform_(-1, 1)
+    s = torch.cuda.current_stream().cuda_stream
+    ws_bytes = native.decorrelate_workspace_bytes(pool, n, 2)
+    ctx.set_variant(FORCE | span_bits(1, 3))
+    y = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda')
+    ws = torch.zeros(ws_bytes // 8 + 1, dtype=torch.float64, device='cuda')
+    table.decorrelate_device(x.data_ptr(), y.data_ptr(), pool, n, cx, mode=d.MODE_FAST, ms_encode=True, width=0.6,
+                             normalize=2, workspace_ptr=ws.data_ptr(), workspace_bytes=ws_bytes, stream=s)
+    torch.cuda.synchronize()
+    ctx.set_variant(-1)
+    source = (tmp_path / 'kernel.hip').read_text()
+    assert '#define VS_EPI 1' in source and '#define VS_EXACT 0' in source and f'#define VS_BC {int(mono)}' in source
+    for b in (0, 11, 23):
+        sig = x[b].cpu().numpy()
+        want = O.decorrelate((sig[:, 0] if mono else sig).copy(), sample_rate_hz=48000, seed=kw['seed'], width=0.6, mode='MS')
+        got = y[b].cpu().numpy()
+        assert np.max(np.abs(got - want)) <= 3e-6 * np.max(np.abs(want)), (b, mono)
+
+
 def test_failed_runtime_build_falls_back_to_the_generic_kernel(env, golden, monkeypatch):
     """If hipRTC cannot build the per-table kernel (here: an injected #error), the launch silently takes the
     generic HIP kernel - never a CPU path - the result is still right, and vnd_describe_launch says so."""

@@ -407,9 +407,9 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     SpecPlan p;
     const int v = ctx->variant;
     if (mode != VND_MODE_FAST && mode != VND_MODE_EXACT) { p.why = "neither the fast nor the exact mode"; return p; }
-    // a fused epilogue is within scope when it is the pointwise steps alone (no sums, no moments sink), exact mode, stereo:
-    // they ride in the exact kernel's store phase (VS_EPI)
-    const bool pointwise = epi != nullptr && !epi->normalize && epi->sink == nullptr && mode == VND_MODE_EXACT && C == 2;
+    // a fused epilogue is within scope when it is the pointwise steps alone (no sums, no moments sink) on a stereo output:
+    // they ride in the per-table kernels' store phase (VS_EPI)
+    const bool pointwise = epi != nullptr && !epi->normalize && epi->sink == nullptr && C == 2;
     // fan-out: a mono input through a stereo table is in scope (one LDS plane, VS_BC); wider fan-outs are not
     const bool bc = Cx == 1 && C == 2;
     if ((epi != nullptr && !pointwise) || (Cx != C && !bc)) { p.why = "fused epilogue or fan-out launch"; return p; }
