@@ -278,6 +278,38 @@ def next_rows(torch, vnd, _native) -> dict:
         out['f1_decorrelate_exact'] = rec
     except Exception as exc:
         out['f1_decorrelate_exact'] = {'error': repr(exc)}
+    # fan-out: mono in, stereo out (decorrelation.py:431-432) on the cfg2 shape, device resident, throughput mode
+    try:
+        from vndecorrelate_amd.taps import function_path_arrays
+        ctx = _native.default_context()
+        arr = function_path_arrays(vnd.generate_velvet_noise(duration_seconds=FIR_SECONDS, num_impulses=TAPS, num_outs=2,
+                                                             sample_rate_hz=SAMPLE_RATE, seed=1))
+        table = _native.TapTable.create(ctx, arr.tap_offsets, arr.tap_index, arr.tap_weight)
+        pool = 128
+        x = torch.empty((pool, n, 1), dtype=torch.float32, device='cuda').uniform_(-1, 1)
+        y = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda')
+        st = torch.cuda.current_stream().cuda_stream
+
+        def run():
+            table.convolve_device(x.data_ptr(), y.data_ptr(), pool, n, 1, vnd.MODE_FAST, st)
+        for _ in range(20):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(200):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 200
+        out['mono_to_stereo_fast'] = {'kernel_ms': round(ms, 4), 'output_Msamples_s': round(pool * n * 2 / ms / 1e3, 1),
+                                      'achieved_GBs_12B_per_frame': round(12e-6 * pool * n / ms, 1),
+                                      'launch': table.describe(pool, n, 1, vnd.MODE_FAST),
+                                      'what': '128 x 10 s mono signals in, stereo out, one launch'}
+        table.close()
+        del x, y
+    except Exception as exc:
+        out['mono_to_stereo_fast'] = {'error': repr(exc)}
     # f3: the optimiser's candidate scan, host to host
     try:
         import vndecorrelate_amd.optimization as opt
