@@ -86,6 +86,70 @@ def test_class_path_tables(ctx, tab, n, seed, pairs):
     _check(ctx, arr, x, want, pairs)
 
 
+# ---- the per-table (hipRTC) kernels on random tables: each example compiles its kernels (~2-4 s), so few examples --------
+_SPEC_SET = settings(max_examples=min(_HUNT, 60) or 12, deadline=None, derandomize=not _HUNT, database=None,
+                     suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+_FORCE_SPEC = (1 << 23) | (1 << 15) | (1 << 20) | (3 << 28)      # specialise whatever the size, exact mode too, spans of >= 1 tile, 3 rounds
+
+
+def _spec_check(ctx, arr, x, want, in_scope):
+    """Through the per-table kernels when the table is within their scope (describe says which kernel runs);
+    fast mode within tolerance, exact mode bit for bit - also for a mono input fanned out to a stereo table."""
+    from vndecorrelate_amd import _native
+    table = _native.TapTable.create(ctx, arr.tap_offsets, arr.tap_index, arr.tap_weight, **arr.kwargs())
+    batch, n, cx = x.shape
+    peak = max(float(np.max(np.abs(want))) if want.size else 0.0, 1e-30)
+    floor = 2.0 ** -24 * _term_scale(arr, x)
+    try:
+        ctx.set_variant(_FORCE_SPEC)
+        for mode in (2, 0):
+            launch = table.describe(batch, n, cx, mode)
+            aligned = batch == 1 or (n * cx * 4) % (16 if cx == 2 else 8) == 0
+            if in_scope is True and aligned:
+                assert launch.startswith('conv_spec'), launch
+            y = table.convolve_host(x, mode)
+            if mode == 0:
+                assert np.array_equal(y, want), launch
+            else:
+                assert np.max(np.abs(y.astype(np.float64) - want)) <= 1e-6 * peak + floor + 1e-30, launch
+    finally:
+        ctx.set_variant(-1)
+        table.close()
+
+
+@_SPEC_SET
+@given(tab=class_table(), n=st.integers(1, 5000), batch=st.integers(1, 3), seed=st.integers(0, 2**31 - 1), mono=st.booleans())
+def test_per_table_kernels_on_random_class_tables(ctx, tab, n, batch, seed, mono):
+    chans, env = tab
+    if len(chans) != 2:
+        chans = (list(chans) + [chans[0]])[:2]
+    channels = 2
+    arr = class_path_arrays(chans, env, env != (1.0,))
+    every_filtered = all(c is not None for c in chans) and len(arr.tap_index) > 0
+    # the exact per-table kernel leaves a table with an empty segment to the generic one (it still adds +0)
+    cx = 1 if mono else channels
+    x = np.random.default_rng(seed).uniform(-1, 1, (batch, n, cx)).astype(np.float32)
+    full = np.ascontiguousarray(np.repeat(x, channels // cx, axis=2))
+    want = c_oracle.convolve(full, arr.tap_offsets, arr.tap_index, arr.tap_weight, seg_off=arr.seg_offsets,
+                             seg_end=arr.seg_end, seg_gain=arr.seg_gain, chan_flags=arr.chan_flags,
+                             apply_gain=arr.apply_gain)
+    _spec_check(ctx, arr, x, want, in_scope=False if not every_filtered else None)
+
+
+@_SPEC_SET
+@given(fir=sparse_fir(), n=st.integers(1, 5000), batch=st.integers(1, 3), seed=st.integers(0, 2**31 - 1), mono=st.booleans())
+def test_per_table_kernels_on_random_function_tables(ctx, fir, n, batch, seed, mono):
+    if fir.shape[1] % 2:
+        fir = np.concatenate([fir, fir[:, :1]], axis=1)             # even channel counts are the kernels' scope
+    channels = fir.shape[1]
+    arr = function_path_arrays(fir)
+    cx = 1 if (mono and channels == 2) else channels
+    x = np.random.default_rng(seed).uniform(-1, 1, (batch, n, cx)).astype(np.float32)
+    full = np.ascontiguousarray(np.repeat(x, channels // cx, axis=2))
+    want = c_oracle.convolve(full, arr.tap_offsets, arr.tap_index, arr.tap_weight)
+    _spec_check(ctx, arr, x, want, in_scope=len(arr.tap_index) > 0)
+
+
 # ---- the rows beyond the plain convolution: whole stage, fan-out, Haas -----------------------------
 def _numpy_stage(x, y, ms_encode, width, normalize):
     """The reference's epilogue (decorrelation.py:433-440) with its own NumPy helpers."""
