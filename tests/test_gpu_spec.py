@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 TOL_PEAK = 1e-6
 FORCE = 1 << 23            # specialise however little work there is
 GENERIC = 1 << 25          # never specialise
-EXACT_TOO = 1 << 15        # specialise VND_MODE_EXACT as well (off by default: 2 % gain)
+EXACT_TOO = 1 << 15        # specialise VND_MODE_EXACT whatever VND_SPEC_EXACT says (it is on by default since the shifted plane copies)
 
 
 def span_bits(min_span, rounds):
@@ -46,8 +46,10 @@ def test_headline_workload_takes_the_specialised_kernel(env, golden):
     table = _table(native, ctx, golden.fir('g48k_k30'))
     text = table.describe(128, 480000, 2, d.MODE_FAST)
     assert text.startswith('conv_spec'), text            # a silent fallback must not pass for the real thing
-    assert table.describe(128, 480000, 2, d.MODE_EXACT).startswith('conv_ordered')
+    exact = table.describe(128, 480000, 2, d.MODE_EXACT)
+    assert exact.startswith('conv_spec_exact') and 'tile=1024' in exact, exact       # 256 threads x 2 pairs with the shifted copies
     ctx.set_variant(GENERIC)
+    assert table.describe(128, 480000, 2, d.MODE_EXACT).startswith('conv_ordered')
     assert table.describe(128, 480000, 2, d.MODE_FAST).startswith('conv_fast')
     ctx.set_variant(-1)
     assert table.describe(1, 5000, 2, d.MODE_FAST).startswith('conv_fast')       # too little work for persistent workgroups
@@ -292,9 +294,9 @@ def test_class_path_exact_takes_the_specialised_kernel_by_default(env, golden):
     taps = golden.class_taps('v48k', 2)
     env_gains = tuple(golden.manifest['class_taps']['v48k']['envelope'])
     assert np.array_equal(y[5].cpu().numpy(), O.class_convolve(x[5].cpu().numpy(), taps, env_gains, 2))
-    # a function-path table (arbitrary weights: multiply + add per tap, 2 % to gain) still specialises on request only
+    # so does a function-path table (arbitrary weights: multiply + add per tap) since the shifted plane copies
     fn = _table(native, ctx, golden.fir('g48k_k30'))
-    assert fn.describe(pool, n, 2, d.MODE_EXACT).startswith('conv_ordered')
+    assert fn.describe(pool, n, 2, d.MODE_EXACT).startswith('conv_spec_exact')
     fn.close()
 
 

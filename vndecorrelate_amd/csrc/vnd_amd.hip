@@ -95,7 +95,6 @@ struct vnd_taps {
     SpecTable spec_table;          // effective weights (segment gain folded in)
     bool spec_ok = false;          // the table is within the specialised kernel's scope
     bool spec_exact_ok = false;    // ... also in VND_MODE_EXACT (no empty segment)
-    bool spec_exact_pays = false;  // ... and worth a build there: every weight +-1 (class path: adds only, +29 % on cfg2)
     std::mutex spec_mutex;
     std::map<SpecConfig, std::unique_ptr<SpecModule>> spec_modules;
 };
@@ -414,15 +413,12 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     const bool bc = Cx == 1 && C == 2;
     if ((epi != nullptr && !pointwise) || (Cx != C && !bc)) { p.why = "fused epilogue or fan-out launch"; return p; }
     if (!(mode == VND_MODE_EXACT ? t->spec_exact_ok : t->spec_ok)) { p.why = "table outside the specialised kernel's scope"; return p; }
-    // The exact arithmetic of a function-path table (two VALU instructions and 1.5 LDS reads per tap) gains 2 %
-    // from specialisation (tools/exact_try.py: 0.298 vs 0.304 ms on the cfg2 pool): not worth a hipRTC build by
-    // default - opt in with VND_SPEC_EXACT=1 or variant bit 15; the parity tests do.  A class-path table
-    // (VelvetNoise.convolve: every weight +-1, one packed add per tap) gains 29 % (tools/exact_class_try.py:
-    // 0.269 vs 0.348 ms): built by default.
-    // (not for a mono input fanned out: the generic ordered fan-out kernel is as fast there, tools/fanout_spec_try.py)
-    if (mode == VND_MODE_EXACT && !(t->spec_exact_ok && t->spec_exact_pays && Cx == C) && !(v >= 0 && ((v >> 15) & 1))) {
-        static const bool on = [] { const char *e = getenv("VND_SPEC_EXACT"); return e && e[0] == '1'; }();
-        if (!on) { p.why = "exact mode specialises on request only"; return p; }
+    // VND_MODE_EXACT specialises by default as well: with the shifted plane copies (odd offsets as aligned pairs) the per-table
+    // kernel is ahead of the generic ordered one by 24 % on a function-path table, 37 % on a class-path one and 23-50 % on a mono
+    // input fanned out (cfg2 pool; tools/exact_geometry_try.py, tools/fanout_spec_try.py).  VND_SPEC_EXACT=0 keeps the generic kernel.
+    if (mode == VND_MODE_EXACT && !(v >= 0 && ((v >> 15) & 1))) {
+        static const bool off = [] { const char *e = getenv("VND_SPEC_EXACT"); return e && e[0] == '0'; }();
+        if (off) { p.why = "exact mode specialisation switched off"; return p; }
     }
     const bool force = v >= 0 && ((v >> 23) & 1);
     if (spec_disabled_by_env() || (v >= 0 && ((v >> 25) & 1))) { p.why = "disabled"; return p; }
@@ -435,7 +431,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     // 1536-frame tiles (cfg4's 32-tile streams included: 0.167 vs 0.179 ms) unless a span would be shorter than 12 of them
     for (int attempt = 0; attempt < 2; ++attempt) {
     // (wider signals - a workgroup per channel pair, 8 bytes per frame - measured best with the 1024-frame tiles)
-    if (!spec_pick_config(t->spec_table, (size_t)ctx->lds_limit, rr_hint, dd_hint, &p.cfg, attempt == 1 || C != 2, bc)) { p.why = "halo does not fit the ring"; return p; }
+    if (!spec_pick_config(t->spec_table, (size_t)ctx->lds_limit, rr_hint, dd_hint, &p.cfg, attempt == 1 || C != 2, bc, mode == VND_MODE_EXACT)) { p.why = "halo does not fit the ring"; return p; }
     const int64_t T = p.cfg.tile();
     const int64_t tiles_total = (n + T - 1) / T;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
@@ -794,8 +790,6 @@ vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, 
         t->spec_table.has_seg = has_seg;
         t->spec_table.apply_gain = t->apply_gain != 0;
         t->spec_exact_ok = t->spec_ok;
-        t->spec_exact_pays = true;
-        for (int32_t k = 0; k < total; ++k) t->spec_exact_pays &= (tap_weight[k] == 1.0f || tap_weight[k] == -1.0f);
         if (has_seg) {
             t->spec_table.seg_off = t->seg_off; t->spec_table.seg_end = t->seg_end; t->spec_table.seg_gain = t->seg_gain;
             for (int c = 0; c < C; ++c) {
@@ -1178,7 +1172,7 @@ vnd_status vnd_spec_kernel_source(int32_t C, const int32_t *tap_offsets, const i
     t.w.assign(tap_weight, tap_weight + total);
     t.w_raw = t.w;
     SpecConfig cfg;
-    if (!spec_pick_config(t, 160 * 1024, 0, 0, &cfg)) return fail(VND_ERR_UNSUPPORTED, "halo does not fit the LDS ring");
+    if (!spec_pick_config(t, 160 * 1024, 0, 0, &cfg, false, false, mode == VND_MODE_EXACT)) return fail(VND_ERR_UNSUPPORTED, "halo does not fit the LDS ring");
     cfg.exact = mode == VND_MODE_EXACT ? 1 : 0;
     const std::string src = spec_prologue(t, cfg) + kSpecKernelSource;
     *bytes = (int64_t)src.size() + 1;

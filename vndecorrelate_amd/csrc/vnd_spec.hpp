@@ -43,15 +43,16 @@ struct SpecConfig {
     int exact = 0;     // VND_MODE_EXACT arithmetic: table order, separately rounded products and sums
     int epi = 0;       // exact mode, stereo: VelvetNoise.decorrelate's pointwise steps in the store phase
     int bc = 0;        // fan-out of a mono input through a stereo table: one LDS plane
+    int shift = 0;     // exact mode: a second copy of every plane, one frame ahead, so that odd offsets are aligned pairs
     int tile() const { return 2 * nt * rr; }
     size_t lds_bytes() const
     {
-        const size_t pl = (size_t)pp * tile() + 2 * nt;
-        return (bc ? 1 : 2) * pl * 4 + (size_t)2 * (nt / 64) * rr * 2 * 4;
+        const size_t pl = (size_t)pp * tile() + 2 * nt + (shift ? 2 : 0);
+        return (bc ? 1 : 2) * (shift ? 2 : 1) * pl * 4 + (size_t)2 * (nt / 64) * rr * 2 * 4;
     }
     bool operator<(const SpecConfig &o) const
     {
-        return std::tie(nt, rr, pp, dd, la, nt_stores, exact, epi, bc) < std::tie(o.nt, o.rr, o.pp, o.dd, o.la, o.nt_stores, o.exact, o.epi, o.bc);
+        return std::tie(nt, rr, pp, dd, la, nt_stores, exact, epi, bc, shift) < std::tie(o.nt, o.rr, o.pp, o.dd, o.la, o.nt_stores, o.exact, o.epi, o.bc, o.shift);
     }
 };
 
@@ -78,7 +79,7 @@ inline int spec_env(const char *name, int fallback)
 }
 
 inline bool spec_pick_config(const SpecTable &t, size_t lds_limit, int rr_hint, int dd_hint, SpecConfig *out,
-                             bool small_tiles = false, bool bc = false)
+                             bool small_tiles = false, bool bc = false, bool shift_wanted = false)
 {
     const int reach = (t.max_index | 1) + 1;          // frames past a pair's first frame that an (aligned) read touches
     // (threads, pairs per lane), best first.  Measured on cfg2 and cfg3 (tools/spec_try.py, several boxes):
@@ -88,7 +89,10 @@ inline bool spec_pick_config(const SpecTable &t, size_t lds_limit, int rr_hint, 
     // better with 1024-frame tiles: small_tiles starts the list there.
     static const int kLong[][2] = {{192, 4}, {256, 4}, {128, 4}, {256, 2}, {128, 2}, {256, 1}};
     static const int kShort[][2] = {{128, 4}, {256, 2}, {128, 2}, {256, 1}, {192, 4}, {256, 4}};
-    const int (&kShapes)[6][2] = small_tiles ? kShort : kLong;
+    // exact mode with the shifted plane copies (tools/exact_geometry_try.py, cfg2): 256 threads x 2 pairs (1024-frame tiles,
+    // 4 ring slots, 74 KB: two workgroups = 8 waves per CU) ahead of 192 x 4 by 5-11 %, everything else behind
+    static const int kExact[][2] = {{256, 2}, {192, 4}, {320, 2}, {128, 4}, {128, 2}, {256, 1}};
+    const int (&kShapes)[6][2] = shift_wanted ? kExact : (small_tiles ? kShort : kLong);
     const int nt_env = spec_env("VND_SPEC_NT", 0);
     rr_hint = spec_env("VND_SPEC_RR", rr_hint);
     dd_hint = spec_env("VND_SPEC_DD", dd_hint);
@@ -103,7 +107,13 @@ inline bool spec_pick_config(const SpecTable &t, size_t lds_limit, int rr_hint, 
         c.pp = (T + reach + T - 1) / T + 1;            // slots covering tile + halo, plus the one being refilled
         if (c.pp < 2) c.pp = 2;
         c.dd = std::min(dd_hint > 0 ? dd_hint : (c.pp >= 4 ? 2 : 1), 3);      // measured: 2 ahead only pays with 4+ slots
-        if (c.pp <= 8 && c.lds_bytes() <= std::min<size_t>(lds_limit, 64 * 1024) &&
+        // exact mode: shifted copies of the planes (odd offsets become aligned pairs: +22 % on class-path tables, +7 % on
+        // function-path ones at cfg2) when two workgroups still fit a CU
+        c.shift = (shift_wanted && c.rr >= 2 && spec_env("VND_SPEC_SHIFT", 1)) ? 1 : 0;
+        if (c.shift && c.lds_bytes() > 81 * 1024) c.shift = 0;
+        // ... and those two still hold six waves (128-thread workgroups measured 23 % slower with the copies than without)
+        if (c.shift && ((size_t)(160 * 1024) / c.lds_bytes()) * (size_t)(c.nt / 64) < 6) c.shift = 0;
+        if (c.pp <= 8 && c.lds_bytes() <= std::min<size_t>(lds_limit, (c.shift ? 81 : 64) * 1024) &&
             2 * ((size_t)c.pp * T + 2 * c.nt) * 4 < 65536) {
             *out = c;
             return true;
@@ -140,8 +150,8 @@ inline std::string spec_prologue(const SpecTable &t, const SpecConfig &c)
     std::string s;
     spec_append(s, "#define VS_NT %d\n#define VS_RR %d\n#define VS_PP %d\n#define VS_DD %d\n#define VS_LA %d\n", c.nt, c.rr,
                 c.pp, c.dd, c.la);
-    spec_append(s, "#define VS_C %d\n#define VS_GROUPS %d\n#define VS_NT_STORES %d\n#define VS_EXACT %d\n#define VS_EPI %d\n#define VS_BC %d\n", t.C, groups,
-                c.nt_stores, c.exact, c.epi, c.bc);
+    spec_append(s, "#define VS_C %d\n#define VS_GROUPS %d\n#define VS_NT_STORES %d\n#define VS_EXACT %d\n#define VS_EPI %d\n#define VS_BC %d\n#define VS_SHIFT %d\n", t.C, groups,
+                c.nt_stores, c.exact, c.epi, c.bc, c.shift);
     spec_append(s, "#define VS_NT_STORE_AUX %d\n", spec_env("VND_SPEC_STORE_AUX", 2));   // cache policy bits of the non-temporal stores (tuning)
     spec_append(s, "#define VS_LOAD_AUX %d\n", spec_env("VND_SPEC_LOAD_AUX", 2));     // input is read once: non-temporal loads (+1-2 % on cfg2)
     {   // resident workgroups per CU (LDS-bound, at most 32 waves) -> waves per SIMD the register budget must allow
