@@ -439,9 +439,14 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     const int64_t per_cu = std::min<int64_t>(std::min<int64_t>(16, 2048 / p.cfg.nt), (int64_t)(160 * 1024) / (int64_t)p.cfg.lds_bytes());
     const int64_t resident = (int64_t)cus * std::max<int64_t>(per_cu, 1);
     const int64_t units = batch * (C / 2);                     // (stream, channel pair)
-    // a workgroup needs a span long enough to amortise filling its ring
-    const int64_t min_span = (v >= 0 && ((v >> 20) & 7)) ? ((v >> 20) & 7) : 8;
-    if (!force && units * tiles_total < resident * min_span) { p.why = "too little work for persistent workgroups"; return p; }
+    // a workgroup needs a span long enough to amortise filling its ring: 8 tiles when there are 16 and more per resident
+    // slot; with less, shorter spans (down to 2 tiles) so that the chip still fills - a lone 60 s stream then runs 1.1x
+    // (fast) to 1.75x (exact, 128 taps) faster than through the generic kernels, tools/single_stream_try.py - and below
+    // about two million frames per channel pair the generic kernels (many small workgroups) stay ahead
+    int64_t min_span = (v >= 0 && ((v >> 20) & 7)) ? ((v >> 20) & 7) : 8;
+    if (!(v >= 0 && ((v >> 20) & 7)))
+        min_span = std::min<int64_t>(8, std::max<int64_t>(2, units * tiles_total / (2 * resident)));
+    if (!force && units * n < 2000000) { p.why = "too little work for persistent workgroups"; return p; }
     // Spans per stream: the workgroups are equally long, so the grid should fill the resident slots
     // a whole number of times ("rounds") - 1.5 rounds cost as much as 2.  Fewest spans (longest
     // rings) whose last round is at least 95 % full, else the fullest.
