@@ -437,6 +437,41 @@ def test_fast_decorrelate_stage_through_the_specialised_kernel(env, golden, tmp_
         assert np.max(np.abs(got - want)) <= 3e-6 * np.max(np.abs(want)), (b, mono)
 
 
+def test_small_launches_never_trigger_a_build(env, golden, tmp_path, monkeypatch):
+    """A launch too small to be worth a hipRTC build (1.5-5 s) takes the per-table kernel only when its code object already
+    exists - built by a larger launch of the same geometry, or found in the disk cache - and the generic kernel otherwise."""
+    import torch
+    d, native, ctx = env
+    monkeypatch.setenv('VND_SPEC_CACHE_DIR', str(tmp_path / 'cache'))
+    fir = d.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=77)
+    table = _table(native, ctx, fir)
+    pool, n = 8, 480000                                                   # 3.8 M frames: in scope, but below the build threshold
+    x = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1)
+    y, y2 = torch.empty_like(x), torch.empty_like(x)
+    s = torch.cuda.current_stream().cuda_stream
+    ctx.set_variant(-1)
+    for mode, generic_name in ((d.MODE_EXACT, 'conv_ordered'), (d.MODE_FAST, 'conv_fast')):
+        assert table.describe(pool, n, 2, mode).startswith(generic_name)
+        table.convolve_device(x.data_ptr(), y.data_ptr(), pool, n, 2, mode=mode, stream=s)
+        torch.cuda.synchronize()
+        assert not list((tmp_path / 'cache').glob('*.co')) or mode == d.MODE_FAST          # nothing was built for it
+        ctx.set_variant(FORCE)                                            # what a larger launch would have done: build it
+        table.convolve_device(x.data_ptr(), y2.data_ptr(), pool, n, 2, mode=mode, stream=s)
+        torch.cuda.synchronize()
+        ctx.set_variant(-1)
+        assert table.describe(pool, n, 2, mode).startswith('conv_spec')  # now the small launch takes it
+        table.convolve_device(x.data_ptr(), y2.data_ptr(), pool, n, 2, mode=mode, stream=s)
+        torch.cuda.synchronize()
+        if mode == d.MODE_EXACT:
+            assert torch.equal(y, y2)
+        else:
+            assert float((y - y2).abs().max()) <= TOL_PEAK * float(y.abs().max())
+    # a second table object with the same taps finds the code objects in the disk cache
+    again = _table(native, ctx, fir)
+    assert again.describe(pool, n, 2, d.MODE_EXACT).startswith('conv_spec_exact')
+    table.close(); again.close()
+
+
 def test_failed_runtime_build_falls_back_to_the_generic_kernel(env, golden, monkeypatch):
     """If hipRTC cannot build the per-table kernel (here: an injected #error), the launch silently takes the
     generic HIP kernel - never a CPU path - the result is still right, and vnd_describe_launch says so."""

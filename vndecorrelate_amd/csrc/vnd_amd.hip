@@ -377,6 +377,7 @@ static vnd_status check_shape(const vnd_ctx *ctx, const vnd_taps *t, int64_t bat
 // ------------------------------------------------------------------------------
 struct SpecPlan {
     bool use = false;
+    bool eager = true;              // false: too small a launch to build the kernel for - taken only if its code object exists
     SpecConfig cfg;
     int tiles_total = 0, tiles_per_span = 0, spans = 0;
     uint32_t nblocks = 0, units = 0;
@@ -447,6 +448,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     if (!(v >= 0 && ((v >> 20) & 7)))
         min_span = std::min<int64_t>(8, std::max<int64_t>(2, units * tiles_total / (2 * resident)));
     if (!force && units * n < 2000000) { p.why = "too little work for persistent workgroups"; return p; }
+    p.eager = force || units * tiles_total >= resident * 8;      // enough work to be worth building the kernel for
     // Spans per stream: the workgroups are equally long, so the grid should fill the resident slots
     // a whole number of times ("rounds") - 1.5 rounds cost as much as 2.  Fewest spans (longest
     // rings) whose last round is at least 95 % full, else the fullest.
@@ -492,24 +494,28 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
 
 // compiled on first use, once per (table, geometry); a failed build is remembered and the generic
 // kernel takes over (the reason stays readable through vnd_describe_launch)
-static SpecModule *spec_module(vnd_ctx *ctx, const vnd_taps *t_, const SpecConfig &cfg)
+// cache_only: a launch too small to be worth a 1.5-5 s build takes the per-table kernel only when its code object is
+// already there - in this table's map or in the disk cache (looked up once) - and the generic kernel otherwise
+static SpecModule *spec_module(vnd_ctx *ctx, const vnd_taps *t_, const SpecConfig &cfg, bool cache_only = false)
 {
     vnd_taps *t = const_cast<vnd_taps *>(t_);
     std::lock_guard<std::mutex> g(t->spec_mutex);
     auto it = t->spec_modules.find(cfg);
     if (it == t->spec_modules.end()) {
         std::unique_ptr<SpecModule> m(new SpecModule);
-        spec_compile(t->spec_table, cfg, ctx->device, ctx->lds_limit, m.get());
+        spec_compile(t->spec_table, cfg, ctx->device, ctx->lds_limit, m.get(), cache_only);
         it = t->spec_modules.emplace(cfg, std::move(m)).first;
+    } else if (it->second->pending && !cache_only) {
+        spec_compile(t->spec_table, cfg, ctx->device, ctx->lds_limit, it->second.get(), false);
     }
-    return it->second.get();
+    return it->second->pending ? nullptr : it->second.get();
 }
 
 static vnd_status launch_spec(vnd_ctx *ctx, const vnd_taps *t, const SpecPlan &p, const float *x, float *y, int64_t n,
                               hipStream_t stream, bool *launched, const EpiFuse *epi = nullptr)
 {
     *launched = false;
-    SpecModule *m = spec_module(ctx, t, p.cfg);
+    SpecModule *m = spec_module(ctx, t, p.cfg, !p.eager);
     if (!m || m->failed) return VND_OK;                      // generic kernel instead
     SpecArgs a{};
     a.x = x; a.y = y; a.n = n;
@@ -1205,7 +1211,7 @@ static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64
     const SpecPlan sp = make_spec_plan(ctx, t, nullptr, nullptr, batch, n, C, Cx, mode, nullptr);
     if (sp.use) {
         DeviceScope on(ctx->device);
-        SpecModule *m = spec_module(ctx, t, sp.cfg);
+        SpecModule *m = spec_module(ctx, t, sp.cfg, !sp.eager);
         if (m && !m->failed) {
             snprintf(text, (size_t)len,
                      "conv_spec%s (hipRTC, per table) pairs_per_lane=%d tile=%d ring_slots=%d prefetch=%d reads_ahead=%d "

@@ -347,6 +347,7 @@ struct SpecModule {
     hipModule_t module = nullptr;
     hipFunction_t fn = nullptr;
     bool failed = false;
+    bool pending = false;        // looked for in the disk cache only (a small launch never triggers a build): not there
     std::string log;
 };
 
@@ -406,9 +407,10 @@ inline void spec_cache_store(const std::string &dir, const std::string &path, co
     if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());     // rename is atomic: readers never see half a file
 }
 
-inline bool spec_compile(const SpecTable &t, const SpecConfig &cfg, int device, int lds_limit, SpecModule *m)
+inline bool spec_compile(const SpecTable &t, const SpecConfig &cfg, int device, int lds_limit, SpecModule *m, bool cache_only = false)
 {
     m->cfg = cfg;
+    m->pending = false;
     std::string src = spec_prologue(t, cfg);
     src += kSpecKernelSource;
     if (getenv("VND_SPEC_BREAK")) src += "\n#error VND_SPEC_BREAK: injected build failure (fallback test)\n";
@@ -420,6 +422,7 @@ inline bool spec_compile(const SpecTable &t, const SpecConfig &cfg, int device, 
     const std::string dir = spec_cache_dir();
     const std::string path = dir.empty() ? std::string() : dir + "/" + spec_cache_key(src, opts, 4) + ".co";
     if (path.empty() || !spec_cache_load(path, &code)) {
+        if (cache_only) { m->pending = true; return false; }
         hiprtcProgram prog = nullptr;
         if (hiprtcCreateProgram(&prog, src.c_str(), "vnd_spec_kernel.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
             m->failed = true; m->log = "hiprtcCreateProgram failed";
