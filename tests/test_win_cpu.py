@@ -1,0 +1,182 @@
+"""CPU tier: the WINDOW form of the per-table kernel (vnd_win.hpp).  No GPU here:
+* the generated tap function vw_taps() - one lane's whole tap sum, with its LDS addressing (ring bases,
+  chunk planes, mirror) - is compiled for the HOST and run on an LDS image laid out by this file from the
+  documented formulas, against the plain tap sum (the oracle's definition, decorrelation.py:649-658);
+* the whole translation unit is cross-compiled for gfx950 and its ISA checked for what the design rests on."""
+import ctypes
+import pathlib
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+REPO = pathlib.Path(__file__).resolve().parents[1]
+HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+CLANG = '/opt/rocm/lib/llvm/bin/clang++'
+
+
+@pytest.fixture(scope='module')
+def native():
+    import __graft_entry__ as entry
+    entry.build()
+    from vndecorrelate_amd import _native
+    _native.load_library()
+    return _native
+
+
+def _table(fir):
+    from vndecorrelate_amd.taps import function_path_arrays
+    a = function_path_arrays(fir)
+    return a.tap_offsets, a.tap_index, a.tap_weight
+
+
+def _macro(src, name):
+    return int(re.search(rf'#define {name} (\d+)', src).group(1))
+
+
+HOST_SHIM = r'''
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef char vw_lchar;
+#define __device__
+#define __forceinline__ inline
+#define VW_RD(base, imm) (*(const volatile v4f *)((base) + (imm)))
+#define VW_FMA(x, w, a) __builtin_elementwise_fma((x), v2f{(w), (w)}, (a))
+#define VW_MUL(x, w) ((x) * v2f{(w), (w)})
+#define VW_SB
+%(defines)s
+%(function)s
+static unsigned wrap(unsigned a) { const unsigned b = a - (unsigned)VW_R; return a < b ? a : b; }
+extern "C" void run_lane(char *lds, unsigned pl, float *o0, float *o1)
+{
+    vw_lchar *b[2][VW_NB];
+    for (int k = 0; k < VW_NB; ++k) { b[0][k] = lds + wrap(pl + (unsigned)(k * VW_G)) * 16u; b[1][k] = b[0][k] + (VW_M / 4) * VW_PLANE; }
+    float a0[VW_M], a1[VW_M];
+    vw_taps(b, a0, a1);
+    for (int j = 0; j < VW_M; ++j) { o0[j] = a0[j]; o1[j] = a1[j]; }
+}
+'''
+
+
+def _host_lane(src, tmp_path, tag):
+    defines = '\n'.join(l for l in src.splitlines() if re.match(r'#define VW_(NT|M|R|G|NB|DE|PLANE|LA) ', l))
+    fn = src[src.index('__device__ __forceinline__ void vw_taps('):]
+    fn = fn[:fn.index('\n}\n') + 3]
+    cpp = tmp_path / f'lane_{tag}.cpp'
+    cpp.write_text(HOST_SHIM % dict(defines=defines, function=fn))
+    so = tmp_path / f'lane_{tag}.so'
+    r = subprocess.run([CLANG, '-O1', '-std=c++17', '-ffp-contract=off', '-shared', '-fPIC', str(cpp), '-o', str(so)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lib = ctypes.CDLL(str(so))
+    lib.run_lane.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p]
+    return lib
+
+
+def _lds_image(x, own_position, M, R, G, plane):
+    """x: (frames, 2) float32, the lane's view: frame 0 = its first own frame.  Ring entry (own + d) mod R holds
+    frames [d*M, (d+1)*M); chunk r of the entry at position p is at r*plane + p*16 (+ (M/4)*plane for channel 1);
+    positions R .. R+G-1 mirror positions 0 .. G-1."""
+    qc = M // 4
+    img = np.full(2 * qc * plane, np.nan, np.float32).view(np.uint8)
+    for d in range(R):
+        p = (own_position + d) % R
+        frames = x[d * M:(d + 1) * M]
+        if len(frames) < M:
+            frames = np.vstack([frames, np.zeros((M - len(frames), 2), np.float32)])
+        for c in range(2):
+            for r in range(qc):
+                for pos in ([p, p + R] if p < G else [p]):
+                    at = c * qc * plane + r * plane + pos * 16
+                    img[at:at + 16] = frames[4 * r:4 * r + 4, c].copy().view(np.uint8)
+    return img
+
+
+def _want(x, offs, idx, w, M):
+    out = np.zeros((M, 2), np.float64)
+    for c in range(2):
+        for i, wt in zip(idx[offs[c]:offs[c + 1]], w[offs[c]:offs[c + 1]]):
+            out[:, c] += np.float64(wt) * x[i:i + M, c]
+    return out
+
+
+def _random_table(rng, taps, span):
+    offs, idx, w = [0], [], []
+    for c in range(2):
+        k = int(rng.integers(1, taps + 1))
+        ii = np.sort(rng.choice(span, size=k, replace=False))
+        idx += list(ii)
+        w += list(rng.choice([0.85, -0.85, 0.55, -0.55, 0.35, -0.2, 1.0, -1.0], size=k))
+        offs.append(len(idx))
+    return np.array(offs, np.int32), np.array(idx, np.int32), np.array(w, np.float32)
+
+
+@pytest.mark.parametrize('case', ['g48k_k30', 'g48k_k128_u', 'random_a', 'random_b', 'random_c', 'head'])
+@pytest.mark.parametrize('M,nt', [(32, 128), (16, 256), (64, 64)])
+def test_one_lane_of_the_generated_tap_function(native, golden, tmp_path, case, M, nt):
+    rng = np.random.default_rng(abs(hash((case, M))) % (1 << 32))
+    if case.startswith('g48k'):
+        offs, idx, w = _table(golden.fir(case))
+    elif case == 'head':            # taps 0 and 1, the last offsets of a short filter: both parities at both edges of a run
+        offs, idx, w = np.array([0, 3, 6], np.int32), np.array([0, 1, 95, 1, 2, 94], np.int32), np.array([1, -1, .5, .25, 2, -3], np.float32)
+    else:
+        offs, idx, w = _random_table(rng, 40, int(rng.integers(8, 1500)))
+    src, lds_bytes, fmas = native.window_kernel_source(offs, idx, w, 2, M, nt, with_traffic=True)
+    R, G, plane = _macro(src, 'VW_R'), _macro(src, 'VW_G'), _macro(src, 'VW_PLANE')
+    assert R == nt + (int(idx.max()) + M - 1) // M and _macro(src, 'VW_NB') * G > R - nt
+    assert (plane // 16) >= R + G and (plane // 16) % 16 == (16 // (M // 4)) % 16
+    assert fmas == M * len(idx) and lds_bytes <= 4 * fmas * (M + 4) // M + 64       # never worse than a window per tap
+    lib = _host_lane(src, tmp_path, f'{case}_{M}')
+    x = rng.uniform(-1, 1, (R * M, 2)).astype(np.float32)
+    want = _want(x.astype(np.float64), offs, idx, w, M)
+    peak = np.abs(want).max()
+    for own in (0, 1, R - 1, R - G, nt, int(rng.integers(0, R))):       # ring positions either side of the wrap
+        img = _lds_image(x, own, M, R, G, plane)
+        o0, o1 = np.zeros(M, np.float32), np.zeros(M, np.float32)
+        lib.run_lane(img.ctypes.data, own, o0.ctypes.data, o1.ctypes.data)
+        got = np.stack([o0, o1], 1).astype(np.float64)
+        assert np.all(np.isfinite(got)), f'own={own}: a read outside the window (NaN filler)'
+        assert np.abs(got - want).max() <= 1e-6 * peak, f'own={own}'
+
+
+def test_window_reads_fewer_lds_bytes_than_a_read_per_tap(native, golden):
+    """The point of the form: bytes read from LDS per (tap, output) product; the pair-read kernel pays 4."""
+    per = {}
+    for name in ('g48k_k30', 'g48k_k128_u'):
+        offs, idx, w = _table(golden.fir(name))
+        for M in (16, 32, 64):
+            _, b, f = native.window_kernel_source(offs, idx, w, 2, M, 64, with_traffic=True)
+            per[name, M] = b / f
+    assert per['g48k_k30', 32] < 2.7 and per['g48k_k128_u', 32] < 1.5 and per['g48k_k128_u', 64] < 0.8
+    assert per['g48k_k30', 16] > per['g48k_k30', 32] > per['g48k_k30', 64]
+
+
+@pytest.mark.parametrize('gname,M,nt', [('g48k_k30', 32, 256), ('g48k_k128_u', 32, 128)])
+def test_window_source_compiles_for_gfx950_with_the_intended_isa(native, golden, tmp_path, gname, M, nt):
+    offs, idx, w = _table(golden.fir(gname))
+    src = native.window_kernel_source(offs, idx, w, 2, M, nt)
+    f = tmp_path / 'k.hip'
+    f.write_text(src)
+    out = tmp_path / 'k.s'
+    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '--cuda-device-only',
+                        '-include', 'hip/hip_runtime.h', '-S', str(f), '-o', str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = out.read_text()
+    assert re.search(r'ScratchSize: 0\b', asm), 'the window kernel must not spill'
+    ops = re.findall(r'^\s+([a-z0-9_]+)', asm, re.M)
+    count = {o: ops.count(o) for o in set(ops)}
+    assert count.get('flat_load_dwordx4', 0) == 0, 'LDS reads fell back to flat loads'
+    taps = len(idx)
+    # a tap costs M/2 packed FMAs when its offset is even, M/2 - 1 packed + 2 single ones when odd; the first
+    # product of an accumulator is a multiply
+    odd = int((idx & 1).sum())
+    packed = count['v_pk_fma_f32'] + count.get('v_pk_mul_f32', 0)
+    assert taps * (M // 2) - odd - 16 <= packed <= taps * (M // 2) - odd        # (hipcc may split a few first products)
+    assert count['s_barrier'] == 3                        # the prologue's and the two of a tile
+    # one 16-byte read per chunk of the union of the windows, each an immediate offset from a base register
+    n_reads = len(re.findall(r'q\[\d+\] = VW_RD\(', src))
+    assert n_reads <= count['ds_read_b128'] <= n_reads + 2 * (M // 4)
+    # ... so the tap phase carries (almost) no address arithmetic
+    assert count.get('v_add_u32_e32', 0) < 200

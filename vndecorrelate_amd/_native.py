@@ -111,6 +111,10 @@ SIGNATURES = {
     'vnd_host_free': (ctypes.c_int, [ctypes.c_void_p]),
     'vnd_spec_kernel_source': (ctypes.c_int, [ctypes.c_int32, _c_i32p, _c_i32p, _c_f32p, ctypes.c_int32, ctypes.c_char_p,
                                               ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
+    'vnd_window_kernel_source': (ctypes.c_int, [ctypes.c_int32, _c_i32p, _c_i32p, _c_f32p, ctypes.c_int32, ctypes.c_int32,
+                                                ctypes.c_int32, ctypes.c_char_p, ctypes.c_int64,
+                                                ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
+                                                ctypes.POINTER(ctypes.c_int64)]),
     'vnd_set_variant': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     'vnd_describe_launch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                            ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
@@ -571,6 +575,25 @@ def spec_kernel_source(tap_offsets, tap_index, tap_weight, mode: int = MODE_FAST
     buf = ctypes.create_string_buffer(need.value)
     _check(lib.vnd_spec_kernel_source(*args, buf, need.value, ctypes.byref(need)), 'vnd_spec_kernel_source')
     return buf.value.decode()
+
+
+def window_kernel_source(tap_offsets, tap_index, tap_weight, mode: int = MODE_FAST, frames_per_lane: int = 32,
+                         threads: int = 256, with_traffic: bool = False):
+    """HIP source of the WINDOW form of the per-table kernel (``vnd_window_kernel_source``; needs no device).
+    ``with_traffic``: also return (LDS bytes one lane reads per tile, (tap, output) products they feed)."""
+    offs = np.ascontiguousarray(tap_offsets, np.int32)
+    idx = np.ascontiguousarray(tap_index, np.int32)
+    w = np.ascontiguousarray(tap_weight, np.float32)
+    lib = load_library()
+    need, lb, fm = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    args = (len(offs) - 1, _ptr(offs, ctypes.c_int32), _ptr(idx, ctypes.c_int32), _ptr(w, ctypes.c_float), int(mode),
+            int(frames_per_lane), int(threads))
+    _check(lib.vnd_window_kernel_source(*args, None, 0, ctypes.byref(need), ctypes.byref(lb), ctypes.byref(fm)),
+           'vnd_window_kernel_source')
+    buf = ctypes.create_string_buffer(need.value)
+    _check(lib.vnd_window_kernel_source(*args, buf, need.value, ctypes.byref(need), None, None), 'vnd_window_kernel_source')
+    src = buf.value.decode()
+    return (src, lb.value, fm.value) if with_traffic else src
 
 
 def device_count() -> int:

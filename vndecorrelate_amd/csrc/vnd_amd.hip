@@ -4,7 +4,7 @@
 #include "vnd_epilogue.hpp"
 #include "vnd_moments.hpp"
 #include "vnd_haas.hpp"
-#include "vnd_spec.hpp"
+#include "vnd_win.hpp"
 #include "../../include/vnd_amd.h"
 
 #include <dlfcn.h>
@@ -429,10 +429,19 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     if (batch > 1 && (((uint64_t)n * C * 4) % align != 0 || ((uint64_t)n * Cx * 4) % align_x != 0)) { p.why = "unaligned streams"; return p; }
     const int rr_hint = (v >= 0 && (v & 31) != 0 && (v & 31) <= 8) ? (v & 31) : 0;
     const int dd_hint = v >= 0 ? ((v >> 26) & 3) : 0;
+    // variant bits 5-7: window form off (1), or 16 (2), 32 (3), 64 (4) frames per lane; VND_WIN_M: the default (tuning)
+    static const int win_env = spec_env("VND_WIN_M", 0);
+    const int vw = v >= 0 ? ((v >> 5) & 7) : 0;
+    const int win_m = vw == 1 ? 0 : (vw == 2 ? 16 : (vw == 3 ? 32 : (vw == 4 ? 64 : win_env)));
     // 1536-frame tiles (cfg4's 32-tile streams included: 0.167 vs 0.179 ms) unless a span would be shorter than 12 of them
     for (int attempt = 0; attempt < 2; ++attempt) {
     // (wider signals - a workgroup per channel pair, 8 bytes per frame - measured best with the 1024-frame tiles)
-    if (!spec_pick_config(t->spec_table, (size_t)ctx->lds_limit, rr_hint, dd_hint, &p.cfg, attempt == 1 || C != 2, bc, mode == VND_MODE_EXACT)) { p.why = "halo does not fit the ring"; return p; }
+    // the WINDOW form (vnd_win.hpp: a lane owns win_m consecutive frames and reads the union of its taps' windows once):
+    // stereo outputs, fast mode
+    bool picked = false;
+    if (win_m > 0 && C == 2 && mode == VND_MODE_FAST && rr_hint == 0)
+        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, bc, &p.cfg);
+    if (!picked && !spec_pick_config(t->spec_table, (size_t)ctx->lds_limit, rr_hint, dd_hint, &p.cfg, attempt == 1 || C != 2, bc, mode == VND_MODE_EXACT)) { p.why = "halo does not fit the ring"; return p; }
     const int64_t T = p.cfg.tile();
     const int64_t tiles_total = (n + T - 1) / T;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
@@ -481,7 +490,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     p.cfg.epi = pointwise ? 1 : 0;
     p.cfg.bc = bc ? 1 : 0;
     // exact mode counts VS_LA in steps of RR to 2*RR reads: the LDS queue holds 15, three steps fill it
-    if (p.cfg.exact && !getenv("VND_SPEC_LA")) p.cfg.la = 3;
+    if (p.cfg.exact && !p.cfg.win && !getenv("VND_SPEC_LA")) p.cfg.la = 3;
     p.tiles_total = (int)tiles_total; p.tiles_per_span = (int)per_span; p.spans = (int)spans;
     // one round of workgroups: at most the resident slots, each walking units w, w + nblocks, ...
     p.units = (uint32_t)(units * spans);
@@ -1193,6 +1202,50 @@ vnd_status vnd_spec_kernel_source(int32_t C, const int32_t *tap_offsets, const i
     return VND_OK;
 }
 
+vnd_status vnd_window_kernel_source(int32_t C, const int32_t *tap_offsets, const int32_t *tap_index,
+                                    const float *tap_weight, int32_t mode, int32_t frames_per_lane, int32_t threads,
+                                    char *text, int64_t capacity, int64_t *bytes, int64_t *lds_bytes_per_tile,
+                                    int64_t *fmas_per_tile)
+{
+    if (mode != VND_MODE_FAST && mode != VND_MODE_EXACT)
+        return fail(VND_ERR_INVALID, "the specialised kernel exists for VND_MODE_FAST and VND_MODE_EXACT");
+    if (!bytes) return fail(VND_ERR_INVALID, "null bytes pointer");
+    if (C != 2 || !tap_offsets || tap_offsets[0] != 0)
+        return fail(VND_ERR_INVALID, "the window kernel takes a stereo CSR tap table");
+    SpecTable t;
+    t.C = C;
+    t.tap_off.assign(tap_offsets, tap_offsets + C + 1);
+    const int32_t total = tap_offsets[C];
+    if (total <= 0 || !tap_index || !tap_weight) return fail(VND_ERR_INVALID, "empty tap table");
+    for (int32_t k = 0; k < total; ++k) {
+        if (tap_index[k] < 0 || tap_index[k] >= (1 << 24) || !std::isfinite(tap_weight[k]))
+            return fail(VND_ERR_UNSUPPORTED, "tap %d is outside the specialised kernel's scope", k);
+        t.max_index = std::max(t.max_index, tap_index[k]);
+    }
+    t.idx.assign(tap_index, tap_index + total);
+    t.w.assign(tap_weight, tap_weight + total);
+    t.w_raw = t.w;
+    WinGeom g;
+    if (!win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g))
+        return fail(VND_ERR_UNSUPPORTED, "this window geometry does not fit the LDS");
+    SpecConfig cfg;
+    cfg.nt = threads; cfg.win = frames_per_lane; cfg.win_g = g.G; cfg.win_lds = (int)g.lds_bytes();
+    cfg.la = spec_env("VND_SPEC_LA", 6);
+    cfg.exact = mode == VND_MODE_EXACT ? 1 : 0;
+    if (lds_bytes_per_tile || fmas_per_tile) {
+        size_t lb = 0, fm = 0;
+        win_traffic(t, frames_per_lane, &lb, &fm);
+        if (lds_bytes_per_tile) *lds_bytes_per_tile = (int64_t)lb;
+        if (fmas_per_tile) *fmas_per_tile = (int64_t)fm;
+    }
+    const std::string src = win_source(t, g, cfg);
+    *bytes = (int64_t)src.size() + 1;
+    if (!text) return VND_OK;                    // size query
+    if (capacity < *bytes) return fail(VND_ERR_INVALID, "buffer too small: need %lld bytes", (long long)*bytes);
+    memcpy(text, src.c_str(), src.size() + 1);
+    return VND_OK;
+}
+
 vnd_status vnd_set_variant(vnd_ctx *ctx, int32_t variant)
 {
     if (!ctx) return fail(VND_ERR_INVALID, "null context");
@@ -1213,6 +1266,14 @@ static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64
         DeviceScope on(ctx->device);
         SpecModule *m = spec_module(ctx, t, sp.cfg, !sp.eager);
         if (m && !m->failed) {
+            if (sp.cfg.win) {
+                snprintf(text, (size_t)len,
+                         "conv_spec%s_window (hipRTC, per table) frames_per_lane=%d tile=%d reads_ahead=%d "
+                         "nt_stores=%d mode=%d lds=%zuB workgroups=%u (%u units: %d spans x %d tiles per stream) threads=%d",
+                         sp.cfg.exact ? "_exact" : "", sp.cfg.win, sp.cfg.tile(), sp.cfg.la, sp.cfg.nt_stores, mode,
+                         sp.cfg.lds_bytes(), sp.nblocks, sp.units, sp.spans, sp.tiles_per_span, sp.cfg.nt);
+                return VND_OK;
+            }
             snprintf(text, (size_t)len,
                      "conv_spec%s (hipRTC, per table) pairs_per_lane=%d tile=%d ring_slots=%d prefetch=%d reads_ahead=%d "
                      "nt_stores=%d mode=%d lds=%zuB workgroups=%u (%u units: %d spans x %d tiles per stream) threads=%d",

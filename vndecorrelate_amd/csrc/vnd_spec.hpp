@@ -44,15 +44,20 @@ struct SpecConfig {
     int epi = 0;       // exact mode, stereo: VelvetNoise.decorrelate's pointwise steps in the store phase
     int bc = 0;        // fan-out of a mono input through a stereo table: one LDS plane
     int shift = 0;     // exact mode: a second copy of every plane, one frame ahead, so that odd offsets are aligned pairs
-    int tile() const { return 2 * nt * rr; }
+    // WINDOW form (vnd_win.hpp): win = consecutive output frames per lane (0: the pair-read kernel above),
+    // win_g = entries one base register reaches, win_lds = its LDS footprint (the halo is the table's)
+    int win = 0, win_g = 0, win_lds = 0;
+    int tile() const { return win ? nt * win : 2 * nt * rr; }
     size_t lds_bytes() const
     {
+        if (win) return (size_t)win_lds;
         const size_t pl = (size_t)pp * tile() + 2 * nt + (shift ? 2 : 0);
         return (bc ? 1 : 2) * (shift ? 2 : 1) * pl * 4 + (size_t)2 * (nt / 64) * rr * 2 * 4;
     }
     bool operator<(const SpecConfig &o) const
     {
-        return std::tie(nt, rr, pp, dd, la, nt_stores, exact, epi, bc, shift) < std::tie(o.nt, o.rr, o.pp, o.dd, o.la, o.nt_stores, o.exact, o.epi, o.bc, o.shift);
+        return std::tie(nt, rr, pp, dd, la, nt_stores, exact, epi, bc, shift, win, win_g) <
+               std::tie(o.nt, o.rr, o.pp, o.dd, o.la, o.nt_stores, o.exact, o.epi, o.bc, o.shift, o.win, o.win_g);
     }
 };
 
@@ -378,41 +383,90 @@ inline std::string spec_cache_key(const std::string &src, const char *const *opt
     return buf;
 }
 
+// A cached object is executed as the table's kernel (in VND_MODE_EXACT: as the bit-identical one), so a file is
+// trusted only behind a header that ties it to its payload and to the compiler that made it:
+//   "VNDCO1\0\0" | payload bytes (u64) | FNV-1a 64 of the payload (u64) | 64 bytes of build id (hipRTC version + HIP runtime build)
+// Anything else - truncated, stale after a ROCm upgrade, not ours - is a cache miss: recompile and overwrite.
+struct SpecCacheHeader {
+    char magic[8];
+    uint64_t bytes, hash;
+    char build[64];
+};
+
+inline uint64_t spec_fnv(const char *p, size_t n, uint64_t h = 1469598103934665603ull)
+{
+    for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+inline void spec_build_id(char (&out)[64])
+{
+    memset(out, 0, sizeof out);
+    int major = 0, minor = 0, rt = 0;
+    (void)hiprtcVersion(&major, &minor);
+    (void)hipRuntimeGetVersion(&rt);
+    snprintf(out, sizeof out, "hiprtc %d.%d hip %d %s", major, minor, rt,
+#ifdef HIP_VERSION_GITHASH
+             HIP_VERSION_GITHASH
+#else
+             ""
+#endif
+    );
+}
+
 inline bool spec_cache_load(const std::string &path, std::vector<char> *code)
 {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return false;
     bool ok = false;
-    if (fseek(f, 0, SEEK_END) == 0) {
-        const long n = ftell(f);
-        if (n > 64 && fseek(f, 0, SEEK_SET) == 0) {
-            code->resize((size_t)n);
-            ok = fread(code->data(), 1, (size_t)n, f) == (size_t)n && memcmp(code->data(), "\177ELF", 4) == 0;
-        }
+    SpecCacheHeader h;
+    char build[64];
+    spec_build_id(build);
+    if (fread(&h, 1, sizeof h, f) == sizeof h && memcmp(h.magic, "VNDCO1\0\0", 8) == 0 && h.bytes > 64 && h.bytes < ((uint64_t)1 << 28) &&
+        memcmp(h.build, build, sizeof build) == 0) {
+        code->resize((size_t)h.bytes);
+        ok = fread(code->data(), 1, (size_t)h.bytes, f) == (size_t)h.bytes && fgetc(f) == EOF &&
+             memcmp(code->data(), "\177ELF", 4) == 0 && spec_fnv(code->data(), code->size()) == h.hash;
     }
     fclose(f);
+    if (!ok) code->clear();
     return ok;
 }
 
 inline void spec_cache_store(const std::string &dir, const std::string &path, const std::vector<char> &code)
 {
     std::string cmd_dir = dir;
-    for (size_t i = 1; i <= cmd_dir.size(); ++i)                     // mkdir -p
-        if (i == cmd_dir.size() || cmd_dir[i] == '/') { const std::string part = cmd_dir.substr(0, i); (void)mkdir(part.c_str(), 0755); }
-    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-    FILE *f = fopen(tmp.c_str(), "wb");
-    if (!f) return;
-    const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
-    fclose(f);
-    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());     // rename is atomic: readers never see half a file
+    for (size_t i = 1; i <= cmd_dir.size(); ++i)                     // mkdir -p, private to the user: the objects are executed
+        if (i == cmd_dir.size() || cmd_dir[i] == '/') { const std::string part = cmd_dir.substr(0, i); (void)mkdir(part.c_str(), 0700); }
+    std::string tmp = path + ".XXXXXX";                              // unique per writer (threads of one process included)
+    const int fd = mkstemp(&tmp[0]);
+    if (fd < 0) return;
+    FILE *f = fdopen(fd, "wb");
+    if (!f) { close(fd); (void)remove(tmp.c_str()); return; }
+    SpecCacheHeader h;
+    memcpy(h.magic, "VNDCO1\0\0", 8);
+    h.bytes = code.size();
+    h.hash = spec_fnv(code.data(), code.size());
+    spec_build_id(h.build);
+    const bool ok = fwrite(&h, 1, sizeof h, f) == sizeof h && fwrite(code.data(), 1, code.size(), f) == code.size();
+    const bool closed = fclose(f) == 0;
+    if (!ok || !closed || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());     // rename is atomic: readers never see half a file
 }
+
+// the WINDOW form's translation unit (vnd_win.hpp)
+inline std::string win_source_for(const SpecTable &t, const SpecConfig &cfg);
 
 inline bool spec_compile(const SpecTable &t, const SpecConfig &cfg, int device, int lds_limit, SpecModule *m, bool cache_only = false)
 {
     m->cfg = cfg;
     m->pending = false;
-    std::string src = spec_prologue(t, cfg);
-    src += kSpecKernelSource;
+    std::string src;
+    if (cfg.win) {
+        src = win_source_for(t, cfg);
+    } else {
+        src = spec_prologue(t, cfg);
+        src += kSpecKernelSource;
+    }
     if (getenv("VND_SPEC_BREAK")) src += "\n#error VND_SPEC_BREAK: injected build failure (fallback test)\n";
     if (const char *dump = getenv("VND_SPEC_DUMP")) {
         if (FILE *f = fopen(dump, "w")) { fputs(src.c_str(), f); fclose(f); }
