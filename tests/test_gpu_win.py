@@ -1,0 +1,144 @@
+"""GPU tier: the WINDOW form of the per-table kernel (vnd_win.hpp; VND_MODE_FAST's default for stereo tables) and
+every per-table kernel at the pool shapes bench.py times, against the oracle.
+Bar: <= 1e-6 of the output peak (2e-6 for 128-tap tables, where the reference's own two associations differ by
+1.2e-6); the exact kernels bit for bit."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from oracle import vnd_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_PEAK = 1e-6
+FORCE = 1 << 23            # specialise however little work there is
+GENERIC = 1 << 25
+WIN = {0: 1 << 5, 16: 2 << 5, 32: 3 << 5, 64: 4 << 5}      # variant bits 5-7: frames per lane (0: the pair-read kernel)
+
+
+def span_bits(min_span, rounds):
+    return (min_span << 20) | (rounds << 28)
+
+
+@pytest.fixture(scope='module')
+def env():
+    import vndecorrelate_amd.decorrelation as d
+    from vndecorrelate_amd import _native
+    ctx = _native.default_context()
+    yield d, _native, ctx
+    ctx.set_variant(-1)
+
+
+def _table(native, ctx, fir):
+    from vndecorrelate_amd.taps import function_path_arrays
+    a = function_path_arrays(fir)
+    return native.TapTable.create(ctx, a.tap_offsets, a.tap_index, a.tap_weight)
+
+
+def _err(got, want):
+    peak = float(np.max(np.abs(want))) or 1.0
+    return float(np.max(np.abs(got.astype(np.float64) - want))) / peak
+
+
+@pytest.mark.parametrize('gname', ['g48k_k30', 'g48k_k128_u', 'g44k_noenv'])
+@pytest.mark.parametrize('M,nt', [(32, 64), (16, 128), (64, 64), (32, 128)])
+def test_window_geometries_seams_and_tails(env, golden, monkeypatch, gname, M, nt):
+    """Every length class around the tile (nt * M frames) and the ring, spans of one tile and more (ring refills,
+    wraps of the ring's entry positions, units following each other in one workgroup), stream tails inside a lane's
+    run, batches.  Checked against the NumPy oracle."""
+    d, native, ctx = env
+    fir = golden.fir(gname)
+    table = _table(native, ctx, fir)
+    monkeypatch.setenv('VND_SPEC_NT', str(nt))
+    tol = 2e-6 if 'k128' in gname else TOL_PEAK
+    rng = np.random.default_rng(5)
+    T = nt * M
+    lengths = [1, 2, 31, M - 1, M, M + 1, T - 1, T, T + 1, 2 * T + 3, 3 * T, 5 * T + 17, 9001, 12346, 40003]
+    for n in sorted(set(lengths)):
+        for batch in (1, 3):
+            if batch > 1 and n % 2:
+                continue                                  # odd stereo streams are 8-byte aligned: generic kernel
+            x = rng.uniform(-1, 1, (batch, n, 2)).astype(np.float32)
+            want = np.stack([O.convolve_velvet_noise(x[b], fir) for b in range(batch)])
+            for min_span, rounds in ((1, 7), (2, 1)):
+                ctx.set_variant(FORCE | WIN[M] | span_bits(min_span, rounds))
+                text = table.describe(batch, n, 2, d.MODE_FAST)
+                assert text.startswith('conv_spec_window') and f'frames_per_lane={M} ' in text and f'threads={nt}' in text, text
+                got = table.convolve_host(x, d.MODE_FAST)
+                assert _err(got, want) <= tol, f'{gname} M={M} nt={nt} n={n} batch={batch} spans=({min_span},{rounds}): {_err(got, want):.2e}'
+    ctx.set_variant(-1)
+    table.close()
+
+
+def test_window_results_do_not_depend_on_the_geometry(env, golden, monkeypatch):
+    """Every output is fl(E + O), E / O the fma chains over its even / odd taps in ascending offset - whatever the run
+    length, the workgroup size, the span layout or the batch: bit-identical across all of them."""
+    import torch
+    d, native, ctx = env
+    fir = golden.fir('g48k_k30')
+    table = _table(native, ctx, fir)
+    pool, n = 6, 100003 * 2
+    x = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1)
+    s = torch.cuda.current_stream().cuda_stream
+    results = []
+    for M, nt, spans in ((32, 256, (1, 2)), (32, 64, (2, 1)), (16, 128, (1, 5)), (64, 64, (3, 1)), (16, 256, (1, 1))):
+        monkeypatch.setenv('VND_SPEC_NT', str(nt))
+        ctx.set_variant(FORCE | WIN[M] | span_bits(*spans))
+        assert f'frames_per_lane={M} ' in table.describe(pool, n, 2, d.MODE_FAST)
+        y = torch.empty_like(x)
+        table.convolve_device(x.data_ptr(), y.data_ptr(), pool, n, 2, mode=d.MODE_FAST, stream=s)
+        torch.cuda.synchronize()
+        results.append(y)
+    for y in results[1:]:
+        assert torch.equal(y, results[0])
+    y1 = torch.empty((1, n, 2), dtype=torch.float32, device='cuda')
+    table.convolve_device(x[4].data_ptr(), y1.data_ptr(), 1, n, 2, mode=d.MODE_FAST, stream=s)       # batch == loop
+    torch.cuda.synchronize()
+    assert torch.equal(y1[0], results[0][4])
+    want = c_oracle.convolve(x[4].cpu().numpy(), *O.fir_to_taps(fir))
+    assert _err(results[0][4].cpu().numpy(), want) <= TOL_PEAK
+    ctx.set_variant(-1)
+    table.close()
+
+
+# ---- the per-table kernels at the pool shapes bench.py times (cfg3 twice, cfg4, cfg5), against the oracle ----
+POOLS = {
+    # name: (golden fir, pool, frames, channels, fast tolerance)
+    'cfg3_uniform': ('g48k_k128_u', 24, 2880000, 2, 2e-6),        # 60 s stereo, 128 taps, kappa = 0
+    'cfg3_log_123taps': ('g48k_k128_l', 24, 2880000, 2, 2e-6),    # kappa = 1: the function path keeps 123 of the 128 taps
+    'cfg4_one_launch': ('g48k_k30', 1024, 48000, 2, 1e-6),        # 1024 streams of 1 s, device resident, ONE launch
+    'cfg5_eight_channels': ('g96k_k64_c8', 16, 960000, 8, 1e-6),  # 96 kHz, 8 channels, 64 taps
+}
+
+
+@pytest.mark.parametrize('name', list(POOLS))
+def test_pools_at_bench_shapes_match_the_oracle(env, golden, name):
+    """What bench.py's `secondary` and `cfg4_strong` legs launch: the automatic choice must be a per-table kernel in
+    both modes; fast against the exact kernel on EVERY stream, three streams of both against the C oracle
+    (exact: bit for bit; fast: the tolerance above)."""
+    import torch
+    d, native, ctx = env
+    ctx.set_variant(-1)
+    gname, pool, n, C, tol = POOLS[name]
+    fir = golden.fir(gname)
+    table = _table(native, ctx, fir)
+    fast_text, exact_text = table.describe(pool, n, C, d.MODE_FAST), table.describe(pool, n, C, d.MODE_EXACT)
+    assert fast_text.startswith('conv_spec'), fast_text
+    assert exact_text.startswith('conv_spec_exact'), exact_text
+    if C == 2:
+        assert fast_text.startswith('conv_spec_window'), fast_text
+    x = torch.empty((pool, n, C), dtype=torch.float32, device='cuda').uniform_(-1, 1)
+    y, ye = torch.empty_like(x), torch.empty_like(x)
+    s = torch.cuda.current_stream().cuda_stream
+    table.convolve_device(x.data_ptr(), y.data_ptr(), pool, n, C, mode=d.MODE_FAST, stream=s)
+    table.convolve_device(x.data_ptr(), ye.data_ptr(), pool, n, C, mode=d.MODE_EXACT, stream=s)
+    torch.cuda.synchronize()
+    peak = float(ye.abs().max())
+    per_stream = (y - ye).abs().amax(dim=(1, 2))
+    assert float(per_stream.max()) <= tol * peak, f'stream {int(per_stream.argmax())}: {float(per_stream.max()) / peak:.2e} of peak'
+    offs, idx, w = O.fir_to_taps(fir)
+    for b in (0, pool // 2, pool - 1):
+        want = c_oracle.convolve(x[b].cpu().numpy(), offs, idx, w)
+        assert np.array_equal(ye[b].cpu().numpy(), want), f'exact kernel, stream {b}'
+        assert _err(y[b].cpu().numpy(), want) <= tol, f'fast kernel, stream {b}: {_err(y[b].cpu().numpy(), want):.2e}'
+    table.close()

@@ -126,7 +126,7 @@ def test_one_lane_of_the_generated_tap_function(native, golden, tmp_path, case, 
     src, lds_bytes, fmas = native.window_kernel_source(offs, idx, w, 2, M, nt, with_traffic=True)
     R, G, plane = _macro(src, 'VW_R'), _macro(src, 'VW_G'), _macro(src, 'VW_PLANE')
     assert R == nt + (int(idx.max()) + M - 1) // M and _macro(src, 'VW_NB') * G > R - nt
-    assert (plane // 16) >= R + G and (plane // 16) % 16 == (16 // (M // 4)) % 16
+    assert (plane // 16) >= R + G and (plane // 16) % (32 // (M // 4)) == 16 // (M // 4)
     assert fmas == M * len(idx) and lds_bytes <= 4 * fmas * (M + 4) // M + 64       # never worse than a window per tap
     lib = _host_lane(src, tmp_path, f'{case}_{M}')
     x = rng.uniform(-1, 1, (R * M, 2)).astype(np.float32)

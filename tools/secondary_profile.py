@@ -10,6 +10,7 @@ from vndecorrelate_amd import _native
 from vndecorrelate_amd.taps import function_path_arrays
 
 CONFIGS = {
+    'cfg2': (dict(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1), (128, 480000, 2)),
     'cfg3': (dict(duration_seconds=0.03, num_impulses=128, num_outs=2, sample_rate_hz=48000, log_distribution_strength=0.0, seed=1), (24, 2880000, 2)),
     'cfg5': (dict(duration_seconds=0.03, num_impulses=64, num_outs=8, sample_rate_hz=96000, seed=1), (16, 960000, 8)),
 }

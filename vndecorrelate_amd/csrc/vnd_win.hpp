@@ -40,8 +40,9 @@ inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size
     g->NB = g->DE / G + 1;
     const int qc = M / 4;
     int units = g->R + G;                               // 16-byte slots of one chunk plane: ring + mirror
-    const int want = (16 / qc) % 16;                    // plane stride mod 16 slots that keeps the pair accesses conflict-free
-    while (units % 16 != want) ++units;
+    // the 8-byte accesses of the staging and of the transposition touch QC planes at once: an ODD multiple of 16/QC slots
+    // between planes spreads them over all banks (QC = 8: stride = 2 mod 4; QC = 4: 4 mod 8; QC = 16: odd)
+    while (units % (32 / qc) != 16 / qc) ++units;
     g->plane = units * 16;
     if ((size_t)(qc - 1) * g->plane + (size_t)G * 16 >= 65536) return false;      // ds offset field
     if ((size_t)qc * g->plane >= 65536 && !bc) return false;                       // channel 1's planes as an immediate
@@ -187,23 +188,35 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
 // (short streams: a ring is filled once per span)
 inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool small_tiles, bool bc, SpecConfig *out)
 {
-    static const int kLong[] = {256, 128, 192, 64}, kShort[] = {128, 64, 192, 256};
-    const int nt_env = spec_env("VND_SPEC_NT", 0);
-    const int G = spec_env("VND_WIN_G", 8);
+    // the geometry that keeps the most waves on a CU (the ring is LDS-bound: tile + halo per workgroup), the larger
+    // workgroup on a tie (the halo is shared by more lanes); short streams (small_tiles: a ring is filled once per
+    // span) take at most 128 threads = 4096-frame tiles
+    static const int kShapes[] = {256, 192, 128, 64};
+    const int nt_env = spec_env("VND_SPEC_NT", 0), g_env = spec_env("VND_WIN_G", 0);
+    int best_waves = 0;
     for (int k = 0; k < 4; ++k) {
-        const int nt = nt_env > 0 ? nt_env : (small_tiles ? kShort[k] : kLong[k]);
-        WinGeom g;
-        if (win_geometry(t, M, nt, G, bc, lds_limit, &g)) {
-            SpecConfig c;
-            c.nt = nt; c.win = M; c.win_g = G; c.win_lds = (int)g.lds_bytes(); c.bc = bc ? 1 : 0;
-            c.la = spec_env("VND_SPEC_LA", 6);
-            c.rr = 0; c.pp = 0; c.dd = 0;
-            *out = c;
-            return true;
+        const int nt = nt_env > 0 ? nt_env : kShapes[k];
+        if (small_tiles && nt_env <= 0 && nt > 128) continue;
+        for (int G : {8, 4}) {
+            if (g_env > 0) G = g_env;
+            WinGeom g;
+            if (win_geometry(t, M, nt, G, bc, lds_limit, &g)) {
+                const int per_cu = (int)std::min<size_t>(std::min<size_t>(16, 2048 / nt), (160 * 1024) / g.lds_bytes());
+                const int waves = per_cu * (nt / 64);
+                if (waves > best_waves) {
+                    best_waves = waves;
+                    SpecConfig c;
+                    c.nt = nt; c.win = M; c.win_g = G; c.win_lds = (int)g.lds_bytes(); c.bc = bc ? 1 : 0;
+                    c.la = spec_env("VND_SPEC_LA", 6);
+                    c.rr = 0; c.pp = 0; c.dd = 0;
+                    *out = c;
+                }
+            }
+            if (g_env > 0) break;
         }
         if (nt_env > 0) break;
     }
-    return false;
+    return best_waves > 0;
 }
 
 inline std::string win_source_for(const SpecTable &t, const SpecConfig &cfg)
