@@ -270,11 +270,14 @@ vnd_status vnd_spec_kernel_source(int32_t num_channels, const int32_t *tap_offse
                                   char *text, int64_t capacity, int64_t *bytes);
 /* The WINDOW form of the per-table kernel (stereo tables): a lane owns `frames_per_lane` (16 | 32 | 64)
  * consecutive output frames and reads the union of its taps' windows from LDS once.
- * Same contract as vnd_spec_kernel_source; `threads` = workgroup size (multiple of 64).  When
- * `lds_bytes_per_tile` / `fmas_per_tile` are non-NULL they receive what ONE lane reads from LDS for its
- * tap sums per tile and the (tap, output) products that feeds - the kernel's figure of merit. */
+ * Same contract as vnd_spec_kernel_source; the table as for vnd_taps_create (seg_* NULL: function path);
+ * `threads` = workgroup size (multiple of 64).  When `lds_bytes_per_tile` / `fmas_per_tile` are non-NULL
+ * they receive what ONE lane reads from LDS for its tap sums per tile and the (tap, output) products that
+ * feeds - the kernel's figure of merit. */
 vnd_status vnd_window_kernel_source(int32_t num_channels, const int32_t *tap_offsets,
-                                    const int32_t *tap_index, const float *tap_weight, int32_t mode,
+                                    const int32_t *tap_index, const float *tap_weight,
+                                    const int32_t *seg_offsets, const int32_t *seg_end,
+                                    const float *seg_gain, int32_t apply_gain, int32_t mode,
                                     int32_t frames_per_lane, int32_t threads, char *text,
                                     int64_t capacity, int64_t *bytes, int64_t *lds_bytes_per_tile,
                                     int64_t *fmas_per_tile);

@@ -4,6 +4,7 @@
   documented formulas, against the plain tap sum (the oracle's definition, decorrelation.py:649-658);
 * the whole translation unit is cross-compiled for gfx950 and its ISA checked for what the design rests on."""
 import ctypes
+import zlib
 import pathlib
 import re
 import shutil
@@ -105,7 +106,7 @@ def _want(x, offs, idx, w, M):
 def _random_table(rng, taps, span):
     offs, idx, w = [0], [], []
     for c in range(2):
-        k = int(rng.integers(1, taps + 1))
+        k = int(rng.integers(1, min(taps, span) + 1))
         ii = np.sort(rng.choice(span, size=k, replace=False))
         idx += list(ii)
         w += list(rng.choice([0.85, -0.85, 0.55, -0.55, 0.35, -0.2, 1.0, -1.0], size=k))
@@ -116,7 +117,7 @@ def _random_table(rng, taps, span):
 @pytest.mark.parametrize('case', ['g48k_k30', 'g48k_k128_u', 'random_a', 'random_b', 'random_c', 'head'])
 @pytest.mark.parametrize('M,nt', [(32, 128), (16, 256), (64, 64)])
 def test_one_lane_of_the_generated_tap_function(native, golden, tmp_path, case, M, nt):
-    rng = np.random.default_rng(abs(hash((case, M))) % (1 << 32))
+    rng = np.random.default_rng(zlib.crc32(f'{case}/{M}'.encode()))
     if case.startswith('g48k'):
         offs, idx, w = _table(golden.fir(case))
     elif case == 'head':            # taps 0 and 1, the last offsets of a short filter: both parities at both edges of a run
@@ -139,6 +140,73 @@ def test_one_lane_of_the_generated_tap_function(native, golden, tmp_path, case, 
         got = np.stack([o0, o1], 1).astype(np.float64)
         assert np.all(np.isfinite(got)), f'own={own}: a read outside the window (NaN filler)'
         assert np.abs(got - want).max() <= 1e-6 * peak, f'own={own}'
+
+
+def _want_exact(x, arr, M):
+    """The reference's association in float32, op by op: taps in table order, separately rounded products and sums;
+    class path: per segment (sum of -x, then of +x) * gain, segments summed (decorrelation.py:402-414, :656-658)."""
+    out = np.zeros((M, 2), np.float32)
+    for c in range(2):
+        k0, k1 = arr.tap_offsets[c], arr.tap_offsets[c + 1]
+        if arr.seg_offsets is None:
+            acc = np.zeros(M, np.float32)
+            for i, wt in zip(arr.tap_index[k0:k1], arr.tap_weight[k0:k1]):
+                acc = acc + x[i:i + M, c] * np.float32(wt)
+            out[:, c] = acc
+            continue
+        total = np.zeros(M, np.float32)
+        prev = k0
+        for sg in range(arr.seg_offsets[c], arr.seg_offsets[c + 1]):
+            sb = np.zeros(M, np.float32)
+            for k in range(prev, arr.seg_end[sg]):
+                i = arr.tap_index[k]
+                sb = sb - x[i:i + M, c] if arr.tap_weight[k] < 0 else sb + x[i:i + M, c]
+            if arr.apply_gain:
+                sb = sb * np.float32(arr.seg_gain[sg])
+            total = total + sb
+            prev = arr.seg_end[sg]
+        out[:, c] = total
+    return out
+
+
+@pytest.mark.parametrize('case', ['fn_g48k_k30', 'fn_g48k_k128_l', 'fn_unordered', 'class_default', 'class_noenv', 'class_dense'])
+@pytest.mark.parametrize('M,nt', [(32, 128), (16, 64), (64, 64)])
+def test_one_lane_of_the_exact_tap_function_is_bit_identical(native, golden, tmp_path, case, M, nt):
+    """VND_MODE_EXACT in the window form: the generated lane function against the reference's float32 association
+    emulated op by op - function-path tables (ascending, and one in scrambled order: a pass per run), class-path
+    tables (segments of -1 / +1 taps with gains, identity envelope, duplicates)."""
+    from vndecorrelate_amd.taps import TapArrays, class_path_arrays, function_path_arrays
+    import vndecorrelate_amd.decorrelation as d
+    rng = np.random.default_rng(zlib.crc32(f'{case}/{M}'.encode()))
+    if case.startswith('fn_g'):
+        arr = function_path_arrays(golden.fir(case[3:]))
+    elif case == 'fn_unordered':
+        offs, idx, w = _random_table(rng, 24, 900)
+        for c in range(2):                           # table order is the caller's: scramble one channel, duplicate an offset
+            seg = slice(offs[c], offs[c + 1])
+            if c == 0:
+                perm = rng.permutation(offs[1] - offs[0])
+                idx[seg], w[seg] = idx[seg][perm], w[seg][perm]
+        arr = TapArrays(offs, idx, w)
+    else:
+        kw = dict(class_default=dict(), class_noenv=dict(segment_envelope=()),
+                  class_dense=dict(num_impulses=128, duration_seconds=0.03))[case]
+        arr = d.VelvetNoise(sample_rate_hz=48000, seed=3, **kw)._tap_arrays()
+        assert arr.seg_offsets is not None and arr.chan_flags.sum() == 0
+    src = native.window_kernel_source(arr.tap_offsets, arr.tap_index, arr.tap_weight, 0, M, nt, seg_offsets=arr.seg_offsets,
+                                      seg_end=arr.seg_end, seg_gain=arr.seg_gain, apply_gain=arr.apply_gain)
+    assert '#define VW_EXACT 1' in src and 'VW_FMA(' not in src[src.index('void vw_taps('):src.index('#if VW_EPI')]
+    R, G, plane = _macro(src, 'VW_R'), _macro(src, 'VW_G'), _macro(src, 'VW_PLANE')
+    lib = _host_lane(src, tmp_path, f'ex_{case}_{M}')
+    x = rng.uniform(-1, 1, (R * M, 2)).astype(np.float32)
+    x[rng.integers(0, len(x), 40), rng.integers(0, 2, 40)] = 0.0          # exact zeros: the sums must start from +0
+    want = _want_exact(x, arr, M)
+    for own in (0, R - 1, int(rng.integers(0, R))):
+        img = _lds_image(x, own, M, R, G, plane)
+        o0, o1 = np.zeros(M, np.float32), np.zeros(M, np.float32)
+        lib.run_lane(img.ctypes.data, own, o0.ctypes.data, o1.ctypes.data)
+        got = np.stack([o0, o1], 1)
+        assert got.tobytes() == want.tobytes(), f'own={own}: {np.abs(got - want).max():.3e}'
 
 
 def test_window_reads_fewer_lds_bytes_than_a_read_per_tap(native, golden):

@@ -111,7 +111,8 @@ SIGNATURES = {
     'vnd_host_free': (ctypes.c_int, [ctypes.c_void_p]),
     'vnd_spec_kernel_source': (ctypes.c_int, [ctypes.c_int32, _c_i32p, _c_i32p, _c_f32p, ctypes.c_int32, ctypes.c_char_p,
                                               ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
-    'vnd_window_kernel_source': (ctypes.c_int, [ctypes.c_int32, _c_i32p, _c_i32p, _c_f32p, ctypes.c_int32, ctypes.c_int32,
+    'vnd_window_kernel_source': (ctypes.c_int, [ctypes.c_int32, _c_i32p, _c_i32p, _c_f32p, _c_i32p, _c_i32p, _c_f32p,
+                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                 ctypes.c_int32, ctypes.c_char_p, ctypes.c_int64,
                                                 ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                                 ctypes.POINTER(ctypes.c_int64)]),
@@ -578,15 +579,22 @@ def spec_kernel_source(tap_offsets, tap_index, tap_weight, mode: int = MODE_FAST
 
 
 def window_kernel_source(tap_offsets, tap_index, tap_weight, mode: int = MODE_FAST, frames_per_lane: int = 32,
-                         threads: int = 256, with_traffic: bool = False):
+                         threads: int = 256, with_traffic: bool = False, *, seg_offsets=None, seg_end=None,
+                         seg_gain=None, apply_gain: bool = False):
     """HIP source of the WINDOW form of the per-table kernel (``vnd_window_kernel_source``; needs no device).
-    ``with_traffic``: also return (LDS bytes one lane reads per tile, (tap, output) products they feed)."""
+    ``seg_*``: a class-path table as for ``TapTable.create``.  ``with_traffic``: also return (LDS bytes one lane
+    reads per tile, (tap, output) products they feed)."""
     offs = np.ascontiguousarray(tap_offsets, np.int32)
     idx = np.ascontiguousarray(tap_index, np.int32)
     w = np.ascontiguousarray(tap_weight, np.float32)
+    so = se = sg = None
+    if seg_offsets is not None:
+        so, se = np.ascontiguousarray(seg_offsets, np.int32), np.ascontiguousarray(seg_end, np.int32)
+        sg = np.ascontiguousarray(seg_gain, np.float32)
     lib = load_library()
     need, lb, fm = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
-    args = (len(offs) - 1, _ptr(offs, ctypes.c_int32), _ptr(idx, ctypes.c_int32), _ptr(w, ctypes.c_float), int(mode),
+    args = (len(offs) - 1, _ptr(offs, ctypes.c_int32), _ptr(idx, ctypes.c_int32), _ptr(w, ctypes.c_float),
+            _ptr(so, ctypes.c_int32), _ptr(se, ctypes.c_int32), _ptr(sg, ctypes.c_float), int(bool(apply_gain)), int(mode),
             int(frames_per_lane), int(threads))
     _check(lib.vnd_window_kernel_source(*args, None, 0, ctypes.byref(need), ctypes.byref(lb), ctypes.byref(fm)),
            'vnd_window_kernel_source')

@@ -433,13 +433,16 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     static const int win_env = spec_env("VND_WIN_M", 32);
     const int vw = v >= 0 ? ((v >> 5) & 7) : 0;
     const int win_m = vw == 1 ? 0 : (vw == 2 ? 16 : (vw == 3 ? 32 : (vw == 4 ? 64 : win_env)));
+    // VND_MODE_EXACT in the window form: tables whose weights let the sign ride in the add (finite) - all in spec scope
+    static const int win_exact_env = spec_env("VND_WIN_EXACT", 1);
+    const bool win_exact = win_exact_env != 0 || vw >= 2;
     // 1536-frame tiles (cfg4's 32-tile streams included: 0.167 vs 0.179 ms) unless a span would be shorter than 12 of them
     for (int attempt = 0; attempt < 2; ++attempt) {
     // (wider signals - a workgroup per channel pair, 8 bytes per frame - measured best with the 1024-frame tiles)
     // the WINDOW form (vnd_win.hpp: a lane owns win_m consecutive frames and reads the union of its taps' windows once):
     // stereo outputs, fast mode
     bool picked = false;
-    if (win_m > 0 && C == 2 && mode == VND_MODE_FAST && rr_hint == 0)
+    if (win_m > 0 && C == 2 && rr_hint == 0 && (mode == VND_MODE_FAST || win_exact))
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, bc, &p.cfg);
     if (!picked && !spec_pick_config(t->spec_table, (size_t)ctx->lds_limit, rr_hint, dd_hint, &p.cfg, attempt == 1 || C != 2, bc, mode == VND_MODE_EXACT)) { p.why = "halo does not fit the ring"; return p; }
     const int64_t T = p.cfg.tile();
@@ -457,7 +460,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     if (!(v >= 0 && ((v >> 20) & 7)))
         min_span = std::min<int64_t>(8, std::max<int64_t>(2, units * tiles_total / (2 * resident)));
     if (!force && units * n < 2000000) { p.why = "too little work for persistent workgroups"; return p; }
-    p.eager = force || units * tiles_total >= resident * 8;      // enough work to be worth building the kernel for
+    p.eager = force || units * n >= 12000000;                  // enough work (frames per channel pair) to be worth building the kernel for
     // Spans per stream: the workgroups are equally long, so the grid should fill the resident slots
     // a whole number of times ("rounds") - 1.5 rounds cost as much as 2.  Fewest spans (longest
     // rings) whose last round is at least 95 % full, else the fullest.
@@ -496,7 +499,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     p.units = (uint32_t)(units * spans);
     p.nblocks = (uint32_t)std::min<int64_t>(units * spans, resident);
     p.use = true;
-    if (per_span >= 12 || rr_hint > 0) break;
+    if (per_span >= (p.cfg.win ? 6 : 12) || rr_hint > 0) break;
     }
     return p;
 }
@@ -1203,9 +1206,10 @@ vnd_status vnd_spec_kernel_source(int32_t C, const int32_t *tap_offsets, const i
 }
 
 vnd_status vnd_window_kernel_source(int32_t C, const int32_t *tap_offsets, const int32_t *tap_index,
-                                    const float *tap_weight, int32_t mode, int32_t frames_per_lane, int32_t threads,
-                                    char *text, int64_t capacity, int64_t *bytes, int64_t *lds_bytes_per_tile,
-                                    int64_t *fmas_per_tile)
+                                    const float *tap_weight, const int32_t *seg_offsets, const int32_t *seg_end,
+                                    const float *seg_gain, int32_t apply_gain, int32_t mode, int32_t frames_per_lane,
+                                    int32_t threads, char *text, int64_t capacity, int64_t *bytes,
+                                    int64_t *lds_bytes_per_tile, int64_t *fmas_per_tile)
 {
     if (mode != VND_MODE_FAST && mode != VND_MODE_EXACT)
         return fail(VND_ERR_INVALID, "the specialised kernel exists for VND_MODE_FAST and VND_MODE_EXACT");
@@ -1225,6 +1229,24 @@ vnd_status vnd_window_kernel_source(int32_t C, const int32_t *tap_offsets, const
     t.idx.assign(tap_index, tap_index + total);
     t.w.assign(tap_weight, tap_weight + total);
     t.w_raw = t.w;
+    if (seg_offsets) {
+        if (!seg_end || !seg_gain || seg_offsets[0] != 0) return fail(VND_ERR_INVALID, "segment arrays incomplete");
+        t.has_seg = true;
+        t.apply_gain = apply_gain != 0;
+        t.seg_off.assign(seg_offsets, seg_offsets + C + 1);
+        t.seg_end.assign(seg_end, seg_end + seg_offsets[C]);
+        t.seg_gain.assign(seg_gain, seg_gain + seg_offsets[C]);
+        for (int c = 0; c < C; ++c) {
+            int32_t prev = tap_offsets[c];
+            for (int32_t sg = seg_offsets[c]; sg < seg_offsets[c + 1]; ++sg) {
+                if (seg_end[sg] <= prev || seg_end[sg] > tap_offsets[c + 1]) return fail(VND_ERR_UNSUPPORTED, "empty or misplaced segment");
+                prev = seg_end[sg];
+                if (apply_gain)
+                    for (int32_t k = (sg == seg_offsets[c] ? tap_offsets[c] : seg_end[sg - 1]); k < seg_end[sg]; ++k) t.w[k] = tap_weight[k] * seg_gain[sg];
+            }
+            if (prev != tap_offsets[c + 1]) return fail(VND_ERR_UNSUPPORTED, "segments do not cover the channel's taps");
+        }
+    }
     WinGeom g;
     if (!win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g))
         return fail(VND_ERR_UNSUPPORTED, "this window geometry does not fit the LDS");
@@ -1234,7 +1256,8 @@ vnd_status vnd_window_kernel_source(int32_t C, const int32_t *tap_offsets, const
     cfg.exact = mode == VND_MODE_EXACT ? 1 : 0;
     if (lds_bytes_per_tile || fmas_per_tile) {
         size_t lb = 0, fm = 0;
-        win_traffic(t, frames_per_lane, &lb, &fm);
+        if (cfg.exact) win_traffic_exact(t, frames_per_lane, &lb, &fm);
+        else win_traffic(t, frames_per_lane, &lb, &fm);
         if (lds_bytes_per_tile) *lds_bytes_per_tile = (int64_t)lb;
         if (fmas_per_tile) *fmas_per_tile = (int64_t)fm;
     }

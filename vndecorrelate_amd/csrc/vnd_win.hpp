@@ -12,6 +12,7 @@
 //     - the reference's sum over taps of w * x[n + i] (decorrelation.py:649-658), every product exactly once.
 #pragma once
 #include "vnd_spec.hpp"
+#include <cmath>
 
 namespace vnd {
 
@@ -157,6 +158,186 @@ inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int l
     return s;
 }
 
+// ---- VND_MODE_EXACT in the window form ----------------------------------------------------------------
+// The reference's association, bit for bit: per output ONE accumulator that takes the taps in TABLE order,
+//     sb = f32(sb + f32(x * w))        (NumPy's  out[:N-i] += x[i:] * w,  decorrelation.py:656-658;
+//                                       a weight of +-1 is the class path's  sb += / -= x,  :405-410)
+// and at a segment's end  sb *= gain  (unless the envelope is the identity, :411-412),  out += sb  (:413).
+// A lane's chunks arrive in ascending order, so for every output the taps of an ascending run of the table
+// arrive in table order: a PASS is a maximal run of consecutive taps (within one segment) with non-decreasing
+// offsets - the whole table on the function path, the negative and the positive list of each segment on the
+// class path (:247-254) - and reads the union of ITS taps' windows.  Within a pass:
+//   * the accumulators are the aligned output pairs (0,1), (2,3), ... and EVERY update is one v_pk_add_f32.  Output
+//     pair (j, j+1) takes from tap i the input pair starting at element e = i + j: for even e an aligned half of a
+//     chunk (A0 = elements o, o+1; A1 = o+2, o+3), for odd e a pair formed once per chunk from its registers
+//     (B1 = o+1, o+2; B0 = o-1, o with the previous chunk's last element: one v_pk_mov_b32 each) and shared by all
+//     the odd taps that meet the chunk.  A B0 pair is met one chunk late; every later tap of the same output still
+//     comes after it, so the order per output stays the table's;
+//   * f32(x * w) is formed once per (chunk, pair, |w|) and shared by the taps of that magnitude; f32(x * -g) = -f32(x * g)
+//     and sb + (-p) = sb - p exactly, so the sign rides in the add;
+//   * accumulators open with 0 + v / 0 - v (NumPy starts from zeros: 0 + -0 = +0), never with a bare copy.
+struct WinExTap { int idx; float w; };
+struct WinExPass { int ch; std::vector<WinExTap> taps; int end; float gain; };      // end: 0 (the segment goes on), 1 sum is the output, 2 out += sb, 3 sb *= gain first
+struct WinExOp { int type, k; float w; };                  // type 0 A0, 1 A1, 2 B0, 3 B1; accumulator pair k
+struct WinExRead { int ch, o; size_t pass; std::vector<WinExOp> ops; };
+
+inline std::vector<WinExPass> win_exact_passes(const SpecTable &t, int ch)
+{
+    std::vector<WinExPass> out;
+    const int32_t k0 = t.tap_off[ch], k1 = t.tap_off[ch + 1];
+    if (k0 == k1) return out;
+    auto add_segment = [&](int32_t a, int32_t b, int end, float gain) {
+        int32_t start = a;
+        for (int32_t k = a + 1; k <= b; ++k) {
+            if (k == b || t.idx[k] < t.idx[k - 1]) {
+                WinExPass ps{ch, {}, k == b ? end : 0, gain};
+                for (int32_t m = start; m < k; ++m) ps.taps.push_back(WinExTap{t.idx[m], t.w_raw[m]});
+                out.push_back(std::move(ps));
+                start = k;
+            }
+        }
+    };
+    if (!t.has_seg) {
+        add_segment(k0, k1, 1, 1.0f);
+    } else {
+        int32_t prev = k0;
+        for (int32_t sg = t.seg_off[ch]; sg < t.seg_off[ch + 1]; ++sg) {
+            add_segment(prev, t.seg_end[sg], t.apply_gain ? 3 : 2, t.seg_gain[sg]);      // spec scope: no empty segment
+            prev = t.seg_end[sg];
+        }
+    }
+    return out;
+}
+
+// the chunks a pass reads, ascending, each with its updates in table order (and the chunks that only lend
+// their last element to the next one's B0 pair)
+inline void win_exact_reads(const std::vector<WinExPass> &passes, int M, std::vector<WinExRead> *reads, size_t pass_base)
+{
+    for (size_t p = 0; p < passes.size(); ++p) {
+        const WinExPass &ps = passes[p];
+        std::map<int, std::vector<WinExOp>> by_chunk;
+        for (const WinExTap &tp : ps.taps)
+            for (int j = 0; j < M; j += 2) {
+                const int e = tp.idx + j;
+                switch (e & 3) {
+                case 0: by_chunk[e].push_back(WinExOp{0, j / 2, tp.w}); break;
+                case 2: by_chunk[e - 2].push_back(WinExOp{1, j / 2, tp.w}); break;
+                case 1: by_chunk[e - 1].push_back(WinExOp{3, j / 2, tp.w}); break;
+                default: by_chunk[e + 1].push_back(WinExOp{2, j / 2, tp.w}); break;
+                }
+            }
+        std::vector<int> lend;
+        for (const auto &kv : by_chunk)
+            for (const WinExOp &op : kv.second)
+                if (op.type == 2) { lend.push_back(kv.first - 4); break; }
+        for (int o : lend) by_chunk[o];                          // present, possibly without updates
+        for (auto &kv : by_chunk) reads->push_back(WinExRead{ps.ch, kv.first, pass_base + p, std::move(kv.second)});
+    }
+}
+
+inline void win_traffic_exact(const SpecTable &t, int M, size_t *lds_bytes, size_t *fmas)
+{
+    *lds_bytes = 0; *fmas = 0;
+    for (int ch = 0; ch < t.C; ++ch) {
+        std::vector<WinExRead> reads;
+        const std::vector<WinExPass> passes = win_exact_passes(t, ch);
+        if (!passes.empty()) win_exact_reads(passes, M, &reads, 0);
+        *lds_bytes += 16 * reads.size();
+        *fmas += (size_t)M * (size_t)(t.tap_off[ch + 1] - t.tap_off[ch]);
+    }
+}
+
+inline std::string win_taps_function_exact(const SpecTable &t, const WinGeom &g, int la)
+{
+    const int M = g.M;
+    const size_t ring = (size_t)la + 2;                  // read k lands in q[k % ring]: the previous chunk stays whole while read k + la is issued
+    std::string s;
+    s += "__device__ __forceinline__ void vw_taps(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
+    spec_append(s, "    v4f q[%zu];\n    v2f S[%d], A[%d];\n    const v2f Z2 = {0.0f, 0.0f};\n", ring, M / 2, M / 2);
+    std::vector<WinExPass> passes;
+    std::vector<WinExRead> reads;
+    size_t pass_first[3] = {0, 0, 0};
+    for (int ch = 0; ch < 2; ++ch) {
+        pass_first[ch] = passes.size();
+        std::vector<WinExPass> ps = win_exact_passes(t, ch);
+        if (!ps.empty()) win_exact_reads(ps, M, &reads, passes.size());
+        for (WinExPass &x : ps) passes.push_back(std::move(x));
+    }
+    pass_first[2] = passes.size();
+    auto emit_read = [&](size_t k) {
+        const WinExRead &r = reads[k];
+        const int dE = r.o / M, rr = (r.o % M) / 4, kb = dE / g.G;       // (a lent chunk may lie before the lane's run only if o < 0: never, o >= 0)
+        spec_append(s, "    q[%zu] = VW_RD(b[%d][%d], %d);\n", k % ring, r.ch, kb, (dE - kb * g.G) * 16 + rr * g.plane);
+    };
+    for (size_t k = 0; k < std::min(reads.size(), (size_t)la); ++k) emit_read(k);
+    size_t rk = 0;
+    for (int ch = 0; ch < 2; ++ch) {
+        std::vector<char> s_live(M / 2, 0);      // per output PAIR: the segment accumulator holds a value
+        bool a_live = false;                     // the channel's output accumulators hold a value (class path)
+        bool sum_is_output = false;
+        for (size_t p = pass_first[ch]; p < pass_first[ch + 1]; ++p) {
+            const WinExPass &ps = passes[p];
+            for (; rk < reads.size() && reads[rk].pass == p; ++rk) {
+                if (rk + la < reads.size()) emit_read(rk + la);
+                const WinExRead &rd = reads[rk];
+                if (rd.ops.empty()) continue;                   // lends its last element to the next chunk only
+                const std::string qk = "q[" + std::to_string(rk % ring) + "]";
+                s += "    {\n";
+                bool need_b0 = false, need_b1 = false;
+                for (const WinExOp &op : rd.ops) { need_b0 |= op.type == 2; need_b1 |= op.type == 3; }
+                if (need_b0) spec_append(s, "        const v2f x2 = {q[%zu].w, %s.x};\n", (rk + ring - 1) % ring, qk.c_str());
+                if (need_b1) spec_append(s, "        const v2f x3 = {%s.y, %s.z};\n", qk.c_str(), qk.c_str());
+                const std::string xs[4] = {qk + ".xy", qk + ".zw", "x2", "x3"};
+                // the products this chunk needs: one per (|w| != 1, pair)
+                // (all the products first, then the sums: a sum right behind its product waits for it)
+                std::vector<std::pair<float, int>> prods;
+                std::string sums;
+                auto value_of = [&](float w, int type) -> std::string {
+                    const float m = std::fabs(w);
+                    if (m == 1.0f) return xs[type];
+                    size_t at = 0;
+                    while (at < prods.size() && !(prods[at].first == m && prods[at].second == type)) ++at;
+                    if (at == prods.size()) {
+                        prods.push_back({m, type});
+                        const std::string gw = spec_float(m);
+                        spec_append(s, "        const v2f p%zu = %s * v2f{%s, %s};\n", at, xs[type].c_str(), gw.c_str(), gw.c_str());
+                    }
+                    return "p" + std::to_string(at);
+                };
+                for (const WinExOp &op : rd.ops) {
+                    const char sign = std::signbit(op.w) ? '-' : '+';
+                    const std::string v = value_of(op.w, op.type);
+                    if (s_live[op.k]) spec_append(sums, "        S[%d] = S[%d] %c %s;\n", op.k, op.k, sign, v.c_str());
+                    else spec_append(sums, "        S[%d] = Z2 %c %s;\n", op.k, sign, v.c_str());
+                    s_live[op.k] = 1;
+                }
+                s += sums;
+                s += "    }\n    VW_SB;\n";
+            }
+            if (ps.end == 1) {
+                sum_is_output = true;
+            } else if (ps.end >= 2) {
+                const std::string gw = spec_float(ps.gain);
+                for (int k = 0; k < M / 2; ++k) {
+                    if (ps.end == 3) spec_append(s, "    S[%d] = S[%d] * v2f{%s, %s};\n", k, k, gw.c_str(), gw.c_str());
+                    if (a_live) spec_append(s, "    A[%d] = A[%d] + S[%d];\n", k, k, k);
+                    else spec_append(s, "    A[%d] = Z2 + S[%d];\n", k, k);
+                }
+                a_live = true;
+                std::fill(s_live.begin(), s_live.end(), 0);
+            }
+        }
+        for (int j = 0; j < M; ++j) {
+            const char *src = sum_is_output ? "S" : "A";
+            const bool have = sum_is_output ? (s_live[j / 2] != 0) : a_live;
+            if (have) spec_append(s, "    o%d[%d] = %s[%d].%s;\n", ch, j, src, j / 2, (j & 1) ? "y" : "x");
+            else spec_append(s, "    o%d[%d] = 0.0f;\n", ch, j);
+        }
+    }
+    s += "}\n";
+    return s;
+}
+
 inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
 {
     std::string s;
@@ -179,7 +360,7 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
     const std::string marker = "//@@VW_TAPS@@";
     const size_t at = fixed.find(marker);
     src += fixed.substr(0, at);
-    src += win_taps_function(t, g, c.la);
+    src += c.exact ? win_taps_function_exact(t, g, c.la) : win_taps_function(t, g, c.la);
     src += fixed.substr(at + marker.size());
     return src;
 }
