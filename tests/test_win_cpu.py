@@ -47,6 +47,7 @@ typedef char vw_lchar;
 #define VW_FMA(x, w, a) __builtin_elementwise_fma((x), v2f{(w), (w)}, (a))
 #define VW_MUL(x, w) ((x) * v2f{(w), (w)})
 #define VW_SB
+static inline v2f vw_pair(v2f a, v2f b) { return v2f{a.y, b.x}; }
 %(defines)s
 %(function)s
 static unsigned wrap(unsigned a) { const unsigned b = a - (unsigned)VW_R; return a < b ? a : b; }

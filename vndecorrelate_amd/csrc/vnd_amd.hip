@@ -95,6 +95,7 @@ struct vnd_taps {
     SpecTable spec_table;          // effective weights (segment gain folded in)
     bool spec_ok = false;          // the table is within the specialised kernel's scope
     bool spec_exact_ok = false;    // ... also in VND_MODE_EXACT (no empty segment)
+    bool win_exact_pays = false;   // ... and dense enough for the exact mode's window form to beat its pair-read form
     std::mutex spec_mutex;
     std::map<SpecConfig, std::unique_ptr<SpecModule>> spec_modules;
 };
@@ -434,8 +435,8 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     const int vw = v >= 0 ? ((v >> 5) & 7) : 0;
     const int win_m = vw == 1 ? 0 : (vw == 2 ? 16 : (vw == 3 ? 32 : (vw == 4 ? 64 : win_env)));
     // VND_MODE_EXACT in the window form: tables whose weights let the sign ride in the add (finite) - all in spec scope
-    static const int win_exact_env = spec_env("VND_WIN_EXACT", 1);
-    const bool win_exact = win_exact_env != 0 || vw >= 2;
+    static const int win_exact_env = spec_env("VND_WIN_EXACT", 1);       // 0: never, 1: where it pays (the table knows), 2: always
+    const bool win_exact = vw >= 2 || win_exact_env == 2 || (win_exact_env == 1 && t->win_exact_pays);
     // 1536-frame tiles (cfg4's 32-tile streams included: 0.167 vs 0.179 ms) unless a span would be shorter than 12 of them
     for (int attempt = 0; attempt < 2; ++attempt) {
     // (wider signals - a workgroup per channel pair, 8 bytes per frame - measured best with the 1024-frame tiles)
@@ -822,6 +823,15 @@ vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, 
                     prev = seg_end[sg];
                 }
             }
+        }
+        // VND_MODE_EXACT in the window form pays where taps share their chunks and products: function-path tables that
+        // read at most 2 bytes of LDS per (tap, output) sum with 32-frame runs (cfg3's 128 uniform taps: 1.43, +16 % over
+        // the pair-read exact kernel; cfg2's 30 log-spaced taps: 2.64, a tie; class-path tables split every segment into
+        // a negative and a positive pass and lose: tools/win_exact_try.py)
+        if (t->spec_exact_ok && C == 2 && !has_seg) {
+            size_t lb = 0, sums = 0;
+            win_traffic_exact(t->spec_table, 32, &lb, &sums);
+            t->win_exact_pays = sums > 0 && (double)lb <= 2.0 * (double)sums;
         }
     }
     if (e == hipSuccess) e = upload(&t->d_taps_fast, fast.data(), fast.size());

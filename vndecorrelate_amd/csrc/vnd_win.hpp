@@ -285,8 +285,8 @@ inline std::string win_taps_function_exact(const SpecTable &t, const WinGeom &g,
                 s += "    {\n";
                 bool need_b0 = false, need_b1 = false;
                 for (const WinExOp &op : rd.ops) { need_b0 |= op.type == 2; need_b1 |= op.type == 3; }
-                if (need_b0) spec_append(s, "        const v2f x2 = {q[%zu].w, %s.x};\n", (rk + ring - 1) % ring, qk.c_str());
-                if (need_b1) spec_append(s, "        const v2f x3 = {%s.y, %s.z};\n", qk.c_str(), qk.c_str());
+                if (need_b0) spec_append(s, "        const v2f x2 = vw_pair(q[%zu].zw, %s.xy);\n", (rk + ring - 1) % ring, qk.c_str());
+                if (need_b1) spec_append(s, "        const v2f x3 = vw_pair(%s.xy, %s.zw);\n", qk.c_str(), qk.c_str());
                 const std::string xs[4] = {qk + ".xy", qk + ".zw", "x2", "x3"};
                 // the products this chunk needs: one per (|w| != 1, pair)
                 // (all the products first, then the sums: a sum right behind its product waits for it)
