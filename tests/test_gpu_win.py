@@ -142,3 +142,68 @@ def test_pools_at_bench_shapes_match_the_oracle(env, golden, name):
         assert np.array_equal(ye[b].cpu().numpy(), want), f'exact kernel, stream {b}'
         assert _err(y[b].cpu().numpy(), want) <= tol, f'fast kernel, stream {b}: {_err(y[b].cpu().numpy(), want):.2e}'
     table.close()
+
+
+# ---- VND_MODE_EXACT in the window form: the reference's association, bit for bit ----
+@pytest.mark.parametrize('gname', ['g48k_k30', 'g48k_k128_u', 'g48k_k128_l', 'g44k_noenv'])
+@pytest.mark.parametrize('M,nt', [(32, 64), (16, 128), (32, 256)])
+def test_exact_mode_window_is_bit_identical(env, golden, monkeypatch, gname, M, nt):
+    """One accumulator per output, taps in table order, separately rounded products and sums, accumulators opened from
+    zero: the window form in exact mode must equal the oracle bit for bit - through ring refills and wraps, stream tails
+    inside a run and batches."""
+    d, native, ctx = env
+    fir = golden.fir(gname)
+    table = _table(native, ctx, fir)
+    monkeypatch.setenv('VND_SPEC_NT', str(nt))
+    rng = np.random.default_rng(23)
+    T = nt * M
+    for n in sorted({1, 2, 31, M + 1, T - 1, T, 2 * T + 3, 9001, 12346, 40003}):
+        for batch in (1, 3):
+            if batch > 1 and n % 2:
+                continue
+            x = rng.uniform(-1, 1, (batch, n, 2)).astype(np.float32)
+            x[rng.integers(0, batch, 50), rng.integers(0, n, 50), rng.integers(0, 2, 50)] = 0.0
+            want = np.stack([O.convolve_velvet_noise(x[b], fir) for b in range(batch)])
+            for min_span, rounds in ((1, 7), (2, 1)):
+                ctx.set_variant(FORCE | WIN[M] | span_bits(min_span, rounds))
+                text = table.describe(batch, n, 2, d.MODE_EXACT)
+                assert text.startswith('conv_spec_exact_window') and f'frames_per_lane={M} ' in text, text
+                got = table.convolve_host(x, d.MODE_EXACT)
+                assert np.array_equal(got, want), f'{gname} M={M} nt={nt} n={n} batch={batch} spans=({min_span},{rounds})'
+    ctx.set_variant(-1)
+    table.close()
+
+
+@pytest.mark.parametrize('name', sorted(__import__('json').loads((__import__('pathlib').Path(__file__).parent / 'golden' / 'manifest.json').read_text())['cls_convolve']))
+def test_exact_mode_window_class_path(env, golden, name):
+    """VelvetNoise.convolve's association (segments of -/+ unit taps, one multiply per segment, segments summed;
+    decorrelation.py:402-414) through the window form: the reference's sha256."""
+    from conftest import make_input
+    d, native, ctx = env
+    meta = golden.manifest['cls_convolve'][name]
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in golden.manifest['class_taps'][meta['class']]['kwargs'].items()}
+    vn = d.VelvetNoise(**kw)
+    x = make_input(meta['input'])
+    ctx.set_variant(FORCE | WIN[32] | span_bits(1, 3))
+    try:
+        y = vn.convolve(x)
+        in_scope = len(kw.get('filtered_channels', (0, 1))) == vn.num_outs == 2 and vn._device_table().max_index < 3000
+        launch = vn._device_table().describe(1, len(x), vn.num_outs, d.MODE_EXACT)
+        if in_scope and (x.ndim == 2 and x.shape[1] == 2):
+            assert launch.startswith('conv_spec_exact_window'), (name, launch)
+    finally:
+        ctx.set_variant(-1)
+    golden.expect(name, y, exact=x.dtype == np.float32, rtol_peak=TOL_PEAK)
+
+
+def test_dense_function_path_tables_take_the_exact_window_form_by_default(env, golden):
+    """Where taps share chunks and products (<= 2 B of LDS per sum: cfg3's 128 uniform taps) the exact mode's automatic
+    choice is the window form; cfg2's sparse table and the class-path tables keep the pair-read form."""
+    d, native, ctx = env
+    ctx.set_variant(-1)
+    dense, sparse = _table(native, ctx, golden.fir('g48k_k128_u')), _table(native, ctx, golden.fir('g48k_k30'))
+    assert dense.describe(24, 2880000, 2, d.MODE_EXACT).startswith('conv_spec_exact_window')
+    text = sparse.describe(128, 480000, 2, d.MODE_EXACT)
+    assert text.startswith('conv_spec_exact') and 'window' not in text, text
+    assert sparse.describe(128, 480000, 2, d.MODE_FAST).startswith('conv_spec_window')
+    dense.close(); sparse.close()

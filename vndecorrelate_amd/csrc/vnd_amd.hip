@@ -5,6 +5,7 @@
 #include "vnd_moments.hpp"
 #include "vnd_haas.hpp"
 #include "vnd_win.hpp"
+#include <functional>
 #include "../../include/vnd_amd.h"
 
 #include <dlfcn.h>
@@ -56,6 +57,7 @@ struct vnd_ctx {
     int lds_limit = 65536;        // bytes of LDS one workgroup may use
     hipStream_t stream = nullptr; // used by the *_host entry points
     hipStream_t stream2 = nullptr;    // second lane of the chunked host pipeline
+    std::vector<hipEvent_t> up_events;    // "piece k is on the device" marks of the time-chunked pipeline (made on first use)
     float *scratch_x = nullptr, *scratch_y = nullptr;
     size_t scratch_elems = 0;
     char *work = nullptr;         // grow-only workspace of the *_host entry points
@@ -700,6 +702,7 @@ vnd_status vnd_ctx_destroy(vnd_ctx *c)
     if (c->work) (void)hipFree(c->work);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    for (hipEvent_t ev : c->up_events) (void)hipEventDestroy(ev);
     delete c;
     return VND_OK;
 }
@@ -1080,6 +1083,75 @@ static vnd_status convolve_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, 
     return launch(ctx, t, x, y, batch, n, C, mode, (hipStream_t)stream, nullptr, Cx);
 }
 
+// Few long streams (the reference's own use is one file at a time, tests/test_example.py:19-49) are cut in TIME:
+// piece k = frames [f_k, f_k+1) of a stream.  Output frame n reads input frames n .. n + max_index
+// (decorrelation.py:656-658), so the launch of piece k runs over [f_k, f_k+1 + max_index) - the tail it computes
+// from an input that ends too early is overwritten by the launch of piece k + 1, on the same HIP stream - and needs
+// the upload of the piece that holds frame f_k+1 + max_index.  Uploads run on one HIP stream, kernels and downloads
+// on the other: the (CPU-staged) upload of piece k + 2 beside the kernel of piece k + 1 and the download of piece k.
+// Every kernel of this library computes an output frame the same way wherever it lies in a launch, so the result
+// is the unchunked call's, bit for bit in VND_MODE_EXACT.
+static int host_time_pieces(int64_t batch, int64_t n, size_t bytes)
+{
+    static const int off = [] { const char *e = getenv("VND_HOST_TIME_CHUNKS"); return e && e[0] == '0'; }();
+    if (off || batch > 4 || bytes < ((size_t)2 << 20) || n < 8 * 4096) return 1;
+    const size_t per_stream = bytes / (size_t)batch;
+    const int64_t want = (int64_t)std::max<size_t>(2, std::min<size_t>(8, per_stream / ((size_t)1 << 20)));
+    return (int)std::min<int64_t>(want, n / 4096);
+}
+
+static vnd_status host_time_pipeline(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch, int64_t n,
+                                     int32_t Cx, int32_t C, int pieces,
+                                     const std::function<vnd_status(const float *, float *, int64_t, hipStream_t)> &launch_piece)
+{
+    const int64_t total = batch * pieces;
+    while ((int64_t)ctx->up_events.size() < total) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ctx->up_events.push_back(ev);
+    }
+    // piece boundaries on 4096-frame marks: every piece starts 16-byte aligned whatever the channel count
+    auto first_frame = [&](int k) { return k >= pieces ? n : ((n * k / pieces) / 4096) * 4096; };
+    const int64_t halo = t->max_index;
+    vnd_status st = VND_OK;
+    hipError_t e = hipSuccess;
+    int64_t uploaded = 0;                                        // flat pieces handed to the upload stream so far
+    auto upload_through = [&](int64_t flat) {
+        for (; uploaded <= flat && e == hipSuccess; ++uploaded) {
+            const int64_t b = uploaded / pieces;
+            const int k = (int)(uploaded % pieces);
+            const int64_t f0 = first_frame(k), f1 = first_frame(k + 1);
+            const size_t xo = ((size_t)b * n + f0) * Cx;
+            if (f1 > f0) e = hipMemcpyAsync(ctx->scratch_x + xo, x + xo, (size_t)(f1 - f0) * Cx * sizeof(float), hipMemcpyHostToDevice, ctx->stream2);
+            if (e == hipSuccess) e = hipEventRecord(ctx->up_events[uploaded], ctx->stream2);
+        }
+    };
+    for (int64_t flat = 0; flat < total && st == VND_OK && e == hipSuccess; ++flat) {
+        const int64_t b = flat / pieces;
+        const int k = (int)(flat % pieces);
+        const int64_t f0 = first_frame(k), f1 = first_frame(k + 1);
+        if (f1 == f0) continue;
+        const int64_t reach = std::min(n, f1 + halo);            // the launch reads input frames [f0, reach)
+        int last = k;
+        while (last + 1 < pieces && first_frame(last + 1) < reach) ++last;
+        upload_through(b * pieces + last);
+        if (e != hipSuccess) break;
+        e = hipStreamWaitEvent(ctx->stream, ctx->up_events[b * pieces + last], 0);
+        if (e != hipSuccess) break;
+        const size_t xo = ((size_t)b * n + f0) * Cx, yo = ((size_t)b * n + f0) * C;
+        st = launch_piece(ctx->scratch_x + xo, ctx->scratch_y + yo, reach - f0, ctx->stream);
+        if (st != VND_OK) break;
+        e = hipMemcpyAsync(y + yo, ctx->scratch_y + yo, (size_t)(f1 - f0) * C * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    }
+    // whatever happened, nothing of this call is in flight when it returns: the caller's arrays and the
+    // context's staging buffers are free again
+    const hipError_t s1 = hipStreamSynchronize(ctx->stream), s2 = hipStreamSynchronize(ctx->stream2);
+    if (st != VND_OK) return st;
+    if (e == hipSuccess) e = s1 != hipSuccess ? s1 : s2;
+    if (e != hipSuccess) return fail(VND_ERR_HIP, "time-chunked host pipeline failed: %s", hipGetErrorString(e));
+    return VND_OK;
+}
+
 static vnd_status convolve_host(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
                                 int64_t n, int32_t Cx, int32_t C, int32_t mode)
 {
@@ -1096,19 +1168,32 @@ static vnd_status convolve_host(vnd_ctx *ctx, const vnd_taps *t, const float *x,
     // one group runs beside the kernel and the download of the one before (PCIe is full duplex, and a
     // download into pinned memory - vnd_host_alloc - does not hold the host thread).
     const int chunks = host_chunks(batch, (in_elems + out_elems) * sizeof(float));
-    for (int c = 0; c < chunks; ++c) {
+    if (chunks == 1) {
+        const int pieces = host_time_pieces(batch, n, (in_elems + out_elems) * sizeof(float));
+        if (pieces > 1)
+            return host_time_pipeline(ctx, t, x, y, batch, n, Cx, C, pieces, [&](const float *xd, float *yd, int64_t frames, hipStream_t s) {
+                return launch(ctx, t, xd, yd, 1, frames, C, mode, s, nullptr, Cx);
+            });
+    }
+    hipError_t e = hipSuccess;
+    for (int c = 0; c < chunks && st == VND_OK && e == hipSuccess; ++c) {
         const int64_t b0 = batch * c / chunks, b1 = batch * (c + 1) / chunks;
         if (b1 == b0) continue;
         hipStream_t s = (c & 1) ? ctx->stream2 : ctx->stream;
         const size_t xo = (size_t)b0 * n * Cx, yo = (size_t)b0 * n * C;
-        HIP_TRY(hipMemcpyAsync(ctx->scratch_x + xo, x + xo, (size_t)(b1 - b0) * n * Cx * sizeof(float), hipMemcpyHostToDevice, s));
+        e = hipMemcpyAsync(ctx->scratch_x + xo, x + xo, (size_t)(b1 - b0) * n * Cx * sizeof(float), hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) break;
         st = launch(ctx, t, ctx->scratch_x + xo, ctx->scratch_y + yo, b1 - b0, n, C, mode, s, nullptr, Cx);
         if (st != VND_OK) break;
-        HIP_TRY(hipMemcpyAsync(y + yo, ctx->scratch_y + yo, (size_t)(b1 - b0) * n * C * sizeof(float), hipMemcpyDeviceToHost, s));
+        e = hipMemcpyAsync(y + yo, ctx->scratch_y + yo, (size_t)(b1 - b0) * n * C * sizeof(float), hipMemcpyDeviceToHost, s);
     }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (chunks > 1) HIP_TRY(hipStreamSynchronize(ctx->stream2));
-    return st;
+    // on any failure too: copies and kernels of the earlier groups may still be in flight, and the caller is about
+    // to recycle its (pinned) result block, the next call this context's staging buffers
+    const hipError_t s1 = hipStreamSynchronize(ctx->stream), s2 = hipStreamSynchronize(ctx->stream2);
+    if (st != VND_OK) return st;
+    if (e == hipSuccess) e = s1 != hipSuccess ? s1 : s2;
+    if (e != hipSuccess) return fail(VND_ERR_HIP, "host pipeline failed: %s", hipGetErrorString(e));
+    return VND_OK;
 }
 
 vnd_status vnd_convolve_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
@@ -1527,20 +1612,25 @@ static vnd_status decorrelate_host(vnd_ctx *ctx, const vnd_taps *t, const float 
         st = ensure_work(ctx, (size_t)ws * 2);
         if (st != VND_OK) return st;
     }
-    for (int c = 0; c < chunks; ++c) {
+    hipError_t e = hipSuccess;
+    for (int c = 0; c < chunks && st == VND_OK && e == hipSuccess; ++c) {
         const int64_t b0 = batch * c / chunks, b1 = batch * (c + 1) / chunks;
         if (b1 == b0) continue;
         hipStream_t s = (c & 1) ? ctx->stream2 : ctx->stream;
         const size_t xo = (size_t)b0 * n * Cx, yo = (size_t)b0 * n * C;
-        HIP_TRY(hipMemcpyAsync(ctx->scratch_x + xo, x + xo, (size_t)(b1 - b0) * n * Cx * sizeof(float), hipMemcpyHostToDevice, s));
+        e = hipMemcpyAsync(ctx->scratch_x + xo, x + xo, (size_t)(b1 - b0) * n * Cx * sizeof(float), hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) break;
         st = decorrelate_dev(ctx, t, ctx->scratch_x + xo, ctx->scratch_y + yo, b1 - b0, n, Cx, C, mode, ms_encode, use_width,
                              width, normalize, eps, ctx->work + (size_t)(c & 1) * (size_t)ws, ws, s);
         if (st != VND_OK) break;
-        HIP_TRY(hipMemcpyAsync(y + yo, ctx->scratch_y + yo, (size_t)(b1 - b0) * n * C * sizeof(float), hipMemcpyDeviceToHost, s));
+        e = hipMemcpyAsync(y + yo, ctx->scratch_y + yo, (size_t)(b1 - b0) * n * C * sizeof(float), hipMemcpyDeviceToHost, s);
     }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (chunks > 1) HIP_TRY(hipStreamSynchronize(ctx->stream2));
-    return st;
+    // on any failure too: nothing of this call stays in flight behind its return (see convolve_host)
+    const hipError_t s1 = hipStreamSynchronize(ctx->stream), s2 = hipStreamSynchronize(ctx->stream2);
+    if (st != VND_OK) return st;
+    if (e == hipSuccess) e = s1 != hipSuccess ? s1 : s2;
+    if (e != hipSuccess) return fail(VND_ERR_HIP, "host pipeline failed: %s", hipGetErrorString(e));
+    return VND_OK;
 }
 
 vnd_status vnd_decorrelate_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch,
