@@ -110,3 +110,47 @@ def test_resident_example_chain_with_normaliser(vnd, golden):
         vnd.set_default_mode(vnd.MODE_EXACT)
         vnd.set_device_epilogue(None)
     assert np.max(np.abs(fused - want)) <= 5e-4 * peak
+
+
+def test_stateless_convolve_stage_stays_on_the_device(vnd, golden):
+    """The README's stateless stage (decorrelation.py:104-110: ``stateless(convolve_velvet_noise, velvet_noise_filters=fir)``)
+    inside a resident chain: velvet noise -> stateless convolution -> Haas without a host round trip between the
+    stages, bit-identical to the stage-by-stage chain; the buffers are the chain's own from the second call on."""
+    from vndecorrelate_amd import resident
+    fs = 48000
+    fir = vnd.generate_velvet_noise(duration_seconds=0.02, num_impulses=20, num_outs=2, sample_rate_hz=fs, seed=9)
+
+    def build(**kw):
+        return (vnd.SignalChain(sample_rate_hz=fs, **kw)
+                .velvet_noise(seed=4, normalizer=None)
+                .stateless(vnd.convolve_velvet_noise, velvet_noise_filters=fir)
+                .haas_effect(delay_time_seconds=0.001))
+
+    plain, res = build(), build(device_resident=True)
+    for seed in (60, 61):
+        x = make_input(dict(seed=seed, shape=[30011, 2]))
+        want, got = plain(x), res(x)
+        assert got.dtype == want.dtype and np.array_equal(got, want)
+        assert resident.transfers == {'to_host': 1, 'to_device': 1}, resident.transfers     # in once, out once
+    pool = res._resident_pool._buffers
+    first = {k: v.data_ptr() for k, v in pool.items()}
+    res(make_input(dict(seed=62, shape=[30011, 2])))
+    assert {k: v.data_ptr() for k, v in pool.items()} == first                             # nothing reallocated
+    # mode keyword, batched form
+    chain = (vnd.SignalChain(sample_rate_hz=fs, device_resident=True)
+             .stateless(vnd.convolve_velvet_noise_batched, velvet_noise_filters=fir, mode=vnd.MODE_EXACT))
+    xb = make_input(dict(seed=63, shape=[3, 5000, 2]))
+    assert np.array_equal(chain(xb), vnd.convolve_velvet_noise_batched(xb, fir))
+    assert resident.transfers == {'to_host': 1, 'to_device': 1}
+    # what has no device form keeps the host function, errors and quirks included: the positional form makes the
+    # SIGNAL the filter (SURVEY Appendix B #7); a float64 signal multiplies in float64
+    quirk_plain = vnd.SignalChain(sample_rate_hz=fs).stateless(vnd.convolve_velvet_noise, fir)
+    quirk_res = vnd.SignalChain(sample_rate_hz=fs, device_resident=True).stateless(vnd.convolve_velvet_noise, fir)
+    xq = make_input(dict(seed=64, shape=[1000, 2]))
+    assert np.array_equal(quirk_res(xq), quirk_plain(xq)) and quirk_res(xq).shape == fir.shape
+    x64 = make_input(dict(seed=65, shape=[4000, 2])).astype(np.float64)
+    chain64 = vnd.SignalChain(sample_rate_hz=fs, device_resident=True).stateless(vnd.convolve_velvet_noise, velvet_noise_filters=fir)
+    assert np.array_equal(chain64(x64), vnd.convolve_velvet_noise(x64, fir))
+    with pytest.raises(ValueError):
+        vnd.SignalChain(sample_rate_hz=fs, device_resident=True).stateless(
+            vnd.convolve_velvet_noise, velvet_noise_filters=fir[:, :1])(xq)

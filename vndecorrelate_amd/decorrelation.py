@@ -769,6 +769,7 @@ class SignalChain:
         self.num_outs = num_outs
         self.lazy = lazy
         self.device_resident = bool(device_resident)
+        self._resident_pool = None            # device buffers of a resident chain, reused from call to call
         self._hot = bool(_hot) or not lazy
         self._decorrelators: list = []
 
@@ -819,7 +820,9 @@ class SignalChain:
         self._init_decorrelators()
         if self.device_resident:
             from . import resident
-            return resident.run(self._decorrelators, input_signal)
+            if self._resident_pool is None:
+                self._resident_pool = resident.BufferPool()
+            return resident.run(self._decorrelators, input_signal, self._resident_pool)
         signal = input_signal
         for stage in self._decorrelators:
             signal = stage(signal)

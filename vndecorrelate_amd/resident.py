@@ -7,14 +7,24 @@ through the ``*_dev`` entry points of the C ABI, and the result comes back once:
 
 * ``VelvetNoise``  -> ``vnd_decorrelate[_fanout]_f32_dev`` (convolution + epilogue; float32)
 * ``HaasEffect``   -> ``vnd_haas_f64_dev`` (float64 ``(n + delay, 2)``, bit-identical)
-* anything else (``WhiteNoise``, ``stateless`` callables, custom normalisers) runs on the
-  host exactly as in the plain chain, with one download/upload around it.
+* ``stateless(convolve_velvet_noise, velvet_noise_filters=fir)`` (the README's stateless stage,
+  decorrelation.py:104-110, :630-660; also ``convolve_velvet_noise_batched``) -> ``vnd_convolve_f32_dev``
+  on a float32 signal with a float32 filter (the operand types NumPy multiplies in float32)
+* anything else (``WhiteNoise``, other ``stateless`` callables - the positional quirk form
+  ``stateless(convolve_velvet_noise, fir)`` included, which makes the SIGNAL the filter, SURVEY
+  Appendix B #7 -, custom normalisers, float64 operands) runs on the host exactly as in the plain
+  chain, with one download/upload around it.
+
+Output and workspace buffers are kept per chain and stage (``BufferPool``): a chain called in a loop
+on signals of one length allocates nothing after its first call.  ``transfers`` counts the host
+round trips of the last ``run`` (tests assert that device stages make none).
 
 torch is used for what it is here for: device buffers and the current stream.
 """
 from __future__ import annotations
 
-from typing import Sequence
+from functools import partial
+from typing import Optional, Sequence
 
 import numpy as np
 
@@ -32,7 +42,53 @@ def _torch():
     return torch
 
 
-def _velvet_on_device(stage, buf, torch, dec):
+transfers = {'to_host': 0, 'to_device': 0}      # of the last run(): downloads / uploads of the signal
+
+
+class BufferPool:
+    """Device buffers of one chain, keyed by (stage index, role): reused while shape and dtype stay the same."""
+
+    def __init__(self):
+        self._buffers: dict = {}
+
+    def get(self, torch, key, shape, dtype, device):
+        have = self._buffers.get(key)
+        if have is None or tuple(have.shape) != tuple(shape) or have.dtype != dtype or have.device != device:
+            have = self._buffers[key] = torch.empty(shape, dtype=dtype, device=device)
+        return have
+
+
+def _stateless_convolve_on_device(stage, buf, torch, dec, pool, key):
+    """``partial(convolve_velvet_noise[_batched], velvet_noise_filters=fir[, mode=...])`` on a device tensor
+    (decorrelation.py:104-110 stores the partial, :142 calls it with the signal), or None when this call has no
+    device form: the float64-promoting operand types, a 1-D signal (the reference raises IndexError there),
+    channel mismatches (ValueError) - the host function keeps every such behaviour."""
+    if not isinstance(stage, partial) or stage.args or stage.func not in (dec.convolve_velvet_noise, dec.convolve_velvet_noise_batched):
+        return None
+    kw = dict(stage.keywords)
+    fir = kw.pop('velvet_noise_filters', None)
+    mode = kw.pop('mode', None)
+    if kw or fir is None:
+        return None
+    fir = np.asarray(fir)
+    if fir.ndim == 1:
+        fir = fir[:, None]
+    batched = stage.func is dec.convolve_velvet_noise_batched
+    if buf.dtype != torch.float32 or fir.dtype != np.float32 or fir.ndim != 2 or buf.dim() != (3 if batched else 2):
+        return None
+    channels = buf.shape[-1]
+    if channels == 0 or buf.shape[-2] == 0 or fir.shape[1] != channels or (batched and buf.shape[0] == 0):
+        return None
+    table = dec._fir_tables.get(dec._fir_key(fir, channels), lambda: dec.function_path_arrays(fir, channels))
+    x = buf.contiguous()
+    y = pool.get(torch, (key, 'y'), tuple(x.shape), torch.float32, x.device)
+    batch = x.shape[0] if batched else 1
+    table.convolve_device(x.data_ptr(), y.data_ptr(), batch, x.shape[-2], channels,
+                          dec._default_mode if mode is None else mode, torch.cuda.current_stream(x.device).cuda_stream)
+    return y
+
+
+def _velvet_on_device(stage, buf, torch, dec, pool=None, key=None):
     """``VelvetNoise.decorrelate`` (decorrelation.py:417-442) on a device tensor, or None when this
     stage's configuration has no device form."""
     if not (stage.normalizer is None or stage.normalizer is rms_normalize):
@@ -50,9 +106,10 @@ def _velvet_on_device(stage, buf, torch, dec):
         return None
     x = x.to(torch.float32).contiguous()                   # to_float32 (utils/dsp.py:66-68)
     n, channels = x.shape
-    y = torch.empty((n, stage.num_outs), dtype=torch.float32, device=x.device)
+    pool = pool or BufferPool()
+    y = pool.get(torch, (key, 'y'), (n, stage.num_outs), torch.float32, x.device)
     ws_bytes = _native.decorrelate_workspace_bytes(1, n, stage.num_outs)
-    work = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    work = pool.get(torch, (key, 'work'), (ws_bytes,), torch.uint8, x.device)
     stage._device_table().decorrelate_device(
         x.data_ptr(), y.data_ptr(), 1, n, channels, mode=dec._default_mode, ms_encode=stage.mode == LayoutMode.MS,
         width=stage.width, normalize=dec._normalize_flag(stage.normalizer is not None), workspace_ptr=work.data_ptr(),
@@ -60,7 +117,7 @@ def _velvet_on_device(stage, buf, torch, dec):
     return y
 
 
-def _haas_on_device(stage, buf, torch):
+def _haas_on_device(stage, buf, torch, pool=None, key=None):
     """``HaasEffect.decorrelate`` (decorrelation.py:192-230) on a device tensor, or None."""
     delay = round(stage.delay_time_seconds * stage.sample_rate_hz)
     if delay < 0 or stage.delayed_channel not in (0, 1):
@@ -73,7 +130,7 @@ def _haas_on_device(stage, buf, torch):
         return None
     x = x.to(torch.float32).contiguous()
     n, channels = x.shape
-    y = torch.empty((n + delay, 2), dtype=torch.float64, device=x.device)
+    y = (pool or BufferPool()).get(torch, (key, 'y'), (n + delay, 2), torch.float64, x.device)
     if n + delay:
         _native.haas_device(_native.default_context(), x.data_ptr(), y.data_ptr(), 1, n, channels, delay=delay,
                             delayed_channel=stage.delayed_channel, ms_mode=stage.mode == LayoutMode.MS,
@@ -81,10 +138,14 @@ def _haas_on_device(stage, buf, torch):
     return y
 
 
-def run(stages: Sequence, input_signal: np.ndarray) -> np.ndarray:
-    """Feed ``input_signal`` through ``stages`` keeping the signal on the device between stages."""
+def run(stages: Sequence, input_signal: np.ndarray, pool: Optional[BufferPool] = None) -> np.ndarray:
+    """Feed ``input_signal`` through ``stages`` keeping the signal on the device between stages.
+    ``pool``: the calling chain's buffers (a stage's output stays valid until that stage runs again:
+    the result handed back to the caller is a host copy)."""
     from . import decorrelation as dec
     torch = _torch()
+    pool = pool or BufferPool()
+    transfers['to_host'] = transfers['to_device'] = 0
     device = torch.device('cuda', _native.default_context().device)
     host = np.asarray(input_signal)
     buf = None                                             # the signal lives in exactly one of host / buf
@@ -98,6 +159,7 @@ def run(stages: Sequence, input_signal: np.ndarray) -> np.ndarray:
             array = host if host.dtype in (np.float32, np.float64) else to_float32(host)
             buf = torch.from_numpy(np.ascontiguousarray(array)).to(device)
             host = None
+            transfers['to_device'] += 1
         return buf
 
     def to_host():
@@ -105,16 +167,23 @@ def run(stages: Sequence, input_signal: np.ndarray) -> np.ndarray:
         if host is None:
             host = buf.cpu().numpy()
             buf = None
+            transfers['to_host'] += 1
         return host
 
-    for stage in stages:
+    for index, stage in enumerate(stages):
         out = None
         if isinstance(stage, dec.VelvetNoise):
             frames = host.shape[0] if buf is None else buf.shape[0]
             if dec._use_device_epilogue(stage.num_outs, stage.normalizer is not None, frames, not odd_layout):
-                out = _velvet_on_device(stage, to_device(), torch, dec)
+                out = _velvet_on_device(stage, to_device(), torch, dec, pool, index)
         elif isinstance(stage, dec.HaasEffect):
-            out = _haas_on_device(stage, to_device(), torch)
+            out = _haas_on_device(stage, to_device(), torch, pool, index)
+        elif isinstance(stage, partial) and stage.func in (dec.convolve_velvet_noise, dec.convolve_velvet_noise_batched):
+            # (decided on what the signal IS: a float64 signal - Haas output - or one still on the host as int16 keeps
+            #  the host function and its promoting kernel)
+            current = buf if buf is not None else host
+            if current.dtype in (np.float32, torch.float32) and not odd_layout:
+                out = _stateless_convolve_on_device(stage, to_device(), torch, dec, pool, index)
         if out is not None:
             buf = out
             odd_layout = False                             # device stages produce C-ordered arrays
