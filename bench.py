@@ -24,10 +24,13 @@ The JSON line also carries
                 (oracle/vnd_oracle.py, single thread - NumPy slicing does not multithread) timed on
                 this host on a bounded number of cfg2 signals; rank 0, N=1 only;
   secondary     the other BASELINE configs on one GPU (cfg3, cfg5, cfg4; kernel ms, GB/s, the
-                binding limit named) - parity for them lives in tests/, these are rates only;
+                binding limit named), each with one stream of the timed output checked against the
+                C oracle (`parity_vs_oracle_of_peak`; the full-pool parity tests are tests/test_gpu_win.py);
   cfg4_strong   SURVEY 8(d) "Scaling (cfg4)": the 1024 x 1 s stereo batch split over the ranks with
                 distributed.shard_range, timed from "table broadcast done, shards resident" to "all
                 ranks done" (max over ranks); reported at every N, so N = 1/2/4/8 lines give the curve;
+                at N = 1 `projection` times what ONE rank does at N = 1/2/4/8 (1024/512/256/128 streams
+                per pass, rotating buffers) beside a plain device copy of the same shard;
   end_to_end    the synchronous host API (H2D + kernel + D2H) on pageable and pinned NumPy buffers,
                 N=1 only - PCIe-inclusive, never part of `value`.
 """
@@ -115,7 +118,7 @@ def cpu_baseline(budget_s: float) -> dict:
             'best_value': round(x.size / best / 1e6, 3)}
 
 
-def device_rate(torch, table, shape, mode, *, min_ms=30.0, buffers=1):
+def device_rate(torch, table, shape, mode, *, min_ms=30.0, buffers=1, taps=None):
     """Kernel milliseconds per launch of `table` over a resident (batch, n, C) pool (HIP events on the
     launch stream, >= min_ms timed after a clock-settling warm-up).  `buffers` > 1 rotates distinct
     pools so that small shapes still stream from HBM, not from the 256 MiB Infinity Cache."""
@@ -149,10 +152,26 @@ def device_rate(torch, table, shape, mode, *, min_ms=30.0, buffers=1):
         iters *= 2
     per = ms / iters
     bytes_per_launch = ALGO_BYTES_PER_SAMPLE * batch * n * c
-    return {'kernel_ms': round(per, 4), 'achieved_GBs': round(bytes_per_launch / (per * 1e-3) / 1e9, 1),
-            'frac_of_8TBs': round(bytes_per_launch / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            'Msamples_s': round(batch * n * c / (per * 1e-3) / 1e6, 1), 'launches_timed': iters,
-            'launch': table.describe(batch, n, c, mode)}
+    rec = {'kernel_ms': round(per, 4), 'achieved_GBs': round(bytes_per_launch / (per * 1e-3) / 1e9, 1),
+           'frac_of_8TBs': round(bytes_per_launch / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           'Msamples_s': round(batch * n * c / (per * 1e-3) / 1e6, 1), 'launches_timed': iters,
+           'launch': table.describe(batch, n, c, mode)}
+    if taps is not None:
+        # one stream of what the timed launches wrote, against the C oracle (the last stream: the highest addresses)
+        rec['parity_vs_oracle_of_peak'] = oracle_parity(xs[(iters - 1) % buffers][batch - 1], ys[(iters - 1) % buffers][batch - 1], taps, mode)
+        rec['parity_stream'] = batch - 1
+    return rec
+
+
+def oracle_parity(x_dev, y_dev, taps, mode, exact_mode=0):
+    """max |y - oracle| / max |oracle| of one device stream (0.0 and an assert in the bit-exact mode)."""
+    from oracle import c_oracle
+    want = c_oracle.convolve(x_dev.cpu().numpy(), *taps, threads=8)
+    got = y_dev.cpu().numpy()
+    if mode == exact_mode:
+        assert np.array_equal(got, want), 'exact mode differs from the oracle'
+        return 0.0
+    return float(np.max(np.abs(got.astype(np.float64) - want)) / np.max(np.abs(want)))
 
 
 def secondary_configs(torch, vnd, _native, ctx, mode) -> dict:
@@ -163,18 +182,19 @@ def secondary_configs(torch, vnd, _native, ctx, mode) -> dict:
     def table_of(**kw):
         fir = vnd.generate_velvet_noise(**kw)
         a = function_path_arrays(fir)
-        return _native.TapTable.create(ctx, a.tap_offsets, a.tap_index, a.tap_weight)
+        return _native.TapTable.create(ctx, a.tap_offsets, a.tap_index, a.tap_weight), (a.tap_offsets, a.tap_index, a.tap_weight)
 
     specs = [
         ('cfg3', dict(duration_seconds=0.03, num_impulses=128, num_outs=2, sample_rate_hz=48000,
                       log_distribution_strength=0.0, seed=1), (24, 2880000, 2), 1,
          '48 kHz stereo, 60 s, 128 taps (segmented decay, kappa 0); pool of 24',
-         'LDS bandwidth: 870 B of LDS reads per 16 B of HBM traffic, LDS busy 0.74 of CU-cycles (profiles/r02_cfg3_cfg5_pmc.txt)'),
+         'vector issue and its waits: 128 FMAs per sample; the window form reads 183 B of LDS per sample (435 in round 2) and is '
+         'no longer on the power cap (profiles/r03_cfg3_window_pmc.txt)'),
         ('cfg3_kappa1', dict(duration_seconds=0.03, num_impulses=128, num_outs=2, sample_rate_hz=48000,
                              log_distribution_strength=1.0, seed=1), (24, 2880000, 2), 1,
          '48 kHz stereo, 60 s, 128 impulses log-distributed (kappa 1): the function path keeps 123 distinct taps per channel '
          '(last write wins on duplicate indices, SURVEY 8d); pool of 24',
-         'LDS bandwidth, as cfg3'),
+         'as cfg3'),
         ('cfg5', dict(duration_seconds=0.03, num_impulses=64, num_outs=8, sample_rate_hz=96000, seed=1),
          (16, 960000, 8), 1, '96 kHz 8-channel, 10 s, 64 log-distributed taps; pool of 16',
          'L2 request rate: a workgroup owns one channel pair, so lanes load/store 8 B of each 32-B frame - 77 M requests per launch, '
@@ -185,8 +205,10 @@ def secondary_configs(torch, vnd, _native, ctx, mode) -> dict:
     ]
     for name, kw, shape, buffers, what, limit in specs:
         try:
-            t = table_of(**kw)
-            r = device_rate(torch, t, shape, mode, buffers=buffers)
+            t, taps = table_of(**kw)
+            r = device_rate(torch, t, shape, mode, buffers=buffers, taps=taps)
+            tol = 2e-6 if kw['num_impulses'] > 64 else 1e-6           # (128 taps: the reference's own two paths differ by 1.2e-6)
+            assert r['parity_vs_oracle_of_peak'] <= tol, f"{name}: timed output off by {r['parity_vs_oracle_of_peak']:.2e} of peak"
             r.update({'workload': what, 'binding_limit': limit})
             out[name] = r
             t.close()
@@ -335,7 +357,44 @@ def next_rows(torch, vnd, _native) -> dict:
     return out
 
 
-def cfg4_strong(torch, dist, vnd, _native, ctx, table_image, mode, world, rank, device, backend) -> dict:
+def shard_projection(torch, table, n, mode, stream) -> dict:
+    """What ONE rank does per pass of the cfg4 strong-scaling leg at N = 1, 2, 4, 8 (1024 / N streams, rotating
+    buffers so that a 49 MB shard still streams from HBM), beside a plain device copy of the same shard: the
+    one-GPU projection of the 8-GPU speed-up (no 8-GPU node is available to the builder)."""
+    out = {}
+    base = None
+    for ranks in (1, 2, 4, 8):
+        mine = 1024 // ranks
+        buffers = max(1, int(np.ceil(600e6 / (mine * n * CHANNELS * 4 * 2))))
+        xs = [torch.empty((mine, n, CHANNELS), dtype=torch.float32, device='cuda').uniform_(-1, 1) for _ in range(buffers)]
+        ys = [torch.empty_like(xs[0]) for _ in range(buffers)]
+
+        def timed_loop(fn, reps):
+            for i in range(reps // 2):
+                fn(i)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for i in range(reps):
+                fn(i)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        reps = 100 * ranks
+        ms = timed_loop(lambda i: table.convolve_device(xs[i % buffers].data_ptr(), ys[i % buffers].data_ptr(), mine, n, CHANNELS, mode, stream), reps)
+        copy_ms = timed_loop(lambda i: ys[i % buffers].copy_(xs[i % buffers]), reps)
+        base = base or ms
+        out[f'N={ranks}'] = {'streams_per_rank': mine, 'us_per_pass': round(ms * 1e3, 2), 'device_copy_us': round(copy_ms * 1e3, 2),
+                             'speedup_vs_N1': round(base / ms, 2), 'launch': table.describe(mine, n, CHANNELS, mode)[:96]}
+        del xs, ys
+        torch.cuda.empty_cache()
+    out['note'] = ('kernel time between HIP events on the launch stream, back-to-back passes over rotating buffers; the 8-GPU job '
+                   'adds one barrier per timed region, not per pass')
+    return out
+
+
+def cfg4_strong(torch, dist, vnd, _native, ctx, table_image, mode, world, rank, device, backend, taps=None) -> dict:
     """SURVEY 8(d) scaling leg: 1024 x 1 s stereo streams, contiguous shards, no data-path collective."""
     from vndecorrelate_amd.distributed import shard_range
     table = _native.TapTable.from_bytes(ctx, table_image)
@@ -376,7 +435,18 @@ def cfg4_strong(torch, dist, vnd, _native, ctx, table_image, mode, world, rank, 
         elapsed = float(t.item())
     per = elapsed / steps
     total = streams * n * CHANNELS
+    parity = None
+    if rank == 0 and taps is not None:
+        last = (steps - 1) % buffers
+        parity = oracle_parity(xs[last][mine - 1], ys[last][mine - 1], taps, mode)
+        assert parity <= 1e-6, f'cfg4_strong: timed output off by {parity:.2e} of peak'
+    projection = None
+    if world == 1:
+        del xs, ys
+        torch.cuda.empty_cache()
+        projection = shard_projection(torch, table, n, mode, stream)
     return {'streams': streams, 'frames_per_stream': n, 'ranks': world, 'streams_on_rank0': mine, 'steps': steps,
+            'parity_vs_oracle_of_peak': parity, 'projection': projection,
             'ms_per_pass_max_over_ranks': round(per * 1e3, 4), 'Msamples_s': round(total / per / 1e6, 1),
             'aggregate_GBs': round(ALGO_BYTES_PER_SAMPLE * total / per / 1e9, 1),
             'timed_from': 'table broadcast done, shards resident; barrier + sync both sides, max over ranks',
@@ -469,23 +539,27 @@ def main():
 
     elapsed, kernel_ms = timed(mode, args.steps, args.warmup)
     timed_ms = elapsed * 1e3
-    y_timed = y[args.pool - 1].cpu().numpy() if rank == 0 else None
+    checked = sorted({0, args.pool // 2, args.pool - 1})      # first, middle, last stream (the last: past 4 GiB of offsets)
+    y_timed = {b: y[b].cpu().numpy() for b in checked} if rank == 0 else None
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # spot-check the timed output against the oracle on one stream (rank 0)
+    # spot-check the timed output against the oracle on three streams (rank 0)
     if rank == 0:
         from oracle import c_oracle
-        xs = x[args.pool - 1].cpu().numpy()
-        want = c_oracle.convolve(xs, arrays.tap_offsets, arrays.tap_index, arrays.tap_weight, threads=8)
-        if mode == vnd.MODE_EXACT:
-            assert np.array_equal(y_timed, want), 'bench output differs from the oracle'
-        else:
-            parity = float(np.max(np.abs(y_timed.astype(np.float64) - want)) / np.max(np.abs(want)))
-            assert parity <= 1e-6, f'bench output off by {parity:.2e} of peak'
+        parity = 0.0
+        for b in checked:
+            xs = x[b].cpu().numpy()
+            want = c_oracle.convolve(xs, arrays.tap_offsets, arrays.tap_index, arrays.tap_weight, threads=8)
+            if mode == vnd.MODE_EXACT:
+                assert np.array_equal(y_timed[b], want), f'bench output differs from the oracle (stream {b})'
+            else:
+                err = float(np.max(np.abs(y_timed[b].astype(np.float64) - want)) / np.max(np.abs(want)))
+                assert err <= 1e-6, f'bench output off by {err:.2e} of peak (stream {b})'
+                parity = max(parity, err)
 
     # the bit-exact mode on the same pool, reported beside the headline (not part of `value`)
     exact_info = None
@@ -549,7 +623,8 @@ def main():
 
     strong = None
     if not args.no_secondary:
-        strong = cfg4_strong(torch, dist, vnd, _native, ctx, image, mode, world, rank, device, args.backend)
+        strong = cfg4_strong(torch, dist, vnd, _native, ctx, image, mode, world, rank, device, args.backend,
+                             taps=(arrays.tap_offsets, arrays.tap_index, arrays.tap_weight) if rank == 0 else None)
 
     if rank == 0:
         value = world * samples_per_step * args.steps / elapsed / 1e6
@@ -577,6 +652,7 @@ def main():
                        'pool_signals_per_gpu': args.pool, 'frames': n, 'channels': CHANNELS,
                        'Mframes_per_s': round(value / CHANNELS, 1),
                        'arithmetic': args.mode, 'parity_vs_oracle_of_peak': (0.0 if mode == vnd.MODE_EXACT else parity),
+                       'parity_streams_checked': checked,
                        'launch': launch_text, 'exact_mode': exact_info,
                        'sharding': 'independent streams per rank; RCCL broadcast of the tap table only'},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
@@ -584,8 +660,8 @@ def main():
                          'traffic_source': traffic_source,
                          'read_only_frac': round(achieved / 2 / HBM_PEAK_GBS, 4),
                          'kernel_ms': round(kernel_ms, 4), 'device_copy_GBs': round(copy_gbs, 1),
-                         'limit': 'board power cap (1400 W; the shader clock falls to ~1.9 GHz under this kernel), '
-                                  'DESIGN.md 3.5',
+                         'limit': 'board power cap (1400 W; the shader clock falls to ~1.9 GHz under this kernel: '
+                                  'profiles/r03_cfg2_power.txt), DESIGN.md 3.5',
                          'algorithmic_bytes_per_launch': ALGO_BYTES_PER_SAMPLE * samples_per_step},
         }
         if strong is not None:
