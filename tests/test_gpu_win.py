@@ -41,7 +41,7 @@ def _err(got, want):
 
 
 @pytest.mark.parametrize('gname', ['g48k_k30', 'g48k_k128_u', 'g44k_noenv'])
-@pytest.mark.parametrize('M,nt', [(32, 64), (16, 128), (64, 64), (32, 128)])
+@pytest.mark.parametrize('M,nt', [(32, 192), (16, 128), (64, 64), (32, 128), (16, 64)])
 def test_window_geometries_seams_and_tails(env, golden, monkeypatch, gname, M, nt):
     """Every length class around the tile (nt * M frames) and the ring, spans of one tile and more (ring refills,
     wraps of the ring's entry positions, units following each other in one workgroup), stream tails inside a lane's
@@ -81,7 +81,7 @@ def test_window_results_do_not_depend_on_the_geometry(env, golden, monkeypatch):
     x = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1)
     s = torch.cuda.current_stream().cuda_stream
     results = []
-    for M, nt, spans in ((32, 256, (1, 2)), (32, 64, (2, 1)), (16, 128, (1, 5)), (64, 64, (3, 1)), (16, 256, (1, 1))):
+    for M, nt, spans in ((32, 256, (1, 2)), (32, 128, (2, 1)), (16, 128, (1, 5)), (64, 64, (3, 1)), (16, 64, (1, 1))):
         monkeypatch.setenv('VND_SPEC_NT', str(nt))
         ctx.set_variant(FORCE | WIN[M] | span_bits(*spans))
         assert f'frames_per_lane={M} ' in table.describe(pool, n, 2, d.MODE_FAST)
@@ -146,7 +146,7 @@ def test_pools_at_bench_shapes_match_the_oracle(env, golden, name):
 
 # ---- VND_MODE_EXACT in the window form: the reference's association, bit for bit ----
 @pytest.mark.parametrize('gname', ['g48k_k30', 'g48k_k128_u', 'g48k_k128_l', 'g44k_noenv'])
-@pytest.mark.parametrize('M,nt', [(32, 64), (16, 128), (32, 256)])
+@pytest.mark.parametrize('M,nt', [(32, 192), (16, 128), (32, 256)])
 def test_exact_mode_window_is_bit_identical(env, golden, monkeypatch, gname, M, nt):
     """One accumulator per output, taps in table order, separately rounded products and sums, accumulators opened from
     zero: the window form in exact mode must equal the oracle bit for bit - through ring refills and wraps, stream tails
@@ -207,3 +207,21 @@ def test_dense_function_path_tables_take_the_exact_window_form_by_default(env, g
     assert text.startswith('conv_spec_exact') and 'window' not in text, text
     assert sparse.describe(128, 480000, 2, d.MODE_FAST).startswith('conv_spec_window')
     dense.close(); sparse.close()
+
+
+def test_a_window_build_that_spills_is_rejected_and_the_launch_still_right(env, golden, monkeypatch):
+    """The window form lives on its registers (about 240 of the 256 a lane has at two waves per SIMD with 32-frame runs): a
+    build that spills is refused - here the one geometry known to, 32-frame runs in one-wave workgroups - and the launch
+    takes the next geometry or the pair-read form; never a wrong result, never a CPU path."""
+    d, native, ctx = env
+    fir = golden.fir('g48k_k30')
+    table = _table(native, ctx, fir)
+    monkeypatch.setenv('VND_SPEC_NT', '64')
+    x = np.random.default_rng(8).uniform(-1, 1, (3, 40000, 2)).astype(np.float32)
+    want = np.stack([O.convolve_velvet_noise(x[b], fir) for b in range(3)])
+    ctx.set_variant(FORCE | WIN[32])
+    text = table.describe(3, 40000, 2, d.MODE_FAST)
+    assert text.startswith('conv_spec'), text                      # (whichever form was built: a per-table kernel)
+    assert _err(table.convolve_host(x, d.MODE_FAST), want) <= TOL_PEAK
+    ctx.set_variant(-1)
+    table.close()

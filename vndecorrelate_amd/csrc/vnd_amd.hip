@@ -5,6 +5,7 @@
 #include "vnd_moments.hpp"
 #include "vnd_haas.hpp"
 #include "vnd_win.hpp"
+#include <atomic>
 #include <functional>
 #include "../../include/vnd_amd.h"
 
@@ -445,14 +446,25 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     // the WINDOW form (vnd_win.hpp: a lane owns win_m consecutive frames and reads the union of its taps' windows once):
     // stereo outputs, fast mode
     bool picked = false;
-    if (win_m > 0 && C == 2 && rr_hint == 0 && (mode == VND_MODE_FAST || win_exact))
-        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, bc, &p.cfg);
+    if (win_m > 0 && C == 2 && rr_hint == 0 && (mode == VND_MODE_FAST || win_exact)) {
+        // (a geometry whose build failed or spilled is remembered in the table's module map: skipped, the next best taken)
+        const bool nt_big = batch * n * C * (int64_t)sizeof(float) >= ((int64_t)64 << 20);
+        auto rejected = [&](const SpecConfig &c0) {
+            SpecConfig c = c0;
+            c.nt_stores = nt_big ? 1 : 0; c.exact = mode == VND_MODE_EXACT ? 1 : 0; c.epi = pointwise ? 1 : 0; c.bc = bc ? 1 : 0;
+            std::lock_guard<std::mutex> g(const_cast<vnd_taps *>(t)->spec_mutex);
+            auto it = t->spec_modules.find(c);
+            return it != t->spec_modules.end() && it->second->failed;
+        };
+        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, bc, &p.cfg, rejected);
+    }
     if (!picked && !spec_pick_config(t->spec_table, (size_t)ctx->lds_limit, rr_hint, dd_hint, &p.cfg, attempt == 1 || C != 2, bc, mode == VND_MODE_EXACT)) { p.why = "halo does not fit the ring"; return p; }
     const int64_t T = p.cfg.tile();
     const int64_t tiles_total = (n + T - 1) / T;
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     // resident workgroups per CU: LDS-bound, within the 32 waves a CU holds
-    const int64_t per_cu = std::min<int64_t>(std::min<int64_t>(16, 2048 / p.cfg.nt), (int64_t)(160 * 1024) / (int64_t)p.cfg.lds_bytes());
+    const int64_t per_cu = p.cfg.win ? p.cfg.win_per_cu
+                                     : std::min<int64_t>(std::min<int64_t>(16, 2048 / p.cfg.nt), (int64_t)(160 * 1024) / (int64_t)p.cfg.lds_bytes());
     const int64_t resident = (int64_t)cus * std::max<int64_t>(per_cu, 1);
     const int64_t units = batch * (C / 2);                     // (stream, channel pair)
     // a workgroup needs a span long enough to amortise filling its ring: 8 tiles when there are 16 and more per resident
@@ -527,10 +539,11 @@ static SpecModule *spec_module(vnd_ctx *ctx, const vnd_taps *t_, const SpecConfi
 }
 
 static vnd_status launch_spec(vnd_ctx *ctx, const vnd_taps *t, const SpecPlan &p, const float *x, float *y, int64_t n,
-                              hipStream_t stream, bool *launched, const EpiFuse *epi = nullptr)
+                              hipStream_t stream, bool *launched, const EpiFuse *epi = nullptr, bool *built = nullptr)
 {
     *launched = false;
     SpecModule *m = spec_module(ctx, t, p.cfg, !p.eager);
+    if (built) *built = !(m && m->failed);                   // false: a build was tried and failed (not: none was tried)
     if (!m || m->failed) return VND_OK;                      // generic kernel instead
     SpecArgs a{};
     a.x = x; a.y = y; a.n = n;
@@ -560,13 +573,13 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
 {
     if (batch == 0 || n == 0) return VND_OK;
     if (Cx == 0) Cx = C;
-    {
+    for (int attempt = 0; attempt < 4; ++attempt) {
         const SpecPlan sp = make_spec_plan(ctx, t, x, y, batch, n, C, Cx, mode, epi);
-        if (sp.use) {
-            bool launched = false;
-            vnd_status st = launch_spec(ctx, t, sp, x, y, n, stream, &launched, epi);
-            if (st != VND_OK || launched) return st;
-        }
+        if (!sp.use) break;
+        bool launched = false, built = true;
+        vnd_status st = launch_spec(ctx, t, sp, x, y, n, stream, &launched, epi, &built);
+        if (st != VND_OK || launched) return st;
+        if (!sp.cfg.win || built) break;                          // (a failed window build: plan again, that geometry is skipped now)
     }
     const Plan p = make_plan(ctx, t, batch, n, C, mode, Cx);
     KArgs a{};
@@ -1091,13 +1104,20 @@ static vnd_status convolve_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, 
 // on the other: the (CPU-staged) upload of piece k + 2 beside the kernel of piece k + 1 and the download of piece k.
 // Every kernel of this library computes an output frame the same way wherever it lies in a launch, so the result
 // is the unchunked call's, bit for bit in VND_MODE_EXACT.
-static int host_time_pieces(int64_t batch, int64_t n, size_t bytes)
+static int host_time_pieces(int64_t batch, int64_t n, size_t bytes, bool pinned)
 {
-    static const int off = [] { const char *e = getenv("VND_HOST_TIME_CHUNKS"); return e && e[0] == '0'; }();
-    if (off || batch > 4 || bytes < ((size_t)2 << 20) || n < 8 * 4096) return 1;
-    const size_t per_stream = bytes / (size_t)batch;
-    const int64_t want = (int64_t)std::max<size_t>(2, std::min<size_t>(8, per_stream / ((size_t)1 << 20)));
-    return (int)std::min<int64_t>(want, n / 4096);
+    // Measured (tools/host_pieces_try.py, profiles/r03_host_pieces.txt): every extra copy call costs ~50 us of fixed time on
+    // this platform, so one 10 s signal (3.84 MB each way, 0.20 ms in one piece) only loses - 0.25 ms in 2 pieces, 0.36 in
+    // 6 - and a pageable 60 s one too (its upload is staged by the CPU, call by call); a PAGE-LOCKED 60 s stream gains 5 %
+    // with 4 pieces (0.85 vs 0.90 ms).  So: page-locked input of 16 MB and more per stream; VND_HOST_TIME_PIECES forces.
+    const char *e_off = getenv("VND_HOST_TIME_CHUNKS"), *e_forced = getenv("VND_HOST_TIME_PIECES");     // (a host call is ms-scale)
+    const bool off = e_off && e_off[0] == '0';
+    const int forced = e_forced ? atoi(e_forced) : 0;
+    if (off || batch > 4 || n < 8 * 4096) return 1;
+    if (forced > 0) return (int)std::min<int64_t>(forced, n / 4096);
+    const size_t per_stream = bytes / (size_t)batch / 2;
+    if (per_stream < ((size_t)16 << 20) || !pinned) return 1;
+    return (int)std::min<int64_t>(4, n / 4096);
 }
 
 static vnd_status host_time_pipeline(vnd_ctx *ctx, const vnd_taps *t, const float *x, float *y, int64_t batch, int64_t n,
@@ -1169,7 +1189,10 @@ static vnd_status convolve_host(vnd_ctx *ctx, const vnd_taps *t, const float *x,
     // download into pinned memory - vnd_host_alloc - does not hold the host thread).
     const int chunks = host_chunks(batch, (in_elems + out_elems) * sizeof(float));
     if (chunks == 1) {
-        const int pieces = host_time_pieces(batch, n, (in_elems + out_elems) * sizeof(float));
+        hipPointerAttribute_t attr{};
+        const bool pinned = hipPointerGetAttributes(&attr, x) == hipSuccess && attr.type == hipMemoryTypeHost;
+        (void)hipGetLastError();                                  // (an ordinary pageable pointer reports an error: not ours)
+        const int pieces = host_time_pieces(batch, n, (in_elems + out_elems) * sizeof(float), pinned);
         if (pieces > 1)
             return host_time_pipeline(ctx, t, x, y, batch, n, Cx, C, pieces, [&](const float *xd, float *yd, int64_t frames, hipStream_t s) {
                 return launch(ctx, t, xd, yd, 1, frames, C, mode, s, nullptr, Cx);
@@ -1347,7 +1370,7 @@ vnd_status vnd_window_kernel_source(int32_t C, const int32_t *tap_offsets, const
         return fail(VND_ERR_UNSUPPORTED, "this window geometry does not fit the LDS");
     SpecConfig cfg;
     cfg.nt = threads; cfg.win = frames_per_lane; cfg.win_g = g.G; cfg.win_lds = (int)g.lds_bytes();
-    cfg.la = spec_env("VND_SPEC_LA", 6);
+    cfg.la = spec_env("VND_SPEC_LA", frames_per_lane >= 32 ? 4 : 6);
     cfg.exact = mode == VND_MODE_EXACT ? 1 : 0;
     if (lds_bytes_per_tile || fmas_per_tile) {
         size_t lb = 0, fm = 0;
@@ -1379,10 +1402,15 @@ static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64
     if (st != VND_OK) return st;
     if (!text || len <= 0) return fail(VND_ERR_INVALID, "null text buffer");
     // the pointers only decide alignment: describe the launch of 256-byte-aligned buffers (hipMalloc's)
-    const SpecPlan sp = make_spec_plan(ctx, t, nullptr, nullptr, batch, n, C, Cx, mode, nullptr);
-    if (sp.use) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        const SpecPlan sp = make_spec_plan(ctx, t, nullptr, nullptr, batch, n, C, Cx, mode, nullptr);
+        if (!sp.use) break;
         DeviceScope on(ctx->device);
         SpecModule *m = spec_module(ctx, t, sp.cfg, !sp.eager);
+        if (m && m->failed && sp.cfg.win && attempt < 3) {         // as launch(): plan again without that geometry
+            if (getenv("VND_SPEC_VERBOSE")) fprintf(stderr, "vnd: window form (frames_per_lane=%d threads=%d) unavailable: %s\n", sp.cfg.win, sp.cfg.nt, m->log.c_str());
+            continue;
+        }
         if (m && !m->failed) {
             if (sp.cfg.win) {
                 snprintf(text, (size_t)len,
@@ -1400,6 +1428,7 @@ static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64
             return VND_OK;
         }
         if (m && getenv("VND_SPEC_VERBOSE")) fprintf(stderr, "vnd: specialised kernel unavailable: %s\n", m->log.c_str());
+        break;
     }
     const Plan p = make_plan(ctx, t, batch, n, C, mode, Cx);
     if (p.direct)

@@ -46,7 +46,7 @@ struct SpecConfig {
     int shift = 0;     // exact mode: a second copy of every plane, one frame ahead, so that odd offsets are aligned pairs
     // WINDOW form (vnd_win.hpp): win = consecutive output frames per lane (0: the pair-read kernel above),
     // win_g = entries one base register reaches, win_lds = its LDS footprint (the halo is the table's)
-    int win = 0, win_g = 0, win_lds = 0;
+    int win = 0, win_g = 0, win_lds = 0, win_per_cu = 0;    // (win_per_cu: workgroups a CU holds - LDS and registers)
     int tile() const { return win ? nt * win : 2 * nt * rr; }
     size_t lds_bytes() const
     {
@@ -505,6 +505,18 @@ inline bool spec_compile(const SpecTable &t, const SpecConfig &cfg, int device, 
         if (!path.empty()) (void)remove(path.c_str());        // a cached object this runtime cannot load: next time, compile
         m->failed = true; m->log += " (module load failed)";
         return false;
+    }
+    if (cfg.win) {
+        // the window form lives on its registers: a build that spills (private memory per lane) streams the spill through
+        // the caches at every tile - slower than the pair-read form it was meant to beat.  Rejected; the caller falls back.
+        int local = 0;
+        if (hipFuncGetAttribute(&local, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, m->fn) == hipSuccess && local > 0 && !getenv("VND_WIN_ALLOW_SPILL")) {
+            (void)hipModuleUnload(m->module);
+            m->module = nullptr; m->fn = nullptr;
+            m->failed = true;
+            m->log += " (window form spills " + std::to_string(local) + " bytes of registers per lane: rejected)";
+            return false;
+        }
     }
     if (cfg.lds_bytes() > 65536)
         (void)hipFuncSetAttribute((const void *)m->fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_limit);

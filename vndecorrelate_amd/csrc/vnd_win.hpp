@@ -13,6 +13,7 @@
 #pragma once
 #include "vnd_spec.hpp"
 #include <cmath>
+#include <functional>
 
 namespace vnd {
 
@@ -48,6 +49,18 @@ inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size
     if ((size_t)(qc - 1) * g->plane + (size_t)G * 16 >= 65536) return false;      // ds offset field
     if ((size_t)qc * g->plane >= 65536 && !bc) return false;                       // channel 1's planes as an immediate
     return g->lds_bytes() <= lds_limit;
+}
+
+// Workgroups a CU holds: LDS-bound, and register-bound - a lane carries its runs' accumulators, the outputs of the first
+// channel and a tile of prefetched frames (about 250 VGPRs with 32-frame runs, 150 with 16, more than 256 with 64), so
+// at most 2 / 3 / 1 waves per SIMD; a budget below that would spill the prefetch to scratch (measured: 3x slower).
+inline int win_waves_per_simd_max(int M) { return M <= 16 ? 3 : (M <= 32 ? 2 : 1); }
+
+inline int win_workgroups_per_cu(const WinGeom &g)
+{
+    const int by_lds = (int)std::min<size_t>(std::min<size_t>(16, 2048 / g.nt), (160 * 1024) / g.lds_bytes());
+    const int by_regs = std::max(1, win_waves_per_simd_max(g.M) * 4 / (g.nt / 64));
+    return std::max(1, std::min(by_lds, by_regs));
 }
 
 struct WinOp { int kind, acc, half; float w; };          // kind 0: E pair, 1: P pair, 2: O0 (second element of the half), 3: OL (first)
@@ -346,9 +359,8 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
     spec_append(s, "#define VW_NT_STORES %d\n#define VW_EPI %d\n#define VW_BC %d\n#define VW_EXACT %d\n", c.nt_stores, c.epi, c.bc, c.exact);
     spec_append(s, "#define VW_NT_STORE_AUX %d\n", spec_env("VND_SPEC_STORE_AUX", 2));
     spec_append(s, "#define VW_LOAD_AUX %d\n", spec_env("VND_SPEC_LOAD_AUX", 2));
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, 2048 / g.nt), (160 * 1024) / g.lds_bytes()));
-    const int waves = (per_cu * (g.nt / 64) + 3) / 4;
-    spec_append(s, "#define VW_WAVES_PER_EU %d\n", std::max(1, std::min(waves, 8)));
+    const int waves = (win_workgroups_per_cu(g) * (g.nt / 64) + 3) / 4;
+    spec_append(s, "#define VW_WAVES_PER_EU %d\n", std::max(1, std::min(waves, win_waves_per_simd_max(g.M))));
     return s;
 }
 
@@ -367,7 +379,8 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
 
 // geometry choice: the largest workgroup whose ring (tile + halo, mirror) still fits; small_tiles starts lower
 // (short streams: a ring is filled once per span)
-inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool small_tiles, bool bc, SpecConfig *out)
+inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool small_tiles, bool bc, SpecConfig *out,
+                            const std::function<bool(const SpecConfig &)> &rejected = nullptr)
 {
     // the geometry that keeps the most waves on a CU (the ring is LDS-bound: tile + halo per workgroup), the larger
     // workgroup on a tie (the halo is shared by more lanes); short streams (small_tiles: a ring is filled once per
@@ -382,14 +395,17 @@ inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool sm
             if (g_env > 0) G = g_env;
             WinGeom g;
             if (win_geometry(t, M, nt, G, bc, lds_limit, &g)) {
-                const int per_cu = (int)std::min<size_t>(std::min<size_t>(16, 2048 / nt), (160 * 1024) / g.lds_bytes());
-                const int waves = per_cu * (nt / 64);
+                const int waves = win_workgroups_per_cu(g) * (nt / 64);
                 if (waves > best_waves) {
-                    best_waves = waves;
                     SpecConfig c;
                     c.nt = nt; c.win = M; c.win_g = G; c.win_lds = (int)g.lds_bytes(); c.bc = bc ? 1 : 0;
-                    c.la = spec_env("VND_SPEC_LA", 6);
+                    c.win_per_cu = win_workgroups_per_cu(g);
+                    // reads kept in flight: each holds 4 registers, and 32-frame runs already live at ~240 of the 256 a lane
+                    // has at two waves per SIMD (measured: 3 to 10 reads ahead run the same, tools/win_try.py)
+                    c.la = spec_env("VND_SPEC_LA", M >= 32 ? 4 : 6);
                     c.rr = 0; c.pp = 0; c.dd = 0;
+                    if (rejected && rejected(c)) continue;          // a build of this geometry failed or spilled before
+                    best_waves = waves;
                     *out = c;
                 }
             }
