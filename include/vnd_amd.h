@@ -292,6 +292,16 @@ vnd_status vnd_describe_fanout_launch(vnd_ctx *ctx, const vnd_taps *taps, int64_
                                       int64_t n_frames, int32_t in_channels, int32_t mode,
                                       char *text, int32_t len);
 
+/* Builds, NOW, whatever per-table kernel a later vnd_convolve_* / vnd_decorrelate_* launch of this shape would
+ * use (hipRTC, 1.5-5 s the first time a table meets a geometry; the code object is then kept with the table and
+ * in the disk cache).  Launches themselves never stall for a build unless they are large (12 M frames and more
+ * per channel pair): a host that will run many SMALL launches of one shape - a rank's shard of a batch, an audio
+ * callback - calls this once, off its hot thread; without it such launches keep the generic kernels.
+ * in_channels = channels of the input (1 for a mono input through a stereo table, else the table's).
+ * Returns VND_OK also when no per-table kernel applies to the shape (the generic kernels need no preparation). */
+vnd_status vnd_prepare_launch(vnd_ctx *ctx, const vnd_taps *taps, int64_t batch, int64_t n_frames,
+                              int32_t in_channels, int32_t mode);
+
 #ifdef __cplusplus
 }
 #endif

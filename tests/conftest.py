@@ -1,8 +1,11 @@
+import os
 import json
 import pathlib
 import sys
 
 import numpy as np
+
+os.environ.setdefault('VND_TUNING', '1')      # tests change kernel geometry (VND_SPEC_NT, ...) between launches: live reads
 import pytest
 
 REPO = pathlib.Path(__file__).resolve().parents[1]

@@ -225,3 +225,34 @@ def test_a_window_build_that_spills_is_rejected_and_the_launch_still_right(env, 
     assert _err(table.convolve_host(x, d.MODE_FAST), want) <= TOL_PEAK
     ctx.set_variant(-1)
     table.close()
+
+
+def test_prepare_builds_the_kernel_a_small_launch_will_take(env, golden, tmp_path, monkeypatch):
+    """vnd_prepare_launch: a launch too small to stall for a hipRTC build (a rank's shard, one file) keeps the generic
+    kernel until the host prepares its shape - once, off the hot path; then launches of that shape take the per-table
+    kernel.  Results: bit-identical in exact mode, within tolerance in fast mode, prepared or not."""
+    import torch
+    d, native, ctx = env
+    monkeypatch.setenv('VND_SPEC_CACHE_DIR', str(tmp_path / 'cache'))
+    fir = d.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=4242)
+    table = _table(native, ctx, fir)
+    pool, n = 128, 48000                                   # the N = 8 shard of cfg4: 6 M frames
+    ctx.set_variant(-1)
+    x = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1)
+    y0, y1 = torch.empty_like(x), torch.empty_like(x)
+    s = torch.cuda.current_stream().cuda_stream
+    for mode, generic in ((d.MODE_FAST, 'conv_fast'), (d.MODE_EXACT, 'conv_ordered')):
+        assert table.describe(pool, n, 2, mode).startswith(generic)
+        table.convolve_device(x.data_ptr(), y0.data_ptr(), pool, n, 2, mode=mode, stream=s)
+        table.prepare(pool, n, 2, mode)
+        assert table.describe(pool, n, 2, mode).startswith('conv_spec'), table.describe(pool, n, 2, mode)
+        table.convolve_device(x.data_ptr(), y1.data_ptr(), pool, n, 2, mode=mode, stream=s)
+        torch.cuda.synchronize()
+        if mode == d.MODE_EXACT:
+            assert torch.equal(y0, y1)
+        else:
+            assert float((y0 - y1).abs().max()) <= TOL_PEAK * float(y0.abs().max())
+    table.prepare(1, 100, 2, d.MODE_FAST)                  # nothing applies to so little work: not an error
+    with pytest.raises(ValueError):
+        table.prepare(4, 1000, 3, d.MODE_FAST)             # a shape the table cannot take
+    table.close()

@@ -5,6 +5,7 @@ beside the head of the next: consecutive passes are independent batches).  usage
 import os, pathlib, sys, time
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
 import numpy as np
+os.environ.setdefault('VND_TUNING', '1')      # geometry variables are read live
 import torch
 import vndecorrelate_amd.decorrelation as vnd
 from vndecorrelate_amd import _native

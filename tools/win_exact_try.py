@@ -5,6 +5,7 @@ usage: win_exact_try.py [seconds per variant] [cfg2|cfg3]"""
 import os, pathlib, sys, time
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
 import numpy as np
+os.environ.setdefault('VND_TUNING', '1')      # geometry variables are read live
 import torch
 import vndecorrelate_amd.decorrelation as vnd
 from vndecorrelate_amd import _native

@@ -2,6 +2,7 @@ import os, sys
 sys.path.insert(0, '/root/repo')
 os.environ['VND_SPEC_VERBOSE'] = '1'
 import numpy as np
+os.environ.setdefault('VND_TUNING', '1')      # geometry variables are read live
 import vndecorrelate_amd.decorrelation as vnd
 from vndecorrelate_amd import _native
 from vndecorrelate_amd.taps import function_path_arrays

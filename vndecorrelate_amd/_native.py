@@ -116,6 +116,8 @@ SIGNATURES = {
                                                 ctypes.c_int32, ctypes.c_char_p, ctypes.c_int64,
                                                 ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                                 ctypes.POINTER(ctypes.c_int64)]),
+    'vnd_prepare_launch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+                                          ctypes.c_int32]),
     'vnd_set_variant': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     'vnd_describe_launch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                            ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
@@ -490,6 +492,11 @@ class TapTable:
             channels, int(mode), n_buffers, stride_elems, iters, ctypes.c_void_p(stream),
             ctypes.byref(ms)), 'vnd_time_convolve_f32_dev')
         return ms.value
+
+    def prepare(self, batch: int, n: int, channels: int, mode: int = MODE_EXACT) -> None:
+        """Build now the per-table kernel that launches of this shape would use (``vnd_prepare_launch``): small
+        launches never trigger a build themselves, so a host that repeats one small shape prepares it once."""
+        _check(self._lib.vnd_prepare_launch(self.ctx.handle, self.handle, batch, n, channels, int(mode)), 'vnd_prepare_launch')
 
     def describe(self, batch: int, n: int, channels: int, mode: int = MODE_EXACT) -> str:
         buf = ctypes.create_string_buffer(512)

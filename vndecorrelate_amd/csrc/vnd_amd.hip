@@ -503,18 +503,20 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     spans = (tiles_total + per_span - 1) / per_span;
     if (units * spans > 0x7fffffffLL) { p.why = "grid too large"; return p; }
     p.cfg.nt_stores = (batch * n * C * (int64_t)sizeof(float) >= ((int64_t)64 << 20)) ? 1 : 0;
-    if (C != 2 && !getenv("VND_FORCE_NT")) p.cfg.nt_stores = 0;      // a channel pair is a piece of a frame: let L2 merge the pieces
+    if (C != 2 && !spec_env("VND_FORCE_NT", 0)) p.cfg.nt_stores = 0;      // a channel pair is a piece of a frame: let L2 merge the pieces
     p.cfg.exact = mode == VND_MODE_EXACT ? 1 : 0;
     p.cfg.epi = pointwise ? 1 : 0;
     p.cfg.bc = bc ? 1 : 0;
     // exact mode counts VS_LA in steps of RR to 2*RR reads: the LDS queue holds 15, three steps fill it
-    if (p.cfg.exact && !p.cfg.win && !getenv("VND_SPEC_LA")) p.cfg.la = 3;
+    if (p.cfg.exact && !p.cfg.win && spec_env("VND_SPEC_LA", -1) < 0) p.cfg.la = 3;
     p.tiles_total = (int)tiles_total; p.tiles_per_span = (int)per_span; p.spans = (int)spans;
     // one round of workgroups: at most the resident slots, each walking units w, w + nblocks, ...
     p.units = (uint32_t)(units * spans);
     p.nblocks = (uint32_t)std::min<int64_t>(units * spans, resident);
     p.use = true;
-    if (per_span >= (p.cfg.win ? 6 : 12) || rr_hint > 0) break;
+    // (window form: 8192-frame tiles down to 3 per span - 256 one-second streams 42.6 us with them, 45.7 with 4096-frame
+    //  tiles; at 2 per span - 128 such streams - the smaller tiles win, 26.3 against 28.1 us: tools/shard_try.py)
+    if (per_span >= (p.cfg.win ? 3 : 12) || rr_hint > 0) break;
     }
     return p;
 }
@@ -591,8 +593,8 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
     // an output beyond what the L2 + Infinity Cache could hand to a consumer is streamed past them
     // (only where a workgroup writes whole frames: pieces of a frame written past the caches by different
     // workgroups reach HBM as separate partial writes)
-    a.stream_out = (batch * n * C * (int64_t)sizeof(float) >= ((int64_t)64 << 20) && !getenv("VND_NO_NT")) ? 1 : 0;
-    if (!p.direct && p.cg != C && !getenv("VND_FORCE_NT")) a.stream_out = 0;
+    a.stream_out = (batch * n * C * (int64_t)sizeof(float) >= ((int64_t)64 << 20) && !spec_env("VND_NO_NT", 0)) ? 1 : 0;
+    if (!p.direct && p.cg != C && !spec_env("VND_FORCE_NT", 0)) a.stream_out = 0;
     a.nblocks = p.nblocks;
     if (p.direct) {
         a.tiles = (int32_t)batch; a.groups = 1; a.W = 0;
@@ -1453,6 +1455,24 @@ vnd_status vnd_describe_fanout_launch(vnd_ctx *ctx, const vnd_taps *t, int64_t b
     if (!t) return fail(VND_ERR_INVALID, "null context or tap table");
     if (in_channels <= 0) return fail(VND_ERR_INVALID, "in_channels must be positive");
     return describe(ctx, t, batch, n, in_channels, t->C, mode, text, len);
+}
+
+vnd_status vnd_prepare_launch(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64_t n, int32_t in_channels, int32_t mode)
+{
+    if (!ctx || !t) return fail(VND_ERR_INVALID, "null context or tap table");
+    if (in_channels <= 0) return fail(VND_ERR_INVALID, "in_channels must be positive");
+    vnd_status st = check_shape(ctx, t, batch, n, t->C, mode, in_channels);
+    if (st != VND_OK) return st;
+    if (batch == 0 || n == 0) return VND_OK;
+    DeviceScope on(ctx->device);
+    for (int attempt = 0; attempt < 4; ++attempt) {               // (a window geometry that does not build is skipped: plan again)
+        const SpecPlan sp = make_spec_plan(ctx, t, nullptr, nullptr, batch, n, t->C, in_channels, mode, nullptr);
+        if (!sp.use) return VND_OK;
+        SpecModule *m = spec_module(ctx, t, sp.cfg, false);
+        if (m && !m->failed) return VND_OK;
+        if (!sp.cfg.win) break;
+    }
+    return VND_OK;                                                 // the generic kernels take such launches
 }
 
 static int64_t epi_chunks(int64_t n) { return (n + kEpiChunk - 1) / kEpiChunk; }

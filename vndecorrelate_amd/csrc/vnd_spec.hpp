@@ -77,10 +77,24 @@ struct SpecTable {
 
 // Smallest ring that holds one tile's window (tile + halo) plus the slot being refilled.
 // Returns false when no supported geometry fits (the caller then uses the generic kernel).
+// Tuning variables (VND_SPEC_NT, VND_SPEC_LA, VND_WIN_G, ...) are consulted on every launch plan.  getenv is not safe
+// against a concurrent setenv/putenv (Python's os.environ) and costs a scan of the environment, so each name is read
+// ONCE per process - unless VND_TUNING was set when the library first looked, which turns every lookup into a live read
+// (the sweep tools and the test suite set it: they change geometry between launches of one process).
 inline int spec_env(const char *name, int fallback)
 {
-    const char *e = getenv(name);             // tuning runs only (tools/spec_try.py)
-    return (e && *e) ? atoi(e) : fallback;
+    static const bool live = [] { const char *e = getenv("VND_TUNING"); return e && *e && *e != '0'; }();
+    auto read = [&]() { const char *e = getenv(name); return (e && *e) ? atoi(e) : fallback; };
+    if (live) return read();
+    static std::mutex mu;
+    static std::map<std::string, std::pair<bool, int>> seen;            // name -> (set, value)
+    std::lock_guard<std::mutex> g(mu);
+    auto it = seen.find(name);
+    if (it == seen.end()) {
+        const char *e = getenv(name);
+        it = seen.emplace(name, std::make_pair(e && *e, (e && *e) ? atoi(e) : 0)).first;
+    }
+    return it->second.first ? it->second.second : fallback;
 }
 
 inline bool spec_pick_config(const SpecTable &t, size_t lds_limit, int rr_hint, int dd_hint, SpecConfig *out,

@@ -99,6 +99,15 @@ class ShardedDecorrelator:
             return np.zeros(x_local.shape, np.float32)
         return self._convolve(x_local, mode)
 
+    def prepare(self, streams_local: int, frames: int, in_channels: Optional[int] = None, mode: int = 2) -> None:
+        """Build now the per-table kernel this rank's shard launches will use (``vnd_prepare_launch``).  A rank's
+        shard of a batch is a SMALL launch (the N = 8 shard of 1024 one-second streams: 6 M frames), and small
+        launches never stall for a hipRTC build themselves - call this once after the table broadcast, before the
+        passes: the 128-stream pass then takes 26 us instead of the generic kernel's 30 (tools/shard_try.py)."""
+        table = getattr(self._convolve, 'table', None)
+        if table is not None and streams_local > 0 and frames > 0:
+            table.prepare(streams_local, frames, in_channels or table.num_channels, mode)
+
     def convolve_local_device(self, x_local, y_local=None, mode: int = 2, stream: Optional[int] = None):
         """Device-resident form of :meth:`convolve_local`: ``x_local`` is this rank's ``(b_local, n, C)``
         float32 block already on ITS GPU (a torch tensor); the kernels are enqueued on ``stream`` (default:
@@ -135,7 +144,7 @@ class ShardedDecorrelator:
         x_local = np.ascontiguousarray(x_local, dtype=np.float32)
         n_local, channels = x_local.shape
         if not dist.is_initialized() or self.world_size == 1:
-            return self._convolve(x_local[None], mode)[0] if n_local else np.zeros_like(x_local)
+            return self._convolve(x_local[None], mode)[0] if n_local else np.zeros((0, self.arrays.num_channels), np.float32)
         if device is None:
             device = torch.device('cuda', torch.cuda.current_device()) \
                 if dist.get_backend(self.group) == 'nccl' else torch.device('cpu')
@@ -149,7 +158,9 @@ class ShardedDecorrelator:
         def wanted(r):                                                  # the frames rank r needs past its own
             return int(starts[r + 1]), int(min(starts[r + 1] + halo, starts[-1]))
 
-        mine = torch.from_numpy(x_local).to(device)
+        out_channels = self.arrays.num_channels
+        # only the frames other ranks ask for travel: the prefix of at most `halo` frames of this slice
+        mine = torch.from_numpy(x_local[:min(n_local, halo)]).to(device)
         ops, pieces = [], []
         lo, hi = wanted(self.rank)
         for s in range(self.rank + 1, self.world_size):                 # receive: prefixes of later slices
@@ -168,7 +179,7 @@ class ShardedDecorrelator:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         if n_local == 0:
-            return np.zeros_like(x_local)
+            return np.zeros((0, out_channels), np.float32)
         window = np.concatenate([x_local] + [p.cpu().numpy() for p in pieces]) if pieces else x_local
         return self._convolve(window[None], mode)[0, :n_local]
 
