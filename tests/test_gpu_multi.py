@@ -208,3 +208,35 @@ def test_two_rank_rccl_broadcast(tmp_path):
     assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
     mp.spawn(_rccl_rank, args=(2, bytes(uid), str(tmp_path)), nprocs=2, join=True)
     assert [(tmp_path / f'rccl{r}.txt').read_text() for r in range(2)] == ['1', '1']
+
+
+def test_bench_runs_with_two_ranks_under_torchrun(tmp_path):
+    """bench.py's N > 1 plumbing exactly as the driver launches it (`python -m torch.distributed.run --nproc-per-node N
+    bench.py --gpus N ...`): RANK / LOCAL_RANK / WORLD_SIZE from the environment, table broadcast from rank 0, barriers
+    around the timed region, max over ranks, ONE JSON line from rank 0, the cfg4 strong-scaling leg cut over the ranks.
+    With two GPUs: RCCL (`nccl`), one device per rank.  On a one-GPU box both ranks share device 0 and the process group
+    is `gloo` - everything but the RCCL transport itself (DESIGN.md 6 lists the lines that have therefore never run
+    with more than one rank)."""
+    import json
+    import pathlib
+    import subprocess
+    import sys
+    import torch
+    repo = pathlib.Path(__file__).resolve().parents[1]
+    two = torch.cuda.device_count() >= 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if not two:
+        env['VND_BENCH_FORCE_DEVICE'] = '0'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), str(repo / 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--pool', '16', '--min-warmup-ms', '10', '--backend', 'nccl' if two else 'gloo']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(repo))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]                        # rank 0 alone reports
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['steps'] == 3 and line['scaling'] == 'weak' and line['value'] > 0
+    assert line['config']['parity_vs_oracle_of_peak'] <= 1e-6
+    strong = line['cfg4_strong']
+    assert strong['ranks'] == 2 and strong['streams_on_rank0'] == 512 and strong['parity_vs_oracle_of_peak'] <= 1e-6
+    assert 'secondary' not in line and 'cpu_baseline' not in line   # N = 1 only

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3: PMC passes of the WINDOW form (VND_WIN_M=32, 256 threads) on cfg3 (and cfg2), one counter group per pass
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-export VND_WIN_M=${VND_WIN_M:-32} VND_SPEC_NT=${VND_SPEC_NT:-256}
+# (the window form is the default for stereo tables in fast mode)
 for cfg in ${CFGS:-cfg3 cfg2}; do
   out=gpurun_out/prof_r3_win_$cfg; mkdir -p $out
   n=40; [ $cfg = cfg2 ] && n=100

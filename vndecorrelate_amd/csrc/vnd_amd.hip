@@ -1072,7 +1072,15 @@ vnd_status vnd_taps_broadcast_rccl(vnd_ctx *ctx, vnd_taps **taps, int32_t root, 
             if (hipMemcpyAsync(image.data(), d_body, (size_t)bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) { st = fail(VND_ERR_HIP, "download of the tap image failed"); break; }
         }
         if (hipStreamSynchronize(stream) != hipSuccess) { st = fail(VND_ERR_HIP, "stream synchronisation failed"); break; }
-        if (rank != root) st = vnd_taps_deserialize(ctx, image.data(), bytes, taps);
+        if (rank != root) {
+            // what arrived must be a tap image of exactly the announced length before anything is built from it
+            // (a communicator whose ranks disagree on the root, or a torn transfer, shows up here, loudly)
+            const int32_t *hd = (const int32_t *)image.data();
+            if (hd[0] != kMagic || hd[1] != VND_ABI_VERSION) { st = fail(VND_ERR_INVALID, "rank %d received %lld bytes that are not a tap image (magic %08x, ABI %d)", rank, (long long)bytes, (unsigned)hd[0], hd[1]); break; }
+            const int64_t words = 8 + ((int64_t)hd[2] + 1) + 2 * (int64_t)hd[3] + (hd[5] ? ((int64_t)hd[2] + 1) + 2 * (int64_t)hd[4] : 0) + (hd[6] ? ((int64_t)hd[2] + 3) / 4 : 0);
+            if (hd[2] <= 0 || hd[3] < 0 || hd[4] < 0 || words * 4 != bytes) { st = fail(VND_ERR_INVALID, "rank %d: the tap image's header (%d channels, %d taps, %d segments) does not match its %lld bytes", rank, hd[2], hd[3], hd[4], (long long)bytes); break; }
+            st = vnd_taps_deserialize(ctx, image.data(), bytes, taps);
+        }
     } while (false);
     if (d_body) (void)hipFree(d_body);
     (void)hipFree(d_len);
