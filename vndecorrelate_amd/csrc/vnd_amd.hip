@@ -446,7 +446,10 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     // the WINDOW form (vnd_win.hpp: a lane owns win_m consecutive frames and reads the union of its taps' windows once):
     // stereo outputs, fast mode
     bool picked = false;
-    if (win_m > 0 && C == 2 && rr_hint == 0 && (mode == VND_MODE_FAST || win_exact)) {
+    // (a mono input fanned out keeps the pair-read form unless forced: there the two channels' taps share the reads of the
+    //  one plane at equal offsets, the window form makes a pass per channel - 0.163 against 0.169 ms for 128 x 10 s,
+    //  tools/fanout_win_try.py)
+    if (win_m > 0 && C == 2 && rr_hint == 0 && (mode == VND_MODE_FAST || win_exact) && (!bc || vw >= 2)) {
         // (a geometry whose build failed or spilled is remembered in the table's module map: skipped, the next best taken)
         const bool nt_big = batch * n * C * (int64_t)sizeof(float) >= ((int64_t)64 << 20);
         auto rejected = [&](const SpecConfig &c0) {
