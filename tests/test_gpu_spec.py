@@ -429,8 +429,10 @@ def test_fast_decorrelate_stage_through_the_specialised_kernel(env, golden, tmp_
     torch.cuda.synchronize()
     ctx.set_variant(-1)
     source = (tmp_path / 'kernel.hip').read_text()
-    # (a stereo table's fast mode takes the WINDOW form of the per-table kernel: the same switches, prefixed VW_)
-    assert '#define VW_EPI 1' in source and '#define VW_EXACT 0' in source and f'#define VW_BC {int(mono)}' in source
+    # (a stereo input's fast mode takes the WINDOW form of the per-table kernel - the same switches, prefixed VW_ -,
+    #  a mono input fanned out the pair-read form)
+    px = 'VS' if mono else 'VW'
+    assert f'#define {px}_EPI 1' in source and f'#define {px}_EXACT 0' in source and f'#define {px}_BC {int(mono)}' in source
     for b in (0, 11, 23):
         sig = x[b].cpu().numpy()
         want = O.decorrelate((sig[:, 0] if mono else sig).copy(), sample_rate_hz=48000, seed=kw['seed'], width=0.6, mode='MS')
