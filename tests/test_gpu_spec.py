@@ -47,6 +47,9 @@ def test_headline_workload_takes_the_specialised_kernel(env, golden):
     text = table.describe(128, 480000, 2, d.MODE_FAST)
     assert text.startswith('conv_spec'), text            # a silent fallback must not pass for the real thing
     exact = table.describe(128, 480000, 2, d.MODE_EXACT)
+    assert exact.startswith('conv_spec_exact_window') and 'frames_per_lane=32 ' in exact, exact     # the window form, 32-frame runs
+    ctx.set_variant(1 << 5)                                                  # window form off: the pair-read exact kernel
+    exact = table.describe(128, 480000, 2, d.MODE_EXACT)
     assert exact.startswith('conv_spec_exact') and 'tile=1024' in exact, exact       # 256 threads x 2 pairs with the shifted copies
     ctx.set_variant(GENERIC)
     assert table.describe(128, 480000, 2, d.MODE_EXACT).startswith('conv_ordered')
@@ -331,7 +334,8 @@ def test_decorrelate_stage_through_the_specialised_kernel(env, golden, ms_encode
     ctx.set_variant(-1)
     assert len(list((tmp_path / 'cache').glob('*.co'))) == 1
     source = (tmp_path / 'kernel.hip').read_text()
-    assert '#define VS_EPI 1' in source and '#define VS_EXACT 1' in source
+    # (a stereo table's exact mode takes the WINDOW form of the per-table kernel too: the same switches, prefixed VW_)
+    assert '#define VW_EPI 1' in source and '#define VW_EXACT 1' in source
     assert torch.equal(outs['spec'], outs['generic'])
     want = O.decorrelate(x[3].cpu().numpy().copy(), sample_rate_hz=48000, seed=kw['seed'], width=width, mode='MS' if ms_encode else 'LR')
     assert np.array_equal(outs['spec'][3].cpu().numpy(), want)

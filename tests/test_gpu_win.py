@@ -196,17 +196,23 @@ def test_exact_mode_window_class_path(env, golden, name):
     golden.expect(name, y, exact=x.dtype == np.float32, rtol_peak=TOL_PEAK)
 
 
-def test_dense_function_path_tables_take_the_exact_window_form_by_default(env, golden):
-    """Where taps share chunks and products (<= 2 B of LDS per sum: cfg3's 128 uniform taps) the exact mode's automatic
-    choice is the window form; cfg2's sparse table and the class-path tables keep the pair-read form."""
+def test_stereo_tables_take_the_window_form_by_default_in_both_modes(env, golden):
+    """The automatic choice for a stereo table with enough work: the window form, fast and exact, function path and class
+    path; a mono input fanned out and wider tables keep the pair-read form."""
     d, native, ctx = env
     ctx.set_variant(-1)
     dense, sparse = _table(native, ctx, golden.fir('g48k_k128_u')), _table(native, ctx, golden.fir('g48k_k30'))
-    assert dense.describe(24, 2880000, 2, d.MODE_EXACT).startswith('conv_spec_exact_window')
-    text = sparse.describe(128, 480000, 2, d.MODE_EXACT)
-    assert text.startswith('conv_spec_exact') and 'window' not in text, text
-    assert sparse.describe(128, 480000, 2, d.MODE_FAST).startswith('conv_spec_window')
-    dense.close(); sparse.close()
+    wide = _table(native, ctx, golden.fir('g96k_k64_c8'))
+    cls = d.VelvetNoise(sample_rate_hz=48000, seed=1)._device_table()
+    for table, shape in ((dense, (24, 2880000, 2)), (sparse, (128, 480000, 2)), (cls, (128, 480000, 2))):
+        assert table.describe(*shape, d.MODE_EXACT).startswith('conv_spec_exact_window'), table.describe(*shape, d.MODE_EXACT)
+        assert table.describe(*shape, d.MODE_FAST).startswith('conv_spec_window')
+    for mode in (d.MODE_FAST, d.MODE_EXACT):
+        text = sparse.describe(128, 480000, 1, mode)
+        assert text.startswith('conv_spec') and 'window' not in text, text
+        text = wide.describe(16, 960000, 8, mode)
+        assert text.startswith('conv_spec') and 'window' not in text, text
+    dense.close(); sparse.close(); wide.close()
 
 
 def test_a_window_build_that_spills_is_rejected_and_the_launch_still_right(env, golden, monkeypatch):

@@ -48,6 +48,8 @@ typedef char vw_lchar;
 #define VW_MUL(x, w) ((x) * v2f{(w), (w)})
 #define VW_SB
 static inline v2f vw_pair(v2f a, v2f b) { return v2f{a.y, b.x}; }
+static inline float vw_add1(float a, float b) { return a + b; }
+static inline float vw_sub1(float a, float b) { return a - b; }
 %(defines)s
 %(function)s
 static unsigned wrap(unsigned a) { const unsigned b = a - (unsigned)VW_R; return a < b ? a : b; }

@@ -845,15 +845,10 @@ vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, 
                 }
             }
         }
-        // VND_MODE_EXACT in the window form pays where taps share their chunks and products: function-path tables that
-        // read at most 2 bytes of LDS per (tap, output) sum with 32-frame runs (cfg3's 128 uniform taps: 1.43, +16 % over
-        // the pair-read exact kernel; cfg2's 30 log-spaced taps: 2.64, a tie; class-path tables split every segment into
-        // a negative and a positive pass and lose: tools/win_exact_try.py)
-        if (t->spec_exact_ok && C == 2 && !has_seg) {
-            size_t lb = 0, sums = 0;
-            win_traffic_exact(t->spec_table, 32, &lb, &sums);
-            t->win_exact_pays = sums > 0 && (double)lb <= 2.0 * (double)sums;
-        }
+        // VND_MODE_EXACT in the window form: ahead of the pair-read exact kernel on every stereo table measured once its
+        // odd-offset taps became single adds (cfg2 function path 4.48 against 4.20 TB/s, class path 4.77 against 4.64; cfg3
+        // 1.93 against 1.40 and 2.03 against 1.74: tools/win_exact_try.py, profiles/r03_exact_window.txt)
+        t->win_exact_pays = t->spec_exact_ok && C == 2;
     }
     if (e == hipSuccess) e = upload(&t->d_taps_fast, fast.data(), fast.size());
     {   // ordered image: table order, weight first (SGPR pair layout), byte offsets, padded

@@ -229,7 +229,18 @@ inline void win_exact_reads(const std::vector<WinExPass> &passes, int M, std::ve
     for (size_t p = 0; p < passes.size(); ++p) {
         const WinExPass &ps = passes[p];
         std::map<int, std::vector<WinExOp>> by_chunk;
-        for (const WinExTap &tp : ps.taps)
+        const bool singles = spec_env("VND_WIN_EXACT_SINGLES", 1) != 0;
+        for (const WinExTap &tp : ps.taps) {
+            if (singles && (tp.idx & 1)) {
+                // an odd offset: output j takes element idx + j.  The aligned input pairs (types 0 / 1) then feed ONE element
+                // each of two neighbouring accumulator pairs - single adds (types 4..7: pair type | 4, k = the OUTPUT index of
+                // the pair's first element, -1 / M - 1 at the run's edges where only one element has an output)
+                for (int j = -1; j < M; j += 2) {
+                    const int e = tp.idx + j;                           // even: an aligned pair (e, e + 1) -> outputs (j, j + 1)
+                    by_chunk[(e & 3) == 0 ? e : e - 2].push_back(WinExOp{((e & 3) == 0 ? 0 : 1) | 4, j, tp.w});
+                }
+                continue;
+            }
             for (int j = 0; j < M; j += 2) {
                 const int e = tp.idx + j;
                 switch (e & 3) {
@@ -239,6 +250,7 @@ inline void win_exact_reads(const std::vector<WinExPass> &passes, int M, std::ve
                 default: by_chunk[e + 1].push_back(WinExOp{2, j / 2, tp.w}); break;
                 }
             }
+        }
         std::vector<int> lend;
         for (const auto &kv : by_chunk)
             for (const WinExOp &op : kv.second)
@@ -285,7 +297,7 @@ inline std::string win_taps_function_exact(const SpecTable &t, const WinGeom &g,
     for (size_t k = 0; k < std::min(reads.size(), (size_t)la); ++k) emit_read(k);
     size_t rk = 0;
     for (int ch = 0; ch < 2; ++ch) {
-        std::vector<char> s_live(M / 2, 0);      // per output PAIR: the segment accumulator holds a value
+        std::vector<char> e_live(M, 0);          // per OUTPUT: the segment accumulator holds a value
         bool a_live = false;                     // the channel's output accumulators hold a value (class path)
         bool sum_is_output = false;
         for (size_t p = pass_first[ch]; p < pass_first[ch + 1]; ++p) {
@@ -319,10 +331,31 @@ inline std::string win_taps_function_exact(const SpecTable &t, const WinGeom &g,
                 };
                 for (const WinExOp &op : rd.ops) {
                     const char sign = std::signbit(op.w) ? '-' : '+';
+                    if (op.type & 4) {
+                        // single sums: element 0 of the pair -> output k, element 1 -> output k + 1 (where they exist)
+                        const std::string v = value_of(op.w, op.type & 3);
+                        for (int e = 0; e < 2; ++e) {
+                            const int j = op.k + e;
+                            if (j < 0 || j >= M) continue;
+                            const std::string acc = "S[" + std::to_string(j / 2) + "]." + ((j & 1) ? "y" : "x");
+                            const std::string first = e_live[j] ? acc : std::string("0.0f");
+                            spec_append(sums, "        %s = %s(%s, %s.%s);\n", acc.c_str(), sign == '-' ? "vw_sub1" : "vw_add1", first.c_str(), v.c_str(), e ? "y" : "x");
+                            e_live[j] = 1;
+                        }
+                        continue;
+                    }
                     const std::string v = value_of(op.w, op.type);
-                    if (s_live[op.k]) spec_append(sums, "        S[%d] = S[%d] %c %s;\n", op.k, op.k, sign, v.c_str());
-                    else spec_append(sums, "        S[%d] = Z2 %c %s;\n", op.k, sign, v.c_str());
-                    s_live[op.k] = 1;
+                    const int j0 = 2 * op.k;
+                    if (e_live[j0] && e_live[j0 + 1]) {
+                        spec_append(sums, "        S[%d] = S[%d] %c %s;\n", op.k, op.k, sign, v.c_str());
+                    } else if (!e_live[j0] && !e_live[j0 + 1]) {
+                        spec_append(sums, "        S[%d] = Z2 %c %s;\n", op.k, sign, v.c_str());
+                    } else {
+                        if (!e_live[j0]) spec_append(sums, "        S[%d].x = 0.0f;\n", op.k);
+                        if (!e_live[j0 + 1]) spec_append(sums, "        S[%d].y = 0.0f;\n", op.k);
+                        spec_append(sums, "        S[%d] = S[%d] %c %s;\n", op.k, op.k, sign, v.c_str());
+                    }
+                    e_live[j0] = e_live[j0 + 1] = 1;
                 }
                 s += sums;
                 s += "    }\n    VW_SB;\n";
@@ -337,12 +370,12 @@ inline std::string win_taps_function_exact(const SpecTable &t, const WinGeom &g,
                     else spec_append(s, "    A[%d] = Z2 + S[%d];\n", k, k);
                 }
                 a_live = true;
-                std::fill(s_live.begin(), s_live.end(), 0);
+                std::fill(e_live.begin(), e_live.end(), 0);
             }
         }
         for (int j = 0; j < M; ++j) {
             const char *src = sum_is_output ? "S" : "A";
-            const bool have = sum_is_output ? (s_live[j / 2] != 0) : a_live;
+            const bool have = sum_is_output ? (e_live[j] != 0) : a_live;
             if (have) spec_append(s, "    o%d[%d] = %s[%d].%s;\n", ch, j, src, j / 2, (j & 1) ? "y" : "x");
             else spec_append(s, "    o%d[%d] = 0.0f;\n", ch, j);
         }
