@@ -98,7 +98,7 @@ struct vnd_taps {
     SpecTable spec_table;          // effective weights (segment gain folded in)
     bool spec_ok = false;          // the table is within the specialised kernel's scope
     bool spec_exact_ok = false;    // ... also in VND_MODE_EXACT (no empty segment)
-    bool win_exact_pays = false;   // ... and dense enough for the exact mode's window form to beat its pair-read form
+    bool win_exact_pays = false;   // ... and its exact mode takes the window form (stereo tables)
     std::mutex spec_mutex;
     std::map<SpecConfig, std::unique_ptr<SpecModule>> spec_modules;
 };
