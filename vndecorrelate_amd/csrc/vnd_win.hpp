@@ -36,6 +36,10 @@ struct WinGeom {
 inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size_t lds_limit, WinGeom *g)
 {
     if (!(M == 16 || M == 32 || M == 64) || nt % 64 != 0 || nt < 64 || nt > 1024 || G < 1) return false;
+    // one lane's tap sum is straight-line code, M/2 packed instructions of 8 bytes per tap: beyond ~1000 taps per channel
+    // pair it would be megabytes of code for hipRTC and the 64 KB instruction cache (cfg3's 256 taps: 33 KB) - such
+    // tables keep the pair-read form
+    if ((int64_t)t.idx.size() * M > 32768) return false;
     g->M = M; g->nt = nt; g->G = G; g->npl = bc ? 1 : 2;
     g->DE = (t.max_index + M - 1) / M;
     g->R = nt + g->DE;
