@@ -262,3 +262,25 @@ def test_prepare_builds_the_kernel_a_small_launch_will_take(env, golden, tmp_pat
     with pytest.raises(ValueError):
         table.prepare(4, 1000, 3, d.MODE_FAST)             # a shape the table cannot take
     table.close()
+
+
+@pytest.mark.parametrize('M', [32, 16])
+def test_mono_fan_out_through_the_window_form_when_forced(env, golden, M):
+    """A mono input through a stereo table keeps the pair-read form by default (its two channels share the reads of the one
+    plane); the window form's one-plane variant (VW_BC: one ring plane, a pass per channel, the transposition in two
+    rounds) stays correct - forced here: fast mode within tolerance, exact mode bit for bit, seams and tails included."""
+    d, native, ctx = env
+    fir = golden.fir('g48k_k30')
+    table = _table(native, ctx, fir)
+    rng = np.random.default_rng(77)
+    for n, batch in ((40003, 1), (12346, 3), (2 * 128 * M + 5, 2)):
+        x = rng.uniform(-1, 1, (batch, n, 1)).astype(np.float32)
+        want = np.stack([O.convolve_velvet_noise(np.repeat(x[b], 2, axis=1), fir) for b in range(batch)])
+        for spans in ((1, 7), (2, 1)):
+            ctx.set_variant(FORCE | WIN[M] | span_bits(*spans))
+            assert table.describe(batch, n, 1, d.MODE_FAST).startswith('conv_spec_window'), table.describe(batch, n, 1, d.MODE_FAST)
+            assert _err(table.convolve_host(x, d.MODE_FAST), want) <= TOL_PEAK
+            assert table.describe(batch, n, 1, d.MODE_EXACT).startswith('conv_spec_exact_window')
+            assert np.array_equal(table.convolve_host(x, d.MODE_EXACT), want), (n, batch, spans)
+    ctx.set_variant(-1)
+    table.close()

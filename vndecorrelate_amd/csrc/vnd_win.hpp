@@ -112,7 +112,7 @@ inline void win_traffic(const SpecTable &t, int M, size_t *lds_bytes, size_t *fm
 
 inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int la)
 {
-    const int M = g.M, qc = M / 4;
+    const int M = g.M;
     std::string s;
     s += "__device__ __forceinline__ void vw_taps(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
     spec_append(s, "    v4f q[%d];\n    v2f E[%d], P[%d];\n    float O0, OL;\n", la + 1, M / 2, M / 2);
@@ -170,7 +170,6 @@ inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int l
         }
         emit_merge(ch, e_used, p_used, o0_used, ol_used);
     }
-    (void)qc;
     s += "}\n";
     return s;
 }
