@@ -594,11 +594,13 @@ def main():
                 assert np.array_equal(y[args.pool - 1].cpu().numpy(), want_cls), 'class-path exact mode differs from the oracle'
                 cls_info = {'kernel_ms': round(c_ms, 4),
                             'achieved_GBs': round(ALGO_BYTES_PER_SAMPLE * samples_per_step / (c_ms * 1e-3) / 1e9, 1),
+                            'frac_of_8TBs': round(ALGO_BYTES_PER_SAMPLE * samples_per_step / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                             'launch': cls_table.describe(args.pool, n, CHANNELS, vnd.MODE_EXACT)}
             except Exception as exc:
                 cls_info = {'error': repr(exc)}
             exact_info = {'kernel_ms': round(e_kernel_ms, 4),
                           'achieved_GBs': round(ALGO_BYTES_PER_SAMPLE * samples_per_step / (e_kernel_ms * 1e-3) / 1e9, 1),
+                          'frac_of_8TBs': round(ALGO_BYTES_PER_SAMPLE * samples_per_step / (e_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                           'warmup_actual': warmups[-1],
                           'parity': 'bit-identical to the oracle (sha-checked in tests)',
                           'launch': table.describe(args.pool, n, CHANNELS, vnd.MODE_EXACT),
