@@ -196,6 +196,37 @@ def test_exact_mode_window_class_path(env, golden, name):
     golden.expect(name, y, exact=x.dtype == np.float32, rtol_peak=TOL_PEAK)
 
 
+@pytest.mark.parametrize('C', [4, 6, 8])
+@pytest.mark.parametrize('M,nt', [(32, 128), (16, 128)])
+def test_window_form_on_wider_signals(env, golden, monkeypatch, C, M, nt):
+    """More than two interleaved channels: a workgroup takes ONE channel pair of a span (8 bytes of every frame, its own
+    pair's tap function).  Every pair has its own taps; lengths around the tile, stream tails inside a run, batches,
+    spans of one tile - fast within tolerance, exact bit for bit, against the NumPy oracle."""
+    d, native, ctx = env
+    fir = np.ascontiguousarray(golden.fir('g96k_k64_c8')[:, :C])
+    table = _table(native, ctx, fir)
+    monkeypatch.setenv('VND_SPEC_NT', str(nt))
+    rng = np.random.default_rng(C * 100 + M)
+    T = nt * M
+    for n in sorted({1, 3, M + 1, T - 1, T, T + 1, 2 * T + 3, 5 * T + 17, 40003}):
+        for batch in (1, 3):
+            x = rng.uniform(-1, 1, (batch, n, C)).astype(np.float32)
+            want = np.stack([O.convolve_velvet_noise(x[b], fir) for b in range(batch)])
+            for min_span, rounds in ((1, 7), (2, 1)):
+                ctx.set_variant(FORCE | WIN[M] | span_bits(min_span, rounds))
+                for mode, name in ((d.MODE_FAST, 'conv_spec_window'), (d.MODE_EXACT, 'conv_spec_exact_window')):
+                    text = table.describe(batch, n, C, mode)
+                    assert text.startswith(name) and f'frames_per_lane={M} ' in text and f'threads={nt}' in text, text
+                    got = table.convolve_host(x, mode)
+                    where = f'C={C} M={M} n={n} batch={batch} spans=({min_span},{rounds})'
+                    if mode == d.MODE_EXACT:
+                        assert np.array_equal(got, want), where
+                    else:
+                        assert _err(got, want) <= TOL_PEAK, f'{where}: {_err(got, want):.2e}'
+    ctx.set_variant(-1)
+    table.close()
+
+
 def test_stereo_tables_take_the_window_form_by_default_in_both_modes(env, golden):
     """The automatic choice for a stereo table with enough work: the window form, fast and exact, function path and class
     path; a mono input fanned out and wider tables keep the pair-read form."""

@@ -64,10 +64,12 @@ extern "C" void run_lane(char *lds, unsigned pl, float *o0, float *o1)
 '''
 
 
-def _host_lane(src, tmp_path, tag):
+def _host_lane(src, tmp_path, tag, pair=0):
+    """pair: the channel pair whose tap function is compiled (vw_taps, vw_taps_1, ...)"""
     defines = '\n'.join(l for l in src.splitlines() if re.match(r'#define VW_(NT|M|R|G|NB|DE|PLANE|LA) ', l))
-    fn = src[src.index('__device__ __forceinline__ void vw_taps('):]
-    fn = fn[:fn.index('\n}\n') + 3]
+    name = 'vw_taps' if pair == 0 else f'vw_taps_{pair}'
+    fn = src[src.index(f'__device__ __forceinline__ void {name}('):]
+    fn = fn[:fn.index('\n}\n') + 3].replace(f'void {name}(', 'void vw_taps(')
     cpp = tmp_path / f'lane_{tag}.cpp'
     cpp.write_text(HOST_SHIM % dict(defines=defines, function=fn))
     so = tmp_path / f'lane_{tag}.so'
@@ -143,6 +145,44 @@ def test_one_lane_of_the_generated_tap_function(native, golden, tmp_path, case, 
         got = np.stack([o0, o1], 1).astype(np.float64)
         assert np.all(np.isfinite(got)), f'own={own}: a read outside the window (NaN filler)'
         assert np.abs(got - want).max() <= 1e-6 * peak, f'own={own}'
+
+
+@pytest.mark.parametrize('mode', ['fast', 'exact'])
+def test_every_channel_pair_of_a_wider_table_gets_its_own_tap_function(native, golden, tmp_path, mode):
+    """More than two channels: a workgroup takes one channel PAIR, and the source carries one tap function per pair
+    (vw_taps, vw_taps_1, ...: that pair's taps, the same two LDS plane sets), vw_taps_of<PG> to pick one and the
+    kernel's dispatch over the pairs."""
+    from vndecorrelate_amd.taps import function_path_arrays
+    fir = np.ascontiguousarray(golden.fir('g96k_k64_c8')[:, :6])
+    arr = function_path_arrays(fir)
+    offs, idx, w = arr.tap_offsets, arr.tap_index, arr.tap_weight
+    M, nt = 32, 128
+    src, lds_bytes, fmas = native.window_kernel_source(offs, idx, w, 2 if mode == 'fast' else 0, M, nt, with_traffic=True)
+    assert '#define VW_C 6' in src and fmas == M * len(idx)
+    assert all(f'if constexpr (PG == {g}) ' in src and f'case {g}: vw_span<{g}>(a, lds, stream, span); break;' in src for g in range(3))
+    assert 'vw_taps_3(' not in src
+    R, G, plane = _macro(src, 'VW_R'), _macro(src, 'VW_G'), _macro(src, 'VW_PLANE')
+    assert R == nt + (int(idx.max()) + M - 1) // M              # the halo of the farthest tap of ANY pair
+    rng = np.random.default_rng(77)
+    for pair in range(3):
+        lib = _host_lane(src, tmp_path, f'wide_{mode}_{pair}', pair)
+        x = rng.uniform(-1, 1, (R * M, 2)).astype(np.float32)
+        o2 = np.array([0, offs[2 * pair + 1] - offs[2 * pair], offs[2 * pair + 2] - offs[2 * pair]], np.int32)
+        i2, w2 = idx[offs[2 * pair]:offs[2 * pair + 2]], w[offs[2 * pair]:offs[2 * pair + 2]]
+        for own in (0, R - 1, nt + 3):
+            img = _lds_image(x, own, M, R, G, plane)
+            o0, o1 = np.zeros(M, np.float32), np.zeros(M, np.float32)
+            lib.run_lane(img.ctypes.data, own, o0.ctypes.data, o1.ctypes.data)
+            got = np.stack([o0, o1], 1)
+            if mode == 'fast':
+                want = _want(x.astype(np.float64), o2, i2, w2, M)
+                assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max(), f'pair {pair} own={own}'
+            else:                                               # the reference's order: one float32 accumulator, taps in table order
+                want = np.zeros((M, 2), np.float32)
+                for c in range(2):
+                    for i, wt in zip(i2[o2[c]:o2[c + 1]], w2[o2[c]:o2[c + 1]]):
+                        want[:, c] = want[:, c] + x[i:i + M, c] * np.float32(wt)
+                assert np.array_equal(got, want), f'pair {pair} own={own}'
 
 
 def _want_exact(x, arr, M):

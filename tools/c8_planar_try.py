@@ -35,8 +35,17 @@ print(full.describe(pool, n, 8, 2)); print(pairs[0].describe(pool, n, 2, 2))
 run8(); run2(); torch.cuda.synchronize()
 err = max(float((y8[:, :, 2 * g:2 * g + 2] - y2[g]).abs().max()) for g in range(4))
 print('max difference between the two forms', err)
+def planar(variant):
+    def fn():
+        ctx.set_variant(variant); run2(); ctx.set_variant(-1)
+    return fn
+
+# round 3: the planar pairs take the WINDOW form by default; 1 << 5 turns it off (the pair-read kernel), 2 << 5 = 16 frames per lane
+forms = (('interleaved, one launch', run8), ('planar pairs, window (default)', run2), ('planar pairs, pair-read', planar(1 << 5)),
+         ('planar pairs, window 16', planar(2 << 5)))
+ctx.set_variant(2 << 5); print(pairs[0].describe(pool, n, 2, 2)); ctx.set_variant(-1)
 for rnd in range(3):
-    for name, fn in (('interleaved, one launch', run8), ('planar pairs, four launches', run2)):
+    for name, fn in forms:
         for _ in range(10): fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(); e0.record()

@@ -4,6 +4,7 @@ off by default for more than two channels) in several geometries."""
 import os, pathlib, sys, time
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
 import numpy as np
+os.environ.setdefault('VND_TUNING', '1')      # geometry variables are read live
 import torch
 import vndecorrelate_amd.decorrelation as vnd
 from vndecorrelate_amd import _native
@@ -41,3 +42,9 @@ for rep in range(2):
     rate(F, 'spec nt=256 rr=2', nt=256, rr=2)
     rate(F, 'spec nt=128 rr=4', nt=128, rr=4)
     rate(F, 'spec nt=192 rr=2', nt=192, rr=2)
+    rate(F, 'spec nt=128 rr=2', nt=128, rr=2)
+    rate(F, 'spec nt=64 rr=4', nt=64, rr=4)
+    rate(F, 'spec nt=128 rr=4 dd=1', nt=128, rr=4, dd=1)
+    rate(F, 'spec nt=128 rr=4 la=4', nt=128, rr=4, la=4)
+    rate(F, 'spec nt=128 rr=4 la=12', nt=128, rr=4, la=12)
+    rate(F, 'spec nt=192 rr=4', nt=192, rr=4)

@@ -449,7 +449,13 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     // (a mono input fanned out keeps the pair-read form unless forced: there the two channels' taps share the reads of the
     //  one plane at equal offsets, the window form makes a pass per channel - 0.163 against 0.169 ms for 128 x 10 s,
     //  tools/fanout_win_try.py)
-    if (win_m > 0 && C == 2 && rr_hint == 0 && (mode == VND_MODE_FAST || win_exact) && (!bc || vw >= 2)) {
+    // (wider signals - a workgroup per channel PAIR, VW_C - keep the pair-read kernel unless variant bits 5-7 or VND_WIN_WIDE=1
+    //  ask for the window form: there a workgroup moves 8 bytes of every frame, the memory pipeline's time per useful byte
+    //  is 2-4x a stereo signal's and the window form's few waves per CU do not hide it - cfg5 0.54 ms against 0.45, while
+    //  the same tables on planar channel pairs run 0.33 against 0.39: tools/c8_win_try.py, profiles/r03_cfg5_request_floor.txt)
+    static const int win_wide_env = spec_env("VND_WIN_WIDE", 0);
+    const bool win_c = C == 2 || (C % 2 == 0 && (win_wide_env != 0 || vw >= 2));
+    if (win_m > 0 && win_c && rr_hint == 0 && (mode == VND_MODE_FAST || win_exact) && (!bc || vw >= 2)) {
         // (a geometry whose build failed or spilled is remembered in the table's module map: skipped, the next best taken)
         const bool nt_big = batch * n * C * (int64_t)sizeof(float) >= ((int64_t)64 << 20);
         auto rejected = [&](const SpecConfig &c0) {
@@ -848,7 +854,7 @@ vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, 
         // VND_MODE_EXACT in the window form: ahead of the pair-read exact kernel on every stereo table measured once its
         // odd-offset taps became single adds (cfg2 function path 4.48 against 4.20 TB/s, class path 4.77 against 4.64; cfg3
         // 1.93 against 1.40 and 2.03 against 1.74: tools/win_exact_try.py, profiles/r03_exact_window.txt)
-        t->win_exact_pays = t->spec_exact_ok && C == 2;
+        t->win_exact_pays = t->spec_exact_ok && C % 2 == 0;
     }
     if (e == hipSuccess) e = upload(&t->d_taps_fast, fast.data(), fast.size());
     {   // ordered image: table order, weight first (SGPR pair layout), byte offsets, padded
@@ -1340,8 +1346,8 @@ vnd_status vnd_window_kernel_source(int32_t C, const int32_t *tap_offsets, const
     if (mode != VND_MODE_FAST && mode != VND_MODE_EXACT)
         return fail(VND_ERR_INVALID, "the specialised kernel exists for VND_MODE_FAST and VND_MODE_EXACT");
     if (!bytes) return fail(VND_ERR_INVALID, "null bytes pointer");
-    if (C != 2 || !tap_offsets || tap_offsets[0] != 0)
-        return fail(VND_ERR_INVALID, "the window kernel takes a stereo CSR tap table");
+    if (C < 2 || (C & 1) || C > 64 || !tap_offsets || tap_offsets[0] != 0)
+        return fail(VND_ERR_INVALID, "the window kernel takes a CSR tap table of whole channel pairs");
     SpecTable t;
     t.C = C;
     t.tap_off.assign(tap_offsets, tap_offsets + C + 1);

@@ -173,6 +173,9 @@ inline std::string spec_prologue(const SpecTable &t, const SpecConfig &c)
                 c.nt_stores, c.exact, c.epi, c.bc, c.shift);
     spec_append(s, "#define VS_NT_STORE_AUX %d\n", spec_env("VND_SPEC_STORE_AUX", 2));   // cache policy bits of the non-temporal stores (tuning)
     spec_append(s, "#define VS_LOAD_AUX %d\n", spec_env("VND_SPEC_LOAD_AUX", 2));     // input is read once: non-temporal loads (+1-2 % on cfg2)
+    // wider signals: the four lanes of a quad exchange their frames so that one store instruction writes four CONSECUTIVE
+    // frames' pieces (one 128-byte line) instead of every other frame's (tools/micro/piece_stores.hip: 2.8 against 1.7 TB/s)
+    spec_append(s, "#define VS_QUAD_STORES %d\n", spec_env("VND_SPEC_QUAD_STORES", 1));
     {   // resident workgroups per CU (LDS-bound, at most 32 waves) -> waves per SIMD the register budget must allow
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, 2048 / c.nt), (160 * 1024) / c.lds_bytes()));
         const int waves = (per_cu * (c.nt / 64) + 3) / 4;

@@ -23,6 +23,7 @@ static const char kWinKernelSource[] =
 
 struct WinGeom {
     int M = 0, nt = 0, G = 8;
+    int C = 2;           // interleaved channels of the signal (a workgroup takes one channel PAIR)
     int DE = 0;          // entries of halo: the farthest entry past its own that a lane reads
     int R = 0;           // ring entries
     int NB = 0;          // base registers per channel
@@ -40,7 +41,8 @@ inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size
     // pair it would be megabytes of code for hipRTC and the 64 KB instruction cache (cfg3's 256 taps: 33 KB) - such
     // tables keep the pair-read form
     if ((int64_t)t.idx.size() * M > 32768) return false;
-    g->M = M; g->nt = nt; g->G = G; g->npl = bc ? 1 : 2;
+    if (t.C < 2 || (t.C & 1) || (bc && t.C != 2)) return false;      // whole channel pairs
+    g->M = M; g->nt = nt; g->G = G; g->npl = bc ? 1 : 2; g->C = t.C;
     g->DE = (t.max_index + M - 1) / M;
     g->R = nt + g->DE;
     g->NB = g->DE / G + 1;
@@ -110,18 +112,33 @@ inline void win_traffic(const SpecTable &t, int M, size_t *lds_bytes, size_t *fm
     }
 }
 
-inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int la)
+// the name of channel pair pg's tap function: vw_taps for the first (a stereo table's only) pair, vw_taps_<pg> for the others
+inline std::string win_taps_name(int pg) { return pg == 0 ? std::string("vw_taps") : "vw_taps_" + std::to_string(pg); }
+
+// vw_taps_of<PG>(): the pair's function by its number, and VW_DISPATCH: the kernel's span loop instantiated per channel pair
+inline std::string win_taps_dispatch(const SpecTable &t)
+{
+    std::string s = "template <int PG> __device__ __forceinline__ void vw_taps_of(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
+    for (int pg = 0; pg < t.C / 2; ++pg)
+        spec_append(s, "    %sif constexpr (PG == %d) %s(b, o0, o1);\n", pg ? "else " : "", pg, win_taps_name(pg).c_str());
+    s += "}\n#define VW_DISPATCH(pg) switch (pg) {";
+    for (int pg = 0; pg < t.C / 2; ++pg) spec_append(s, " case %d: vw_span<%d>(a, lds, stream, span); break;", pg, pg);
+    s += " default: break; }\n";
+    return s;
+}
+
+inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int la, int pg = 0)
 {
     const int M = g.M;
     std::string s;
-    s += "__device__ __forceinline__ void vw_taps(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
+    s += "__device__ __forceinline__ void " + win_taps_name(pg) + "(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
     spec_append(s, "    v4f q[%d];\n    v2f E[%d], P[%d];\n    float O0, OL;\n", la + 1, M / 2, M / 2);
     // one read stream over both channels: the pipeline stays full across the channel boundary
     std::vector<WinRead> reads;
     size_t first_of_ch[3] = {0, 0, 0};
     for (int ch = 0; ch < 2; ++ch) {
         first_of_ch[ch] = reads.size();
-        for (WinRead &r : win_schedule(t, ch, M)) reads.push_back(std::move(r));
+        for (WinRead &r : win_schedule(t, 2 * pg + ch, M)) { r.ch = ch; reads.push_back(std::move(r)); }      // ch: the LDS plane set
     }
     first_of_ch[2] = reads.size();
     auto emit_read = [&](size_t k) {
@@ -275,19 +292,20 @@ inline void win_traffic_exact(const SpecTable &t, int M, size_t *lds_bytes, size
     }
 }
 
-inline std::string win_taps_function_exact(const SpecTable &t, const WinGeom &g, int la)
+inline std::string win_taps_function_exact(const SpecTable &t, const WinGeom &g, int la, int pg = 0)
 {
     const int M = g.M;
     const size_t ring = (size_t)la + 2;                  // read k lands in q[k % ring]: the previous chunk stays whole while read k + la is issued
     std::string s;
-    s += "__device__ __forceinline__ void vw_taps(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
+    s += "__device__ __forceinline__ void " + win_taps_name(pg) + "(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
     spec_append(s, "    v4f q[%zu];\n    v2f S[%d], A[%d];\n    const v2f Z2 = {0.0f, 0.0f};\n", ring, M / 2, M / 2);
     std::vector<WinExPass> passes;
     std::vector<WinExRead> reads;
     size_t pass_first[3] = {0, 0, 0};
     for (int ch = 0; ch < 2; ++ch) {
         pass_first[ch] = passes.size();
-        std::vector<WinExPass> ps = win_exact_passes(t, ch);
+        std::vector<WinExPass> ps = win_exact_passes(t, 2 * pg + ch);
+        for (WinExPass &x : ps) x.ch = ch;                           // the LDS plane set
         if (!ps.empty()) win_exact_reads(ps, M, &reads, passes.size());
         for (WinExPass &x : ps) passes.push_back(std::move(x));
     }
@@ -392,8 +410,9 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
     std::string s;
     spec_append(s, "#define VW_NT %d\n#define VW_M %d\n#define VW_R %d\n#define VW_G %d\n#define VW_NB %d\n#define VW_DE %d\n#define VW_PLANE %d\n#define VW_LA %d\n",
                 g.nt, g.M, g.R, g.G, g.NB, g.DE, g.plane, c.la);
-    spec_append(s, "#define VW_NT_STORES %d\n#define VW_EPI %d\n#define VW_BC %d\n#define VW_EXACT %d\n", c.nt_stores, c.epi, c.bc, c.exact);
+    spec_append(s, "#define VW_NT_STORES %d\n#define VW_EPI %d\n#define VW_BC %d\n#define VW_EXACT %d\n#define VW_C %d\n", c.nt_stores, c.epi, c.bc, c.exact, g.C);
     spec_append(s, "#define VW_NT_STORE_AUX %d\n", spec_env("VND_SPEC_STORE_AUX", 2));
+    spec_append(s, "#define VW_DEBUG %d\n", spec_env("VND_WIN_DEBUG", 0));          // diagnosis builds (wrong results): see the kernel
     spec_append(s, "#define VW_LOAD_AUX %d\n", spec_env("VND_SPEC_LOAD_AUX", 2));
     const int waves = (win_workgroups_per_cu(g) * (g.nt / 64) + 3) / 4;
     spec_append(s, "#define VW_WAVES_PER_EU %d\n", std::max(1, std::min(waves, win_waves_per_simd_max(g.M))));
@@ -408,7 +427,8 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
     const std::string marker = "//@@VW_TAPS@@";
     const size_t at = fixed.find(marker);
     src += fixed.substr(0, at);
-    src += c.exact ? win_taps_function_exact(t, g, c.la) : win_taps_function(t, g, c.la);
+    for (int pg = 0; pg < t.C / 2; ++pg) src += c.exact ? win_taps_function_exact(t, g, c.la, pg) : win_taps_function(t, g, c.la, pg);
+    src += win_taps_dispatch(t);
     src += fixed.substr(at + marker.size());
     return src;
 }
