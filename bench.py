@@ -54,6 +54,7 @@ CHANNELS = 2
 TAPS = 30
 FIR_SECONDS = 0.03
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X FP32 vector peak (same guide): what bounds a table of more than ~80 taps per stereo frame
 ALGO_BYTES_PER_SAMPLE = 8      # 4 B read + 4 B written per output channel-sample
 MIN_TIMED_MS = 50.0            # the timed region of the headline must be at least this long
 
@@ -157,6 +158,13 @@ def device_rate(torch, table, shape, mode, *, min_ms=30.0, buffers=1, taps=None)
            'Msamples_s': round(batch * n * c / (per * 1e-3) / 1e6, 1), 'launches_timed': iters,
            'launch': table.describe(batch, n, c, mode)}
     if taps is not None:
+        # the arithmetic beside the bytes: one FMA per (frame, non-zero tap of its channel).  Above 157.3 / 8 = 19.7 flop per
+        # byte (MI355X_MICROARCH.md: FP32 vector peak, v_pk_fma_f32 on every SIMD) the FP32 pipe bounds the launch, not HBM
+        fmas = float(np.count_nonzero(np.asarray(taps[2]))) * batch * n
+        rec['fp32_TFLOPs'] = round(2.0 * fmas / (per * 1e-3) / 1e12, 1)
+        rec['frac_of_fp32_vector_peak'] = round(2.0 * fmas / (per * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4)
+        rec['flop_per_byte'] = round(2.0 * fmas / bytes_per_launch, 1)
+        rec['bound'] = 'fp32 vector' if 2.0 * fmas / bytes_per_launch > FP32_VECTOR_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS else 'hbm'
         # one stream of what the timed launches wrote, against the C oracle (the last stream: the highest addresses)
         rec['parity_vs_oracle_of_peak'] = oracle_parity(xs[(iters - 1) % buffers][batch - 1], ys[(iters - 1) % buffers][batch - 1], taps, mode)
         rec['parity_stream'] = batch - 1
