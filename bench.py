@@ -250,10 +250,11 @@ def end_to_end(torch, vnd, mode) -> dict:
             rec[kind] = {'ms_per_call': round(dt * 1e3, 3), 'Msamples_s': round(x.size / dt / 1e6, 1),
                          'GBs_in_plus_out': round(2 * x.nbytes / dt / 1e9, 2)}
         out[name] = rec
-    out['note'] = ('host pointers in, host pointers out (H2D + kernel + D2H inside the call); the result array is '
-                   'allocated by the call as the reference does; never part of `value`.  A page-locked input is not faster '
-                   'for the large batch: page-locked uploads and downloads share the SDMA path (57 GB/s in total on this '
-                   'platform, tools/pcie_probe.py), a pageable upload is staged by the CPU beside the SDMA download')
+    out['note'] = ('host pointers in, host pointers out; the result array is allocated by the call as the reference does (from a '
+                   'page-locked pool); never part of `value`.  pageable: H2D + kernel + D2H inside the call, pipelined over groups of '
+                   'streams (one group: the kernel writes the result in place).  pinned: no staging, the kernel reads and writes the '
+                   'page-locked buffers in place across PCIe (profiles/r03_host_in_place.txt).  The pageable batch stays ahead: its '
+                   'upload is staged by the CPU beside the SDMA download, page-locked copies share the SDMA path (57 GB/s in total)')
     return out
 
 

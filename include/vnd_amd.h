@@ -247,6 +247,12 @@ vnd_status vnd_haas_f64_host(vnd_ctx *ctx, const float *x, double *y, int64_t ba
  * groups of streams on two HIP streams, so uploads, kernels and downloads overlap.        */
 vnd_status vnd_host_alloc(int64_t bytes, void **ptr);
 vnd_status vnd_host_free(void *ptr);
+/* When BOTH buffers of vnd_convolve_f32_host / vnd_convolve_fanout_f32_host are page-locked and mapped
+ * (vnd_host_alloc, hipHostMalloc, hipHostRegister), there is no staging at all: the
+ * kernel reads x and writes y in place, across PCIe in both directions at once (VND_HOST_DIRECT=0: never).
+ * *mapped = 1 if a call on these two buffers takes that path.  Results are the staged path's (bit for bit
+ * in VND_MODE_EXACT; VND_MODE_FAST within its tolerance - the kernel may be cut into other launches). */
+vnd_status vnd_host_buffers_mapped(const void *x, int64_t x_bytes, const void *y, int64_t y_bytes, int32_t *mapped);
 
 /* ---- measurement helpers (used by bench.py; not on the data path) ---------- */
 /* Launches the convolve `iters` times back to back on `hip_stream`, cycling

@@ -48,3 +48,44 @@ def test_time_pieces_only_for_a_few_long_streams(golden):
         y = d.convolve_velvet_noise_batched(x, fir) if x.ndim == 3 else d.convolve_velvet_noise(x, fir)
         ref = np.stack([O.convolve_velvet_noise(s, fir) for s in x]) if x.ndim == 3 else O.convolve_velvet_noise(x, fir)
         assert np.array_equal(y, ref), shape
+
+
+@pytest.mark.parametrize('shape', [(480000, 2), (3, 300007, 2), (2, 131072, 1), (16, 48000, 2), (250001, 2)])
+def test_page_locked_buffers_are_convolved_in_place(golden, monkeypatch, shape):
+    """Both buffers page-locked (the input from the library's own pool here; torch's pin_memory is the same kind of
+    memory): no staging - the kernel reads x and writes y across PCIe.  The library says so (vnd_host_buffers_mapped), the
+    exact result is the oracle's bytes and equals the staged path's, the fast result keeps its tolerance.  Below the
+    pool's 1 MiB threshold the result is an ordinary array and the call is staged."""
+    import vndecorrelate_amd.decorrelation as d
+    from vndecorrelate_amd import _native
+    from vndecorrelate_amd.taps import function_path_arrays
+    fir = golden.fir('g48k_k30')
+    a = function_path_arrays(fir)
+    table = _native.TapTable.create(_native.default_context(), a.tap_offsets, a.tap_index, a.tap_weight)
+    rng = np.random.default_rng(len(shape) * 1000 + shape[-2])
+    pageable = rng.uniform(-1, 1, shape).astype(np.float32)
+    x = _native.pinned_pool.empty(shape, np.float32)
+    x[...] = pageable
+    out_shape = shape[:-1] + (2,)
+    y_probe = _native.pinned_pool.empty(out_shape, np.float32)
+    assert _native.host_buffers_mapped(x, y_probe)
+    assert not _native.host_buffers_mapped(pageable, y_probe) and not _native.host_buffers_mapped(x, np.empty(out_shape, np.float32))
+    assert _native.host_buffers_mapped(x[..., 1000:, :], y_probe[..., 1000:, :]) if x.ndim == 2 else True      # a view: still mapped
+    del y_probe
+    offs, idx, w = O.fir_to_taps(fir)
+    got, fast = table.convolve_host(x, d.MODE_EXACT), table.convolve_host(x, d.MODE_FAST)
+    monkeypatch.setenv('VND_HOST_DIRECT', '0')                    # (read live: tests run with VND_TUNING=1)
+    staged = table.convolve_host(x, d.MODE_EXACT)
+    monkeypatch.delenv('VND_HOST_DIRECT')
+    assert np.array_equal(got, staged)
+    xs = x if x.ndim == 3 else x[None]
+    for b in range(xs.shape[0]):
+        xb = xs[b] if xs.shape[-1] == 2 else np.repeat(xs[b], 2, axis=1)
+        want = c_oracle.convolve(np.ascontiguousarray(xb), offs, idx, w)
+        gb, fb = (got[b], fast[b]) if x.ndim == 3 else (got, fast)
+        assert np.array_equal(gb, want), (shape, b)
+        assert np.max(np.abs(fb.astype(np.float64) - want)) <= 1e-6 * np.max(np.abs(want))
+    # the public function on a page-locked input: same bytes
+    if x.ndim == 2 and shape[-1] == 2:
+        assert np.array_equal(d.convolve_velvet_noise(x, fir), got)
+    table.close()

@@ -108,6 +108,8 @@ SIGNATURES = {
                                                  ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,
                                                  _c_f32p]),
     'vnd_host_alloc': (ctypes.c_int, [ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
+    'vnd_host_buffers_mapped': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                               ctypes.POINTER(ctypes.c_int32)]),
     'vnd_host_free': (ctypes.c_int, [ctypes.c_void_p]),
     'vnd_spec_kernel_source': (ctypes.c_int, [ctypes.c_int32, _c_i32p, _c_i32p, _c_f32p, ctypes.c_int32, ctypes.c_char_p,
                                               ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
@@ -609,6 +611,15 @@ def window_kernel_source(tap_offsets, tap_index, tap_weight, mode: int = MODE_FA
     _check(lib.vnd_window_kernel_source(*args, buf, need.value, ctypes.byref(need), None, None), 'vnd_window_kernel_source')
     src = buf.value.decode()
     return (src, lb.value, fm.value) if with_traffic else src
+
+
+def host_buffers_mapped(x: np.ndarray, y: np.ndarray) -> bool:
+    """True if a ``*_host`` convolution from ``x`` into ``y`` would run in place on the two buffers (both
+    page-locked and mapped: ``vnd_host_buffers_mapped``)."""
+    flag = ctypes.c_int32()
+    _check(load_library().vnd_host_buffers_mapped(x.ctypes.data, x.nbytes, y.ctypes.data, y.nbytes, ctypes.byref(flag)),
+           'vnd_host_buffers_mapped')
+    return bool(flag.value)
 
 
 def device_count() -> int:
