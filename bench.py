@@ -617,7 +617,7 @@ def main():
 
     # the device's own streaming ceiling on the same pool: a plain device copy (4 B read + 4 B
     # written per sample, the kernel's algorithmic traffic), the honest companion of the 8 TB/s figure
-    copy_gbs = None
+    copy_gbs = stream_copy_gbs = None
     if rank == 0:
         for _ in range(3):
             y.copy_(x)
@@ -629,6 +629,11 @@ def main():
         c1.record()
         torch.cuda.synchronize()
         copy_gbs = ALGO_BYTES_PER_SAMPLE * samples_per_step / (c0.elapsed_time(c1) / 10 * 1e-3) / 1e9
+        # ... and the best plain copy this library knows (16-byte non-temporal accesses, tools/micro/copy_ceiling.hip)
+        stream_ptr = torch.cuda.current_stream().cuda_stream
+        ctx.time_copy(x.data_ptr(), y.data_ptr(), x.numel(), 3, stream_ptr)
+        stream_copy_ms = ctx.time_copy(x.data_ptr(), y.data_ptr(), x.numel(), 20, stream_ptr)
+        stream_copy_gbs = ALGO_BYTES_PER_SAMPLE * samples_per_step / (stream_copy_ms * 1e-3) / 1e9
 
     launch_text = table.describe(args.pool, n, CHANNELS, mode)
     del x, y
@@ -673,6 +678,12 @@ def main():
                          'traffic_source': traffic_source,
                          'read_only_frac': round(achieved / 2 / HBM_PEAK_GBS, 4),
                          'kernel_ms': round(kernel_ms, 4), 'device_copy_GBs': round(copy_gbs, 1),
+                         'streaming_copy_GBs': round(stream_copy_gbs, 1),
+                         'frac_of_streaming_copy': round(achieved / stream_copy_gbs, 4),
+                         'streaming_copy_what': 'a plain copy of the same pool in this run (vnd_time_copy_f32_dev: 16-byte '
+                                                'non-temporal loads and stores; device_copy_GBs is torch\'s Tensor.copy_): what a '
+                                                'kernel that reads 4 B and writes 4 B per sample can reach on this box',
+
                          'limit': 'board power cap (1400 W; the shader clock falls to ~1.9 GHz under this kernel: '
                                   'profiles/r03_cfg2_power.txt), DESIGN.md 3.5',
                          'algorithmic_bytes_per_launch': ALGO_BYTES_PER_SAMPLE * samples_per_step},

@@ -264,6 +264,11 @@ vnd_status vnd_time_convolve_f32_dev(vnd_ctx *ctx, const vnd_taps *taps, const f
                                      int32_t n_channels, int32_t mode, int32_t n_buffers,
                                      int64_t stride_elems, int32_t iters, void *hip_stream,
                                      float *avg_ms);
+/* The box's streaming ceiling, as a companion of the 8 TB/s figure: `iters` plain copies of `elems`
+ * floats (a multiple of 4; 16-byte aligned buffers) with 16-byte non-temporal accesses, the average
+ * kernel milliseconds between two hipEvents on `hip_stream`.                                    */
+vnd_status vnd_time_copy_f32_dev(vnd_ctx *ctx, const float *x_dev, float *y_dev, int64_t elems,
+                                 int32_t iters, void *hip_stream, float *avg_ms);
 /* VND_MODE_FAST and VND_MODE_EXACT compile a kernel PER TAP TABLE with hipRTC on first use
  * (offsets become LDS-read immediates, weights literals; persistent workgroups over an LDS ring;
  * `mode` picks the arithmetic: free summation order, or the reference's own association bit for

@@ -107,6 +107,8 @@ SIGNATURES = {
                                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                  ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,
                                                  _c_f32p]),
+    'vnd_time_copy_f32_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                             ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
     'vnd_host_alloc': (ctypes.c_int, [ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
     'vnd_host_buffers_mapped': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                                ctypes.POINTER(ctypes.c_int32)]),
@@ -320,6 +322,14 @@ class Context:
 
     def set_variant(self, variant: int):
         _check(self._lib.vnd_set_variant(self.handle, int(variant)), 'vnd_set_variant')
+
+    def time_copy(self, x_ptr: int, y_ptr: int, elems: int, iters: int = 10, stream: int = 0) -> float:
+        """Average kernel milliseconds of a plain streaming copy of ``elems`` floats (``vnd_time_copy_f32_dev``:
+        the box's streaming ceiling for bench.py; not on the data path)."""
+        ms = ctypes.c_float()
+        _check(self._lib.vnd_time_copy_f32_dev(self.handle, ctypes.c_void_p(x_ptr), ctypes.c_void_p(y_ptr), int(elems),
+                                               int(iters), ctypes.c_void_p(stream), ctypes.byref(ms)), 'vnd_time_copy_f32_dev')
+        return float(ms.value)
 
 
 class TapTable:

@@ -1337,6 +1337,48 @@ vnd_status vnd_time_convolve_f32_dev(vnd_ctx *ctx, const vnd_taps *t, const floa
     return VND_OK;
 }
 
+// The streaming ceiling of the box, for bench.py: a plain copy with the per-table kernels' access shape (16 bytes per
+// lane, non-temporal loads and stores) - the best of the shapes tools/micro/copy_ceiling.hip tries (5.9 TB/s on 7.9 GB
+// each way, where hipMemcpyAsync reaches 5.1).  Not on the data path.
+typedef float copy_v4f __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_copy_kernel(const copy_v4f *x, copy_v4f *y, long long quads)
+{
+    const long long stride = (long long)gridDim.x * 256 * 4;
+    for (long long base = (long long)blockIdx.x * 256 * 4 + threadIdx.x; base < quads; base += stride) {
+        copy_v4f a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (base + k * 256 < quads) a[k] = __builtin_nontemporal_load(x + base + k * 256);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (base + k * 256 < quads) __builtin_nontemporal_store(a[k], y + base + k * 256);
+    }
+}
+
+vnd_status vnd_time_copy_f32_dev(vnd_ctx *ctx, const float *x, float *y, int64_t elems, int32_t iters, void *stream_, float *avg_ms)
+{
+    if (!ctx || !x || !y || !avg_ms || iters <= 0 || elems <= 0 || (elems & 3)) return fail(VND_ERR_INVALID, "bad copy timing arguments");
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return fail(VND_ERR_INVALID, "the copy wants 16-byte aligned buffers");
+    DeviceScope on(ctx->device);
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long quads = elems / 4;
+    const unsigned grid = (unsigned)std::min<long long>(65536, (quads + 1023) / 1024);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t he = hipEventCreate(&e0);
+    if (he == hipSuccess) he = hipEventCreate(&e1);
+    if (he == hipSuccess) he = hipEventRecord(e0, stream);
+    for (int i = 0; he == hipSuccess && i < iters; ++i)
+        hipLaunchKernelGGL(stream_copy_kernel, dim3(grid), dim3(256), 0, stream, (const copy_v4f *)x, (copy_v4f *)y, quads);
+    float ms = 0.f;
+    if (he == hipSuccess) he = hipEventRecord(e1, stream);
+    if (he == hipSuccess) he = hipEventSynchronize(e1);
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+    if (he == hipSuccess) he = hipGetLastError();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (he != hipSuccess) return fail(VND_ERR_HIP, "copy timing: %s", hipGetErrorString(he));
+    *avg_ms = ms / iters;
+    return VND_OK;
+}
+
 vnd_status vnd_host_alloc(int64_t bytes, void **ptr)
 {
     if (!ptr || bytes <= 0) return fail(VND_ERR_INVALID, "bad host allocation request");
