@@ -412,7 +412,9 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
                 g.nt, g.M, g.R, g.G, g.NB, g.DE, g.plane, c.la);
     spec_append(s, "#define VW_NT_STORES %d\n#define VW_EPI %d\n#define VW_BC %d\n#define VW_EXACT %d\n#define VW_C %d\n", c.nt_stores, c.epi, c.bc, c.exact, g.C);
     spec_append(s, "#define VW_NT_STORE_AUX %d\n", spec_env("VND_SPEC_STORE_AUX", 2));
-    spec_append(s, "#define VW_DEBUG %d\n", spec_env("VND_WIN_DEBUG", 0));          // diagnosis builds (wrong results): see the kernel
+    // diagnosis builds (WRONG results on purpose: no stores / every load from one place - see the kernel): only in a tuning session
+    const char *tuning = getenv("VND_TUNING");
+    spec_append(s, "#define VW_DEBUG %d\n", (tuning && *tuning && *tuning != '0') ? spec_env("VND_WIN_DEBUG", 0) : 0);
     // s_setprio of the store / refill phase (0: none): cfg2 +1.0 % fast, +0.5 % exact at 1, 2 or 3; cfg3 unchanged (tools/win_phase_try.py)
     spec_append(s, "#define VW_PRIO %d\n", spec_env("VND_WIN_PRIO", 1));
     spec_append(s, "#define VW_LOAD_AUX %d\n", spec_env("VND_SPEC_LOAD_AUX", 2));
