@@ -60,6 +60,6 @@ if 'hbm_read_bytes_per_launch' in derived and 'hbm_write_bytes_per_launch' in de
 stats = glob.glob(str(REPO / 'gpurun_out' / f'prof_{tag}' / 'trace' / '**' / '*kernel_stats.csv'), recursive=True)
 if stats:
     lines = pathlib.Path(stats[0]).read_text().splitlines()
-    keep = [lines[0]] + [l for l in lines[1:] if 'vnd' in l or 'copyBuffer' in l]      # vnd:: kernels and the hipRTC-built vnd_spec_kernel
+    keep = [lines[0]] + [l for l in lines[1:] if 'vnd' in l or 'copyBuffer' in l or 'stream_copy_kernel' in l]      # vnd:: kernels, the hipRTC-built vnd_spec_kernel, the copies beside them
     (REPO / 'profiles' / f'{stem}_kernel_stats.csv').write_text('\n'.join(keep) + '\n')
 print(json.dumps({'kernel': kernel, 'trace': trace, 'derived': derived}, indent=1))
