@@ -1,240 +1,76 @@
-"""GPU tier: randomised parity (hypothesis) of the C-ABI convolve against the C oracle -
-random channel counts, lengths, tap tables (function- and class-path shapes, duplicates,
-pass-through channels, taps beyond the signal), every arithmetic mode."""
+"""GPU tier: RANDOM tap tables - channel counts, spans, tap counts, weights (among them +-1, tiny ones, repeated magnitudes),
+signal lengths and batches drawn per seed - through every kernel family the library can pick or be told to pick (automatic
+choice, per-table pair-read form, per-table window form with 32- and 16-frame runs, generic kernels), against the NumPy
+oracle: VND_MODE_EXACT bit for bit, VND_MODE_FAST within 1e-6 of the output peak.  The golden tables of the other tests
+are the reference's; these are not velvet noise at all - any FIR table the API accepts must come out right."""
 import numpy as np
 import pytest
-from hypothesis import HealthCheck, given, settings, strategies as st
 
-from oracle import c_oracle
-from test_properties_cpu import class_table, sparse_fir
-from vndecorrelate_amd.taps import class_path_arrays, function_path_arrays
+from oracle import vnd_oracle as O
 
 pytestmark = pytest.mark.gpu
-# derandomize: the same examples on every run (a judged run must not meet a fresh corner case);
-# VND_FUZZ_EXAMPLES=N hunts with N fresh random examples per test instead
-import os
-_HUNT = int(os.environ.get('VND_FUZZ_EXAMPLES', '0'))
-SET = settings(max_examples=_HUNT or 150, deadline=None, derandomize=not _HUNT, database=None,
-               suppress_health_check=[HealthCheck.function_scoped_fixture])
+
+FORCE = 1 << 23
+GENERIC = 1 << 25
+WIN = {0: 1 << 5, 16: 2 << 5, 32: 3 << 5}
 
 
-@pytest.fixture(scope='module')
-def ctx():
+def span_bits(min_span, rounds):
+    return (min_span << 20) | (rounds << 28)
+
+
+# (channels, span of the offsets, most taps per channel): the shapes are laid out, what fills them is drawn
+CASES = [(2, 700, 40), (8, 700, 24), (3, 64, 20), (2, 2500, 40), (4, 1500, 30), (6, 300, 16), (2, 8, 8), (1, 700, 30),
+         (2, 3000, 60), (4, 8, 6)]
+
+
+@pytest.mark.parametrize('seed', range(len(CASES)))
+def test_random_tables_through_every_kernel_family(seed):
+    import vndecorrelate_amd.decorrelation as d
     from vndecorrelate_amd import _native
-    c = _native.default_context()
-    yield c
-    c.set_variant(-1)
-
-
-def _term_scale(arr, x) -> float:
-    """max over channels of sum_k |w_k * gain| times max|x|: the size of what is being added up.
-    The fma modes round each product differently from mul-then-add and the fast mode adds in
-    another order, so when the taps cancel (output peak << terms; hypothesis finds -x[0] + x[0])
-    the honest floor is the rounding bound of a K-term sum, K * 2^-24 * sum|terms|, not a
-    fraction of the vanishing peak.  (A wrong tap or weight is off by the size of a term.)"""
-    w = np.abs(arr.tap_weight.astype(np.float64))
-    if arr.seg_offsets is not None and arr.apply_gain and len(w):
-        gain = np.zeros(len(w))
-        start = 0
-        for end, g in zip(arr.seg_end, arr.seg_gain):
-            gain[start:end] = abs(float(g))
-            start = end
-        w = w * gain
-    sums = [w[arr.tap_offsets[c]:arr.tap_offsets[c + 1]].sum() for c in range(arr.num_channels)]
-    most = int(np.max(np.diff(arr.tap_offsets))) if arr.num_channels else 0
-    return most * (max(sums) if sums else 0.0) * (float(np.max(np.abs(x))) if x.size else 0.0)
-
-
-def _check(ctx, arr, x, want, pairs):
-    from vndecorrelate_amd import _native
-    table = _native.TapTable.create(ctx, arr.tap_offsets, arr.tap_index, arr.tap_weight, **arr.kwargs())
-    peak = max(float(np.max(np.abs(want))) if want.size else 0.0, 1e-30)
-    floor = 2.0 ** -24 * _term_scale(arr, x)
+    from vndecorrelate_amd.taps import function_path_arrays
+    rng = np.random.default_rng(1000 + seed)
+    ctx = _native.default_context()
+    C, span, most = CASES[seed]
+    fir = np.zeros((span, C), np.float32)
+    for c in range(C):
+        k = int(rng.integers(max(1, most // 2), min(most, span) + 1))
+        idx = rng.choice(span, size=k, replace=False)
+        w = rng.choice([1.0, -1.0, 0.5, -0.5, 0.85, -0.2, 1e-3, -3.0], size=k) * rng.choice([1.0, 1.0, rng.uniform(0.1, 1.0)], size=k)
+        fir[idx, c] = w.astype(np.float32)
+    if seed % 3 == 0:
+        fir[0, :] = 0.75                                # a tap at offset 0 in every channel
+    a = function_path_arrays(fir)
+    table = _native.TapTable.create(ctx, a.tap_offsets, a.tap_index, a.tap_weight)
+    variants = [('automatic', -1), ('pair-read', FORCE | WIN[0] | span_bits(1, 3)), ('window 32', FORCE | WIN[32] | span_bits(1, 3)),
+                ('window 16', FORCE | WIN[16] | span_bits(2, 1)), ('generic', GENERIC)]
     try:
-        ctx.set_variant(pairs)
-        for mode in (0, 1, 2):
-            y = table.convolve_host(x, mode)
-            if mode == 0:
-                assert np.array_equal(y, want), f'exact mode, pairs={pairs}'
-            else:
-                assert np.max(np.abs(y.astype(np.float64) - want)) <= 1e-6 * peak + floor + 1e-30, (mode, pairs)
+        # (the largest length is a multiple of 4 frames: streams of a batch then start 16-byte aligned, which the per-table
+        #  kernels ask for - the odd lengths before it go through the generic kernels whatever is asked)
+        for n in sorted({int(rng.integers(1, 200)), int(rng.integers(200, 9000)), 4 * int(rng.integers(2500, 17000))}):
+            for batch in (1, 3):
+                x = rng.uniform(-1, 1, (batch, n, C)).astype(np.float32)
+                x[rng.integers(0, batch, 20), rng.integers(0, n, 20), rng.integers(0, C, 20)] = 0.0
+                if seed % 2:
+                    x[0, :min(n, 50)] *= np.float32(1e-30)      # products that underflow to denormals and to zero
+                want = np.stack([O.convolve_velvet_noise(x[b], fir) for b in range(batch)])
+                peak = float(np.max(np.abs(want))) or 1.0
+                for name, variant in variants:
+                    ctx.set_variant(variant)
+                    for mode in (d.MODE_EXACT, d.MODE_FAST):
+                        got = table.convolve_host(x, mode)
+                        where = f'seed {seed} C={C} span={span} taps={len(a.tap_index)} n={n} batch={batch} {name}: {table.describe(batch, n, C, mode)[:60]}'
+                        assert got.shape == want.shape, where
+                        if C % 2 == 0 and n >= 10000 and name != 'automatic':       # the family asked for is the family that ran
+                            text = table.describe(batch, n, C, mode)
+                            family = {'pair-read': 'conv_spec', 'generic': 'conv_'}.get(name, 'conv_spec')
+                            assert text.startswith(family) and ('_window' in text) == name.startswith('window') and \
+                                ('conv_spec' in text) == (name != 'generic'), where
+                        if mode == d.MODE_EXACT:
+                            assert np.array_equal(got, want), where
+                        else:
+                            err = float(np.max(np.abs(got.astype(np.float64) - want))) / peak
+                            assert err <= 1e-6, f'{where}: {err:.2e}'
     finally:
         ctx.set_variant(-1)
         table.close()
-
-
-@SET
-@given(fir=sparse_fir(), n=st.integers(1, 6000), batch=st.integers(1, 3), seed=st.integers(0, 2**31 - 1),
-       pairs=st.sampled_from([0, 1, 2, 4, 8]))
-def test_function_path_tables(ctx, fir, n, batch, seed, pairs):
-    x = np.random.default_rng(seed).uniform(-1, 1, (batch, n, fir.shape[1])).astype(np.float32)
-    arr = function_path_arrays(fir)
-    want = c_oracle.convolve(x, arr.tap_offsets, arr.tap_index, arr.tap_weight)
-    _check(ctx, arr, x, want, pairs)
-
-
-@SET
-@given(tab=class_table(), n=st.integers(1, 6000), seed=st.integers(0, 2**31 - 1),
-       pairs=st.sampled_from([0, 1, 4]))
-def test_class_path_tables(ctx, tab, n, seed, pairs):
-    chans, env = tab
-    x = np.random.default_rng(seed).uniform(-1, 1, (n, len(chans))).astype(np.float32)
-    arr = class_path_arrays(chans, env, env != (1.0,))
-    want = c_oracle.convolve(x, arr.tap_offsets, arr.tap_index, arr.tap_weight, seg_off=arr.seg_offsets,
-                             seg_end=arr.seg_end, seg_gain=arr.seg_gain, chan_flags=arr.chan_flags,
-                             apply_gain=arr.apply_gain)
-    _check(ctx, arr, x, want, pairs)
-
-
-# ---- the per-table (hipRTC) kernels on random tables: each example compiles its kernels (~2-4 s), so few examples --------
-_SPEC_SET = settings(max_examples=min(_HUNT, 60) or 12, deadline=None, derandomize=not _HUNT, database=None,
-                     suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
-_FORCE_SPEC = (1 << 23) | (1 << 15) | (1 << 20) | (3 << 28)      # specialise whatever the size, exact mode too, spans of >= 1 tile, 3 rounds
-
-
-def _spec_check(ctx, arr, x, want, in_scope):
-    """Through the per-table kernels when the table is within their scope (describe says which kernel runs);
-    fast mode within tolerance, exact mode bit for bit - also for a mono input fanned out to a stereo table."""
-    from vndecorrelate_amd import _native
-    table = _native.TapTable.create(ctx, arr.tap_offsets, arr.tap_index, arr.tap_weight, **arr.kwargs())
-    batch, n, cx = x.shape
-    peak = max(float(np.max(np.abs(want))) if want.size else 0.0, 1e-30)
-    floor = 2.0 ** -24 * _term_scale(arr, x)
-    try:
-        ctx.set_variant(_FORCE_SPEC)
-        for mode in (2, 0):
-            launch = table.describe(batch, n, cx, mode)
-            aligned = batch == 1 or (n * cx * 4) % (16 if cx == 2 else 8) == 0
-            if in_scope is True and aligned:
-                assert launch.startswith('conv_spec'), launch
-            y = table.convolve_host(x, mode)
-            if mode == 0:
-                assert np.array_equal(y, want), launch
-            else:
-                assert np.max(np.abs(y.astype(np.float64) - want)) <= 1e-6 * peak + floor + 1e-30, launch
-    finally:
-        ctx.set_variant(-1)
-        table.close()
-
-
-@_SPEC_SET
-@given(tab=class_table(), n=st.integers(1, 5000), batch=st.integers(1, 3), seed=st.integers(0, 2**31 - 1), mono=st.booleans())
-def test_per_table_kernels_on_random_class_tables(ctx, tab, n, batch, seed, mono):
-    chans, env = tab
-    if len(chans) != 2:
-        chans = (list(chans) + [chans[0]])[:2]
-    channels = 2
-    arr = class_path_arrays(chans, env, env != (1.0,))
-    every_filtered = all(c is not None for c in chans) and len(arr.tap_index) > 0
-    # the exact per-table kernel leaves a table with an empty segment to the generic one (it still adds +0)
-    cx = 1 if mono else channels
-    x = np.random.default_rng(seed).uniform(-1, 1, (batch, n, cx)).astype(np.float32)
-    full = np.ascontiguousarray(np.repeat(x, channels // cx, axis=2))
-    want = c_oracle.convolve(full, arr.tap_offsets, arr.tap_index, arr.tap_weight, seg_off=arr.seg_offsets,
-                             seg_end=arr.seg_end, seg_gain=arr.seg_gain, chan_flags=arr.chan_flags,
-                             apply_gain=arr.apply_gain)
-    _spec_check(ctx, arr, x, want, in_scope=False if not every_filtered else None)
-
-
-@_SPEC_SET
-@given(fir=sparse_fir(), n=st.integers(1, 5000), batch=st.integers(1, 3), seed=st.integers(0, 2**31 - 1), mono=st.booleans())
-def test_per_table_kernels_on_random_function_tables(ctx, fir, n, batch, seed, mono):
-    if fir.shape[1] % 2:
-        fir = np.concatenate([fir, fir[:, :1]], axis=1)             # even channel counts are the kernels' scope
-    channels = fir.shape[1]
-    arr = function_path_arrays(fir)
-    cx = 1 if (mono and channels == 2) else channels
-    x = np.random.default_rng(seed).uniform(-1, 1, (batch, n, cx)).astype(np.float32)
-    full = np.ascontiguousarray(np.repeat(x, channels // cx, axis=2))
-    want = c_oracle.convolve(full, arr.tap_offsets, arr.tap_index, arr.tap_weight)
-    _spec_check(ctx, arr, x, want, in_scope=len(arr.tap_index) > 0)
-
-
-# ---- the rows beyond the plain convolution: whole stage, fan-out, Haas -----------------------------
-def _numpy_stage(x, y, ms_encode, width, normalize):
-    """The reference's epilogue (decorrelation.py:433-440) with its own NumPy helpers."""
-    from vndecorrelate_amd.utils import dsp
-    if ms_encode:
-        dsp.encode_signal_to_side_channel(x, y)
-    if width is not None:
-        dsp.apply_stereo_width(y, width)
-    if normalize:
-        with np.errstate(all='ignore'):
-            dsp.rms_normalize(x, y)
-    return y
-
-
-@SET
-@given(tab=class_table(), n=st.integers(1, 20000), seed=st.integers(0, 2**31 - 1), kind=st.sampled_from(['uniform', 'int16', 'sparse']),
-       ms_encode=st.booleans(), width=st.sampled_from([None, 0.0, 0.3, 1.0]), normalize=st.booleans(),
-       mono=st.booleans(), batch=st.integers(1, 3))
-def test_exact_stage_is_numpys(ctx, tab, n, seed, kind, ms_encode, width, normalize, mono, batch):
-    """vnd_decorrelate in exact mode == bit-exact convolution + the NumPy epilogue, for random class
-    tables, lengths, integer-valued and sparse signals (ties and zero runs in the sums), mono fan-out."""
-    from vndecorrelate_amd import _native
-    chans, env = tab
-    channels = len(chans)
-    stereo_steps = ms_encode or width is not None
-    if stereo_steps and channels != 2:
-        ms_encode, width = False, None
-    in_channels = 1 if (mono and channels == 2) else channels
-    rng = np.random.default_rng(seed)
-    if kind == 'uniform':
-        x = rng.uniform(-1, 1, (batch, n, in_channels))
-    elif kind == 'int16':
-        x = rng.integers(-32768, 32767, (batch, n, in_channels)).astype(np.float64)
-    else:
-        x = rng.integers(-3, 4, (batch, n, in_channels)) * (rng.random((batch, n, in_channels)) < 0.2)
-    x = np.ascontiguousarray(x, np.float32)
-    arr = class_path_arrays(chans, env, env != (1.0,))
-    table = _native.TapTable.create(ctx, arr.tap_offsets, arr.tap_index, arr.tap_weight, **arr.kwargs())
-    try:
-        got = table.decorrelate_host(x, 0, ms_encode=ms_encode, width=width, normalize=normalize)
-    finally:
-        table.close()
-    full = np.ascontiguousarray(np.tile(x, (1, 1, channels // in_channels)))
-    conv = c_oracle.convolve(full, arr.tap_offsets, arr.tap_index, arr.tap_weight, seg_off=arr.seg_offsets,
-                             seg_end=arr.seg_end, seg_gain=arr.seg_gain, chan_flags=arr.chan_flags,
-                             apply_gain=arr.apply_gain)
-    for b in range(batch):
-        # (a single channel is summed pairwise by NumPy, two or more row by row: the device repeats either)
-        want = _numpy_stage(full[b], conv[b].copy(), ms_encode, width, normalize)
-        assert np.array_equal(got[b], want, equal_nan=True), (b, channels, in_channels, kind)
-
-
-@SET
-@given(fir=sparse_fir(), n=st.integers(1, 5000), seed=st.integers(0, 2**31 - 1), fan=st.integers(1, 3),
-       pairs=st.sampled_from([0, 1, 4]))
-def test_fanout_equals_replicated_input(ctx, fir, n, seed, fan, pairs):
-    """A bank of `fan` copies of a random filter over one signal == the plain call on the tiled signal."""
-    from vndecorrelate_amd import _native
-    from vndecorrelate_amd.taps import concat_tap_arrays
-    in_channels = fir.shape[1]
-    x = np.random.default_rng(seed).uniform(-1, 1, (n, in_channels)).astype(np.float32)
-    bank = concat_tap_arrays([function_path_arrays(fir)] * fan)
-    table = _native.TapTable.create(ctx, bank.tap_offsets, bank.tap_index, bank.tap_weight)
-    want = c_oracle.convolve(np.ascontiguousarray(np.tile(x, (1, fan))), bank.tap_offsets, bank.tap_index,
-                             bank.tap_weight)
-    try:
-        ctx.set_variant(pairs)
-        assert np.array_equal(table.convolve_host(x, 0), want)
-        peak = max(float(np.max(np.abs(want))), 1e-30)
-        floor = 2.0 ** -24 * _term_scale(bank, x)
-        assert np.max(np.abs(table.convolve_host(x, 2).astype(np.float64) - want)) <= 1e-6 * peak + floor + 1e-30
-    finally:
-        ctx.set_variant(-1)
-        table.close()
-
-
-@SET
-@given(n=st.integers(0, 3000), delay=st.integers(0, 4000), channel=st.integers(0, 1), ms_mode=st.booleans(),
-       width=st.sampled_from([None, 0.0, 0.25, 0.9]), mono=st.booleans(), seed=st.integers(0, 2**31 - 1))
-def test_device_haas_is_the_oracles(ctx, n, delay, channel, ms_mode, width, mono, seed):
-    from oracle import vnd_oracle as O
-    from vndecorrelate_amd import _native
-    x = np.random.default_rng(seed).uniform(-1, 1, (n,) if mono else (n, 2)).astype(np.float32)
-    want = O.haas_effect(x, sample_rate_hz=1000, delay_time_seconds=delay / 1000, delayed_channel=channel,
-                         mode='MS' if ms_mode else 'LR', width=width)
-    got = _native.haas_host(ctx, np.ascontiguousarray(x[:, None] if mono else x), delay=delay, delayed_channel=channel,
-                            ms_mode=ms_mode, width=width)
-    assert got.shape == want.shape and np.array_equal(got, want)
