@@ -74,3 +74,45 @@ def test_random_tables_through_every_kernel_family(seed):
     finally:
         ctx.set_variant(-1)
         table.close()
+
+
+# (sample rate, seconds of filter, impulses, segment envelope, log strength, width, mode, normalise, input: frames / channels)
+CLASS_CASES = [
+    (48000, 0.03, 30, None, 1.0, None, 'MS', True, (48000, 2)),
+    (44100, 0.02, 12, (0.9, 0.5, 0.2), 0.5, 0.3, 'MS', True, (30011, 2)),
+    (96000, 0.03, 64, (1.0,), 0.0, None, 'LR', True, (100000, 2)),
+    (22050, 0.05, 40, (0.85, 0.55, 0.35, 0.2, 0.1), 1.0, 1.0, 'MS', False, (7001, 2)),
+    (48000, 0.01, 5, (0.7, 0.7), 2.0, 0.0, 'LR', False, (500, 2)),
+    (48000, 0.03, 30, None, 1.0, None, 'MS', True, (20000, 1)),          # a mono signal: duplicated to stereo first
+    (32000, 0.04, 100, (1.0, 0.25), 0.3, 0.6, 'MS', True, (64000, 2)),
+    (48000, 0.03, 30, None, 1.0, 0.5, 'LR', True, (200, 2)),             # shorter than the filter
+]
+
+
+@pytest.mark.parametrize('case', range(len(CLASS_CASES)))
+def test_random_class_configurations_match_the_oracle(case):
+    """VelvetNoise with fields away from the defaults (sample rate, filter length, impulse and segment counts, envelope,
+    log-distribution strength, width, layout mode, normaliser off, seeds drawn per case) on random signals, against the
+    oracle's restatement of the whole stage (tap generation included): bit for bit - the stage's default arithmetic is
+    the reference's."""
+    import vndecorrelate_amd.decorrelation as d
+    rate, seconds, impulses, envelope, strength, width, mode, normalise, shape = CLASS_CASES[case]
+    rng = np.random.default_rng(500 + case)
+    for seed in (int(rng.integers(0, 2 ** 31)), int(rng.integers(0, 2 ** 31))):
+        kw = dict(sample_rate_hz=rate, duration_seconds=seconds, num_impulses=impulses, log_distribution_strength=strength,
+                  width=width, seed=seed)
+        if envelope is not None:
+            kw['segment_envelope'] = envelope
+        vn = d.VelvetNoise(mode=d.LayoutMode[mode], **kw) if normalise else d.VelvetNoise(mode=d.LayoutMode[mode], normalizer=None, **kw)
+        x = rng.uniform(-1, 1, shape if shape[1] == 2 else shape[:1]).astype(np.float32)
+        want = O.decorrelate(x, mode=mode, normalize=normalise, **kw)
+        got = vn.decorrelate(x)
+        assert got.dtype == want.dtype and got.shape == want.shape, (case, seed)
+        assert np.array_equal(got, want), f'case {case} seed {seed}: {float(np.max(np.abs(got - want))):.3e}'
+        # convolve alone, and a second signal through the same (cached) table
+        taps = O.generate_class_taps(sample_rate_hz=rate, duration_seconds=seconds, num_impulses=impulses,
+                                     segment_envelope=envelope if envelope is not None else O.DEFAULT_ENVELOPE,
+                                     log_distribution_strength=strength, seed=seed)
+        x2 = rng.uniform(-1, 1, (shape[0] + 17, 2)).astype(np.float32)
+        env = tuple(envelope) if envelope is not None else tuple(O.DEFAULT_ENVELOPE)
+        assert np.array_equal(vn.convolve(x2), O.class_convolve(x2, taps, env, 2)), (case, seed)
