@@ -1,6 +1,8 @@
 // vnd_win.hpp - the WINDOW form of the per-table kernel: geometry and source generator (host code, pure:
 // testable without a device).  The kernel's fixed part is vnd_win_kernel.inc; what is generated here is
-// the prologue of geometry macros and vw_taps(), one lane's tap sum fully unrolled:
+// the prologue of geometry macros and vw_taps(), one lane's tap sum fully unrolled - one such function per channel PAIR of
+// the table (vw_taps, vw_taps_1, ...: a workgroup works on one pair of a span; a stereo table has the one), each over
+// the pair's two LDS plane sets:
 //   * the lane owns M consecutive output frames j = 0 .. M-1 of both channels;
 //   * per channel the union of the taps' windows [i, i + M) is read once, in ascending 16-byte chunks
 //     (elements o .. o+3 of the lane's view, o = 0 at the lane's first own frame);
