@@ -237,10 +237,16 @@ class _TableCache:
 _fir_tables = _TableCache()
 
 
+try:                                   # a 128-bit content hash of the filter per call: xxh3 takes 0.7 us for a 30 ms stereo
+    from xxhash import xxh3_128_digest as _digest16          # filter where blake2b takes 16 (of a 190 us call)
+except ImportError:                    # pragma: no cover - the hash is an optional dependency
+    def _digest16(view):
+        return hashlib.blake2b(view.tobytes(), digest_size=16).digest()
+
+
 def _fir_key(fir: np.ndarray, channels: int):
     view = np.ascontiguousarray(fir[:, :channels])
-    return (view.shape, str(view.dtype), hashlib.blake2b(view.tobytes(), digest_size=16).digest(),
-            _native.default_context().device)
+    return (view.shape, str(view.dtype), _digest16(view), _native.default_context().device)
 
 
 def _promoted_convolve(x: NDArray, fir: NDArray, num_channels: int, mode: int) -> Optional[NDArray]:
