@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Window kernel, fast mode: what the store / refill phase costs and whether wave priorities help.
 A fresh table per setting (a table keeps its built kernels; these switches are not part of a kernel's key).
-  VND_WIN_DEBUG=1  no stores (wrong results on purpose)      VND_WIN_PRIO=k  s_setprio k between the tile's two barriers
+  VND_WIN_DEBUG=1  no stores, 4: no barriers (wrong results on purpose)      VND_WIN_PRIO=k  s_setprio k between the tile's two barriers
 usage: win_phase_try.py [cfg2|cfg3|cfg4] [seconds per setting]"""
 import os, pathlib, sys, time
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
@@ -29,7 +29,7 @@ x = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1
 y = torch.empty_like(x)
 st = torch.cuda.current_stream().cuda_stream
 ref = None
-settings = [dict(), dict(VND_WIN_DEBUG=1), dict(VND_WIN_PRIO=1), dict(VND_WIN_PRIO=3), dict(), dict(VND_WIN_PRIO=2)]
+settings = [dict(), dict(VND_WIN_DEBUG=1), dict(VND_WIN_DEBUG=4), dict(VND_WIN_DEBUG=5), dict(VND_WIN_PRIO=0), dict()]
 modes = [2, 0] if len(sys.argv) > 3 and sys.argv[3] == 'both' else [2]
 for env in settings:
     for k in ('VND_WIN_DEBUG', 'VND_WIN_PRIO'):
