@@ -35,6 +35,8 @@ struct WinGeom {
     int tile() const { return nt * M; }
 };
 
+inline int win_workgroups_per_cu(const WinGeom &g);
+
 // Geometry of the window kernel for a table; false when it does not fit (the caller keeps the pair-read kernel).
 inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size_t lds_limit, WinGeom *g)
 {
@@ -45,18 +47,38 @@ inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size
     if ((int64_t)t.idx.size() * M > 32768) return false;
     if (t.C < 2 || (t.C & 1) || (bc && t.C != 2)) return false;      // whole channel pairs
     g->M = M; g->nt = nt; g->G = G; g->npl = bc ? 1 : 2; g->C = t.C;
-    g->DE = (t.max_index + M - 1) / M;
-    g->R = nt + g->DE;
-    g->NB = g->DE / G + 1;
     const int qc = M / 4;
-    int units = g->R + G;                               // 16-byte slots of one chunk plane: ring + mirror
-    // the 8-byte accesses of the staging and of the transposition touch QC planes at once: an ODD multiple of 16/QC slots
-    // between planes spreads them over all banks (QC = 8: stride = 2 mod 4; QC = 4: 4 mod 8; QC = 16: odd)
-    while (units % (32 / qc) != 16 / qc) ++units;
-    g->plane = units * 16;
-    if ((size_t)(qc - 1) * g->plane + (size_t)G * 16 >= 65536) return false;      // ds offset field
-    if ((size_t)qc * g->plane >= 65536 && !bc) return false;                       // channel 1's planes as an immediate
-    return g->lds_bytes() <= lds_limit;
+    auto lay_out = [&](int de) {
+        g->DE = de;
+        g->R = nt + g->DE;
+        g->NB = g->DE / G + 1;
+        int units = g->R + G;                           // 16-byte slots of one chunk plane: ring + mirror
+        // the 8-byte accesses of the staging and of the transposition: 16 lanes at a time write (read) 32 dwords into 32 banks -
+        // 8 planes x 2 halves of ONE entry with 32-frame runs (4 planes of two entries with 16, 8 of the 16 planes with 64) - so the
+        // planes must lie an ODD multiple of 8/QC slots apart (QC = 8: an odd number of slots; QC = 4: 2 mod 4; QC = 16: odd).
+        // Counted, not guessed (SQ_LDS_BANK_CONFLICT per launch of 512 cfg2 streams, tools/ablate/run_r3f.sh): odd 7.7 M,
+        // 2 mod 4 - the rule until late round 3 - 16.2 M, 4 mod 8 56 M, 0 mod 8 137 M.
+        const int mod_rule = std::max(2, 16 / qc), res_rule = std::max(1, 8 / qc);
+        const int res = spec_env("VND_WIN_PLANE_RES", -1), mod = spec_env("VND_WIN_PLANE_MOD", mod_rule);      // (tuning)
+        while (units % mod != (res >= 0 ? res : res_rule)) ++units;
+        g->plane = units * 16;
+        if ((size_t)(qc - 1) * g->plane + (size_t)G * 16 >= 65536) return false;  // ds offset field
+        if ((size_t)qc * g->plane >= 65536 && !bc) return false;                   // channel 1's planes as an immediate
+        return g->lds_bytes() <= lds_limit;
+    };
+    const int de = (t.max_index + M - 1) / M;
+    if (!lay_out(de)) return false;
+    // A wave's window read is 64 consecutive ring entries - 16 bytes each, so entry e sits in banks 4e .. 4e+3 (mod 64) - EXCEPT in
+    // the wave whose lanes straddle the ring's end: there entry R-1 is followed by entry 0, and unless R is a multiple of 16
+    // entries the two runs of lanes meet in the same banks (13 % of all LDS cycles on cfg2 were such conflicts: R = 301).  A few
+    // entries of extra halo make the wrap invisible to the banks - taken when they cost no workgroup of residency.
+    const int aligned = de + (16 - (nt + de) % 16) % 16;
+    if (aligned != de && spec_env("VND_WIN_ALIGN_RING", 1) != 0) {
+        const int before = win_workgroups_per_cu(*g);
+        WinGeom plain = *g;
+        if (!(lay_out(aligned) && win_workgroups_per_cu(*g) >= before)) *g = plain;
+    }
+    return true;
 }
 
 // Workgroups a CU holds: LDS-bound, and register-bound - a lane carries its runs' accumulators, the outputs of the first
