@@ -136,7 +136,8 @@ def test_one_lane_of_the_generated_tap_function(native, golden, tmp_path, case, 
     need = nt + (int(idx.max()) + M - 1) // M
     assert need <= R < need + 16 and (R % 16 == 0 or R == need) and _macro(src, 'VW_NB') * G > R - nt
     qc = M // 4                     # planes an odd multiple of 8/QC slots apart: the 8-byte accesses of 16 lanes fill 32 banks once
-    assert (plane // 16) >= R + G and (plane // 16) % max(2, 16 // qc) == max(1, 8 // qc)
+    assert (plane // 16) >= R + G     # (32-frame runs: 2 mod 4, with the lanes' pair indices swizzled - reads and writes conflict-free)
+    assert (plane // 16) % 4 == 2 and '#define VW_LANE_SWIZZLE 1' in src if M == 32 else (plane // 16) % max(2, 16 // qc) == max(1, 8 // qc)
     assert fmas == M * len(idx) and lds_bytes <= 4 * fmas * (M + 4) // M + 64       # never worse than a window per tap
     lib = _host_lane(src, tmp_path, f'{case}_{M}')
     x = rng.uniform(-1, 1, (R * M, 2)).astype(np.float32)

@@ -58,7 +58,10 @@ inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size
         // planes must lie an ODD multiple of 8/QC slots apart (QC = 8: an odd number of slots; QC = 4: 2 mod 4; QC = 16: odd).
         // Counted, not guessed (SQ_LDS_BANK_CONFLICT per launch of 512 cfg2 streams, tools/ablate/run_r3f.sh): odd 7.7 M,
         // 2 mod 4 - the rule until late round 3 - 16.2 M, 4 mod 8 56 M, 0 mod 8 137 M.
-        const int mod_rule = std::max(2, 16 / qc), res_rule = std::max(1, 8 / qc);
+        // 32-frame runs: with the lanes' pair indices swizzled (VW_LANE_SWIZZLE, the kernel) planes 2 mod 4 slots apart make
+        // BOTH the 16-lane writes and the 32-lane read-backs conflict-free
+        const bool swz = qc == 8 && spec_env("VND_WIN_LANE_SWIZZLE", 1) != 0;
+        const int mod_rule = swz ? 4 : std::max(2, 16 / qc), res_rule = swz ? 2 : std::max(1, 8 / qc);
         const int res = spec_env("VND_WIN_PLANE_RES", -1), mod = spec_env("VND_WIN_PLANE_MOD", mod_rule);      // (tuning)
         while (units % mod != (res >= 0 ? res : res_rule)) ++units;
         g->plane = units * 16;
@@ -436,6 +439,7 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
                 g.nt, g.M, g.R, g.G, g.NB, g.DE, g.plane, c.la);
     spec_append(s, "#define VW_NT_STORES %d\n#define VW_EPI %d\n#define VW_BC %d\n#define VW_EXACT %d\n#define VW_C %d\n", c.nt_stores, c.epi, c.bc, c.exact, g.C);
     spec_append(s, "#define VW_NT_STORE_AUX %d\n", spec_env("VND_SPEC_STORE_AUX", 2));
+    spec_append(s, "#define VW_LANE_SWIZZLE %d\n", (g.M == 32 && spec_env("VND_WIN_LANE_SWIZZLE", 1) != 0) ? 1 : 0);
     // diagnosis builds (WRONG results on purpose: no stores / every load from one place - see the kernel): only in a tuning session
     const char *tuning = getenv("VND_TUNING");
     spec_append(s, "#define VW_DEBUG %d\n", (tuning && *tuning && *tuning != '0') ? spec_env("VND_WIN_DEBUG", 0) : 0);
