@@ -584,7 +584,7 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
 {
     if (batch == 0 || n == 0) return VND_OK;
     if (Cx == 0) Cx = C;
-    for (int attempt = 0; attempt < 4; ++attempt) {
+    for (int attempt = 0; attempt < 8; ++attempt) {
         const SpecPlan sp = make_spec_plan(ctx, t, x, y, batch, n, C, Cx, mode, epi);
         if (!sp.use) break;
         bool launched = false, built = true;
@@ -1474,6 +1474,7 @@ vnd_status vnd_window_kernel_source(int32_t C, const int32_t *tap_offsets, const
     SpecConfig cfg;
     cfg.nt = threads; cfg.win = frames_per_lane; cfg.win_g = g.G; cfg.win_lds = (int)g.lds_bytes();
     cfg.la = spec_env("VND_SPEC_LA", frames_per_lane >= 32 ? 4 : 6);
+    cfg.win_xpose = spec_env("VND_WIN_XPOSE_PAIRS", 1) != 0 ? 1 : 0;
     cfg.exact = mode == VND_MODE_EXACT ? 1 : 0;
     if (lds_bytes_per_tile || fmas_per_tile) {
         size_t lb = 0, fm = 0;
@@ -1505,12 +1506,12 @@ static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64
     if (st != VND_OK) return st;
     if (!text || len <= 0) return fail(VND_ERR_INVALID, "null text buffer");
     // the pointers only decide alignment: describe the launch of 256-byte-aligned buffers (hipMalloc's)
-    for (int attempt = 0; attempt < 4; ++attempt) {
+    for (int attempt = 0; attempt < 8; ++attempt) {
         const SpecPlan sp = make_spec_plan(ctx, t, nullptr, nullptr, batch, n, C, Cx, mode, nullptr);
         if (!sp.use) break;
         DeviceScope on(ctx->device);
         SpecModule *m = spec_module(ctx, t, sp.cfg, !sp.eager);
-        if (m && m->failed && sp.cfg.win && attempt < 3) {         // as launch(): plan again without that geometry
+        if (m && m->failed && sp.cfg.win && attempt < 7) {         // as launch(): plan again without that geometry
             if (getenv("VND_SPEC_VERBOSE")) fprintf(stderr, "vnd: window form (frames_per_lane=%d threads=%d) unavailable: %s\n", sp.cfg.win, sp.cfg.nt, m->log.c_str());
             continue;
         }
@@ -1518,9 +1519,10 @@ static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64
             if (sp.cfg.win) {
                 snprintf(text, (size_t)len,
                          "conv_spec%s_window (hipRTC, per table) frames_per_lane=%d tile=%d reads_ahead=%d "
-                         "nt_stores=%d mode=%d lds=%zuB workgroups=%u (%u units: %d spans x %d tiles per stream) threads=%d",
+                         "nt_stores=%d mode=%d lds=%zuB workgroups=%u (%u units: %d spans x %d tiles per stream) threads=%d store_phase=%s",
                          sp.cfg.exact ? "_exact" : "", sp.cfg.win, sp.cfg.tile(), sp.cfg.la, sp.cfg.nt_stores, mode,
-                         sp.cfg.lds_bytes(), sp.nblocks, sp.units, sp.spans, sp.tiles_per_span, sp.cfg.nt);
+                         sp.cfg.lds_bytes(), sp.nblocks, sp.units, sp.spans, sp.tiles_per_span, sp.cfg.nt,
+                         sp.cfg.win_xpose ? "frame-pairs" : "planar");
                 return VND_OK;
             }
             snprintf(text, (size_t)len,
@@ -1566,7 +1568,7 @@ vnd_status vnd_prepare_launch(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, in
     if (st != VND_OK) return st;
     if (batch == 0 || n == 0) return VND_OK;
     DeviceScope on(ctx->device);
-    for (int attempt = 0; attempt < 4; ++attempt) {               // (a window geometry that does not build is skipped: plan again)
+    for (int attempt = 0; attempt < 8; ++attempt) {               // (a window geometry that does not build is skipped: plan again)
         const SpecPlan sp = make_spec_plan(ctx, t, nullptr, nullptr, batch, n, t->C, in_channels, mode, nullptr);
         if (!sp.use) return VND_OK;
         SpecModule *m = spec_module(ctx, t, sp.cfg, false);

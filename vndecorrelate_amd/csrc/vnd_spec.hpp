@@ -47,6 +47,7 @@ struct SpecConfig {
     // WINDOW form (vnd_win.hpp): win = consecutive output frames per lane (0: the pair-read kernel above),
     // win_g = entries one base register reaches, win_lds = its LDS footprint (the halo is the table's)
     int win = 0, win_g = 0, win_lds = 0, win_per_cu = 0;    // (win_per_cu: workgroups a CU holds - LDS and registers)
+    int win_xpose = 0; // the store phase transposes through LDS as interleaved frame pairs (1) or as planar chunks (0: fewer registers)
     int tile() const { return win ? nt * win : 2 * nt * rr; }
     size_t lds_bytes() const
     {
@@ -56,8 +57,8 @@ struct SpecConfig {
     }
     bool operator<(const SpecConfig &o) const
     {
-        return std::tie(nt, rr, pp, dd, la, nt_stores, exact, epi, bc, shift, win, win_g) <
-               std::tie(o.nt, o.rr, o.pp, o.dd, o.la, o.nt_stores, o.exact, o.epi, o.bc, o.shift, o.win, o.win_g);
+        return std::tie(nt, rr, pp, dd, la, nt_stores, exact, epi, bc, shift, win, win_g, win_xpose) <
+               std::tie(o.nt, o.rr, o.pp, o.dd, o.la, o.nt_stores, o.exact, o.epi, o.bc, o.shift, o.win, o.win_g, o.win_xpose);
     }
 };
 

@@ -439,6 +439,10 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
                 g.nt, g.M, g.R, g.G, g.NB, g.DE, g.plane, c.la);
     spec_append(s, "#define VW_NT_STORES %d\n#define VW_EPI %d\n#define VW_BC %d\n#define VW_EXACT %d\n#define VW_C %d\n", c.nt_stores, c.epi, c.bc, c.exact, g.C);
     spec_append(s, "#define VW_NT_STORE_AUX %d\n", spec_env("VND_SPEC_STORE_AUX", 2));
+    // the transposition as interleaved frame pairs (one 16-byte read-back per store, planes an odd number of slots apart) or as
+    // planar chunks read back in 8-byte halves (VND_WIN_XPOSE_PAIRS=0: then 32-frame runs swizzle their lanes' pair indices)
+    const int xpose = (!c.bc && c.win_xpose) ? 1 : 0;
+    spec_append(s, "#define VW_XPOSE_PAIRS %d\n", xpose);
     spec_append(s, "#define VW_LANE_SWIZZLE %d\n", (g.M == 32 && spec_env("VND_WIN_LANE_SWIZZLE", 1) != 0) ? 1 : 0);
     // diagnosis builds (WRONG results on purpose: no stores / every load from one place - see the kernel): only in a tuning session
     const char *tuning = getenv("VND_TUNING");
@@ -492,7 +496,23 @@ inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool sm
                     // has at two waves per SIMD (measured: 3 to 10 reads ahead run the same, tools/win_try.py)
                     c.la = spec_env("VND_SPEC_LA", M >= 32 ? 4 : 6);
                     c.rr = 0; c.pp = 0; c.dd = 0;
-                    if (rejected && rejected(c)) continue;          // a build of this geometry failed or spilled before
+                    // the store phase: interleaved frame pairs (one 16-byte read-back per store) unless that build spilled
+                    // before - it holds both channels' outputs interleaved - then planar chunks in 8-byte halves
+                    c.win_xpose = bc ? 0 : (spec_env("VND_WIN_XPOSE_PAIRS", 1) != 0 ? 1 : 0);
+                    if (rejected && rejected(c)) {                  // a build of this geometry failed or spilled before
+                        if (!c.win_xpose) continue;
+                        // (cfg2's fast kernel: 44 bytes of spill with 4 reads ahead, none with 3 - and 3 to 10 run the same)
+                        bool found = false;
+                        if (c.la > 3 && spec_env("VND_SPEC_LA", -1) < 0) {
+                            c.la -= 1;
+                            found = !rejected(c);
+                            if (!found) c.la += 1;
+                        }
+                        if (!found) {
+                            c.win_xpose = 0;
+                            if (rejected(c)) continue;
+                        }
+                    }
                     best_waves = waves;
                     *out = c;
                 }
