@@ -264,6 +264,12 @@ vnd_status vnd_time_convolve_f32_dev(vnd_ctx *ctx, const vnd_taps *taps, const f
                                      int32_t n_channels, int32_t mode, int32_t n_buffers,
                                      int64_t stride_elems, int32_t iters, void *hip_stream,
                                      float *avg_ms);
+/* Bytes of private (scratch) memory per lane the kernel `kernel` of a gfx950 code object (an ELF image)
+ * asks for, read from its kernel descriptor: > 0 means the compiler spilled registers.  The library
+ * rejects such builds of the window form of its per-table kernels (the registers ARE that kernel);
+ * exposed so that the check can be tested without a device.  -1: no such kernel in the image.        */
+vnd_status vnd_code_object_private_bytes(const void *code, int64_t bytes, const char *kernel,
+                                         int64_t *private_bytes);
 /* The box's streaming ceiling, as a companion of the 8 TB/s figure: `iters` plain copies of `elems`
  * floats (a multiple of 4; 16-byte aligned buffers) with 16-byte non-temporal accesses, the average
  * kernel milliseconds between two hipEvents on `hip_stream`.                                    */

@@ -134,3 +134,32 @@ def test_source_compiles_for_gfx950_with_the_intended_isa(native, golden, tmp_pa
     assert count['s_barrier'] == groups * (dd + 1) + 1       # one per tile body, the prologue's, the one between units
     # offsets are immediates: no per-tap address arithmetic
     assert count.get('v_add_u32_e32', 0) < 40 * groups
+
+
+def test_spill_check_reads_the_code_object_itself(native, tmp_path):
+    """The window form rejects builds that spill registers (private memory per lane > 0).  The number is read from the
+    kernel descriptor inside the ELF - hipFuncGetAttribute reports it too, but not under every tool that wraps the
+    runtime (under rocprofv3 a spilling build was let through) - so the check can run here, without a device."""
+    src = tmp_path / 'k.hip'
+    src.write_text('''
+extern "C" __global__ void clean_kernel(float *y) { y[threadIdx.x] = 1.0f; }
+extern "C" __global__ void spilling_kernel(float *y, const int *idx)
+{
+    float a[600];
+    for (int i = 0; i < 600; ++i) a[i] = y[i] * 2.0f;
+    float s = 0.f;
+    for (int i = 0; i < 600; ++i) s += a[idx[i] % 600];
+    y[threadIdx.x] = s;
+}
+''')
+    out = tmp_path / 'k.co'
+    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '--cuda-device-only', '--no-gpu-bundle-output', '-include',
+                        'hip/hip_runtime.h', '-c', str(src), '-o', str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    image = out.read_bytes()
+    assert image[:4] == b'\x7fELF'
+    assert native.code_object_private_bytes(image, 'clean_kernel') == 0
+    assert native.code_object_private_bytes(image, 'spilling_kernel') >= 2400          # the 600-float array lives in scratch
+    assert native.code_object_private_bytes(image, 'no_such_kernel') == -1
+    assert native.code_object_private_bytes(image[:200], 'clean_kernel') == -1          # a truncated image: no answer, no crash
+    assert native.code_object_private_bytes(b'not an object at all' * 10, 'clean_kernel') == -1

@@ -109,6 +109,7 @@ SIGNATURES = {
                                                  _c_f32p]),
     'vnd_time_copy_f32_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                              ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
+    'vnd_code_object_private_bytes': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int64, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
     'vnd_host_alloc': (ctypes.c_int, [ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
     'vnd_host_buffers_mapped': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                                ctypes.POINTER(ctypes.c_int32)]),
@@ -621,6 +622,15 @@ def window_kernel_source(tap_offsets, tap_index, tap_weight, mode: int = MODE_FA
     _check(lib.vnd_window_kernel_source(*args, buf, need.value, ctypes.byref(need), None, None), 'vnd_window_kernel_source')
     src = buf.value.decode()
     return (src, lb.value, fm.value) if with_traffic else src
+
+
+def code_object_private_bytes(image: bytes, kernel: str) -> int:
+    """Private (scratch) bytes per lane of ``kernel`` in a gfx950 code object (``vnd_code_object_private_bytes``);
+    -1 if the image has no such kernel."""
+    out = ctypes.c_int64()
+    _check(load_library().vnd_code_object_private_bytes(image, len(image), kernel.encode(), ctypes.byref(out)),
+           'vnd_code_object_private_bytes')
+    return out.value
 
 
 def host_buffers_mapped(x: np.ndarray, y: np.ndarray) -> bool:

@@ -1491,6 +1491,14 @@ vnd_status vnd_window_kernel_source(int32_t C, const int32_t *tap_offsets, const
     return VND_OK;
 }
 
+vnd_status vnd_code_object_private_bytes(const void *code, int64_t bytes, const char *kernel, int64_t *private_bytes)
+{
+    if (!code || bytes <= 0 || !kernel || !private_bytes) return fail(VND_ERR_INVALID, "bad arguments");
+    const std::vector<char> image((const char *)code, (const char *)code + bytes);
+    *private_bytes = spec_private_bytes(image, kernel);
+    return VND_OK;
+}
+
 vnd_status vnd_set_variant(vnd_ctx *ctx, int32_t variant)
 {
     if (!ctx) return fail(VND_ERR_INVALID, "null context");

@@ -471,6 +471,43 @@ inline void spec_cache_store(const std::string &dir, const std::string &path, co
     if (!ok || !closed || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());     // rename is atomic: readers never see half a file
 }
 
+// Bytes of private (scratch) memory per lane that a code object's kernel asks for - what a register spill shows up as - read
+// from the kernel descriptor in the ELF itself (symbol <kernel>.kd: group_segment_fixed_size at byte 0, private_segment_fixed_size
+// at byte 4).  hipFuncGetAttribute reports the same number, but not under every tool that wraps the runtime (under rocprofv3 it
+// came back empty and a spilling build was let through); the file does not change with the observer.  -1: not found.
+inline long spec_private_bytes(const std::vector<char> &code, const char *kernel)
+{
+    struct Ehdr { unsigned char ident[16]; uint16_t type, machine; uint32_t version; uint64_t entry, phoff, shoff; uint32_t flags;
+                  uint16_t ehsize, phentsize, phnum, shentsize, shnum, shstrndx; };
+    struct Shdr { uint32_t name, type; uint64_t flags, addr, offset, size; uint32_t link, info; uint64_t addralign, entsize; };
+    struct Sym { uint32_t name; unsigned char info, other; uint16_t shndx; uint64_t value, size; };
+    const size_t n = code.size();
+    if (n < sizeof(Ehdr) || memcmp(code.data(), "\177ELF", 4) != 0 || code[4] != 2) return -1;
+    Ehdr eh; memcpy(&eh, code.data(), sizeof eh);
+    if (eh.shentsize != sizeof(Shdr) || eh.shoff > n || (uint64_t)eh.shnum * sizeof(Shdr) > n - eh.shoff) return -1;
+    auto shdr = [&](unsigned i) { Shdr sh; memcpy(&sh, code.data() + eh.shoff + (size_t)i * sizeof(Shdr), sizeof sh); return sh; };
+    const std::string want = std::string(kernel) + ".kd";
+    for (unsigned i = 0; i < eh.shnum; ++i) {
+        const Shdr st = shdr(i);
+        if ((st.type != 2 && st.type != 11) || st.entsize != sizeof(Sym) || st.link >= eh.shnum) continue;      // SYMTAB, DYNSYM
+        const Shdr str = shdr(st.link);
+        if (st.offset > n || st.size > n - st.offset || str.offset > n || str.size > n - str.offset) continue;
+        for (uint64_t k = 0; k + sizeof(Sym) <= st.size; k += sizeof(Sym)) {
+            Sym sy; memcpy(&sy, code.data() + st.offset + k, sizeof sy);
+            if (sy.name >= str.size || sy.shndx == 0 || sy.shndx >= eh.shnum) continue;
+            const char *nm = code.data() + str.offset + sy.name;
+            if (strnlen(nm, str.size - sy.name) != want.size() || memcmp(nm, want.data(), want.size()) != 0) continue;
+            const Shdr sec = shdr(sy.shndx);
+            if (sy.value < sec.addr) return -1;
+            const uint64_t at = sec.offset + (sy.value - sec.addr);
+            if (at > n || n - at < 8) return -1;
+            uint32_t priv; memcpy(&priv, code.data() + at + 4, 4);
+            return (long)priv;
+        }
+    }
+    return -1;
+}
+
 // the WINDOW form's translation unit (vnd_win.hpp)
 inline std::string win_source_for(const SpecTable &t, const SpecConfig &cfg);
 
@@ -528,7 +565,9 @@ inline bool spec_compile(const SpecTable &t, const SpecConfig &cfg, int device, 
         // the window form lives on its registers: a build that spills (private memory per lane) streams the spill through
         // the caches at every tile - slower than the pair-read form it was meant to beat.  Rejected; the caller falls back.
         int local = 0;
-        if (hipFuncGetAttribute(&local, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, m->fn) == hipSuccess && local > 0 && !getenv("VND_WIN_ALLOW_SPILL")) {
+        if (hipFuncGetAttribute(&local, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, m->fn) != hipSuccess) { local = 0; (void)hipGetLastError(); }
+        local = (int)std::max<long>(local, spec_private_bytes(code, "vnd_spec_kernel"));      // (the code object itself: observer-proof)
+        if (local > 0 && !getenv("VND_WIN_ALLOW_SPILL")) {
             (void)hipModuleUnload(m->module);
             m->module = nullptr; m->fn = nullptr;
             m->failed = true;
