@@ -88,4 +88,11 @@ def test_page_locked_buffers_are_convolved_in_place(golden, monkeypatch, shape):
     # the public function on a page-locked input: same bytes
     if x.ndim == 2 and shape[-1] == 2:
         assert np.array_equal(d.convolve_velvet_noise(x, fir), got)
+        # a view that starts 3 frames in (8-byte aligned only, still page-locked): in place through the kernels that take any alignment
+        view = x[3:]
+        assert view.flags.c_contiguous and view.ctypes.data % 16 == 8
+        want_view = c_oracle.convolve(np.ascontiguousarray(view), offs, idx, w)
+        assert np.array_equal(table.convolve_host(view, d.MODE_EXACT), want_view)
+        fast_view = table.convolve_host(view, d.MODE_FAST)
+        assert np.max(np.abs(fast_view.astype(np.float64) - want_view)) <= 1e-6 * np.max(np.abs(want_view))
     table.close()
