@@ -453,20 +453,32 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     //  ask for the window form: there a workgroup moves 8 bytes of every frame, the memory pipeline's time per useful byte
     //  is 2-4x a stereo signal's and the window form's few waves per CU do not hide it - cfg5 0.54 ms against 0.45, while
     //  the same tables on planar channel pairs run 0.33 against 0.39: tools/c8_win_try.py, profiles/r03_cfg5_request_floor.txt)
-    static const int win_wide_env = spec_env("VND_WIN_WIDE", 0);
+    const int win_wide_env = spec_env("VND_WIN_WIDE", 0);
     const bool win_c = C == 2 || (C % 2 == 0 && (win_wide_env != 0 || vw >= 2));
-    if (win_m > 0 && win_c && rr_hint == 0 && (mode == VND_MODE_FAST || win_exact) && (!bc || vw >= 2)) {
-        // (a geometry whose build failed or spilled is remembered in the table's module map: skipped, the next best taken)
-        const bool nt_big = batch * n * C * (int64_t)sizeof(float) >= ((int64_t)64 << 20);
-        auto rejected = [&](const SpecConfig &c0) {
-            SpecConfig c = c0;
-            c.nt_stores = nt_big ? 1 : 0; c.exact = mode == VND_MODE_EXACT ? 1 : 0; c.epi = pointwise ? 1 : 0; c.bc = bc ? 1 : 0;
-            std::lock_guard<std::mutex> g(const_cast<vnd_taps *>(t)->spec_mutex);
-            auto it = t->spec_modules.find(c);
-            return it != t->spec_modules.end() && it->second->failed;
-        };
+    // signals of 4k channels: the window form on channel QUADS (VW_Q, vw_span_q: a workgroup moves 16 bytes of every frame, half
+    // its lanes per channel pair, 16-frame runs so that two workgroups of 256 lanes share a CU) - VND_WIN_QUAD=0 keeps the
+    // pair-read kernel (or, with VND_WIN_WIDE=1 / variant bits 5-7, the window form on channel pairs)
+    const bool win_quad = C % 4 == 0 && Cx == C && !pointwise && spec_env("VND_WIN_QUAD", 1) != 0;
+    // (a geometry whose build failed or spilled is remembered in the table's module map: skipped, the next best taken)
+    const bool nt_big = batch * n * C * (int64_t)sizeof(float) >= ((int64_t)64 << 20);
+    auto nt_stores_of = [&](const SpecConfig &c) {
+        // a channel pair (or quad) is a piece of a frame: let L2 merge the pieces - unless the quad IS the frame
+        if (C != 2 && !(c.win_q && C == 4) && !spec_env("VND_FORCE_NT", 0)) return 0;
+        return nt_big ? 1 : 0;
+    };
+    auto rejected = [&](const SpecConfig &c0) {
+        SpecConfig c = c0;
+        c.nt_stores = nt_stores_of(c0); c.exact = mode == VND_MODE_EXACT ? 1 : 0; c.epi = pointwise ? 1 : 0; c.bc = bc ? 1 : 0;
+        std::lock_guard<std::mutex> g(const_cast<vnd_taps *>(t)->spec_mutex);
+        auto it = t->spec_modules.find(c);
+        return it != t->spec_modules.end() && it->second->failed;
+    };
+    const bool win_mode_ok = win_m > 0 && rr_hint == 0 && (mode == VND_MODE_FAST || win_exact || (win_quad && win_exact_env != 0));
+    if (win_mode_ok && win_quad)
+        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, vw >= 2 ? win_m : spec_env("VND_WIN_QUAD_M", 16), attempt == 1,
+                                 false, &p.cfg, rejected, true);
+    if (!picked && win_mode_ok && win_c && (!bc || vw >= 2))
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, bc, &p.cfg, rejected);
-    }
     if (!picked && !spec_pick_config(t->spec_table, (size_t)ctx->lds_limit, rr_hint, dd_hint, &p.cfg, attempt == 1 || C != 2, bc, mode == VND_MODE_EXACT)) { p.why = "halo does not fit the ring"; return p; }
     const int64_t T = p.cfg.tile();
     const int64_t tiles_total = (n + T - 1) / T;
@@ -475,7 +487,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     const int64_t per_cu = p.cfg.win ? p.cfg.win_per_cu
                                      : std::min<int64_t>(std::min<int64_t>(16, 2048 / p.cfg.nt), (int64_t)(160 * 1024) / (int64_t)p.cfg.lds_bytes());
     const int64_t resident = (int64_t)cus * std::max<int64_t>(per_cu, 1);
-    const int64_t units = batch * (C / 2);                     // (stream, channel pair)
+    const int64_t units = batch * (p.cfg.win_q ? C / 4 : C / 2);      // (stream, channel pair) - or channel quad
     // a workgroup needs a span long enough to amortise filling its ring: 8 tiles when there are 16 and more per resident
     // slot; with less, shorter spans (down to 2 tiles) so that the chip still fills - a lone 60 s stream then runs 1.1x
     // (fast) to 1.75x (exact, 128 taps) faster than through the generic kernels, tools/single_stream_try.py - and below
@@ -511,8 +523,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     per_span = std::min(per_span, max_tiles);
     spans = (tiles_total + per_span - 1) / per_span;
     if (units * spans > 0x7fffffffLL) { p.why = "grid too large"; return p; }
-    p.cfg.nt_stores = (batch * n * C * (int64_t)sizeof(float) >= ((int64_t)64 << 20)) ? 1 : 0;
-    if (C != 2 && !spec_env("VND_FORCE_NT", 0)) p.cfg.nt_stores = 0;      // a channel pair is a piece of a frame: let L2 merge the pieces
+    p.cfg.nt_stores = nt_stores_of(p.cfg);
     p.cfg.exact = mode == VND_MODE_EXACT ? 1 : 0;
     p.cfg.epi = pointwise ? 1 : 0;
     p.cfg.bc = bc ? 1 : 0;
@@ -1469,10 +1480,13 @@ vnd_status vnd_window_kernel_source(int32_t C, const int32_t *tap_offsets, const
         }
     }
     WinGeom g;
-    if (!win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g))
+    // (tables of 4k channels: the quad form, as the launches take it - VND_WIN_QUAD=0: channel pairs)
+    const bool quad = C % 4 == 0 && spec_env("VND_WIN_QUAD", 1) != 0 &&
+                      win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, true);
+    if (!quad && !win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g))
         return fail(VND_ERR_UNSUPPORTED, "this window geometry does not fit the LDS");
     SpecConfig cfg;
-    cfg.nt = threads; cfg.win = frames_per_lane; cfg.win_g = g.G; cfg.win_lds = (int)g.lds_bytes();
+    cfg.nt = threads; cfg.win = frames_per_lane; cfg.win_g = g.G; cfg.win_lds = (int)g.lds_bytes(); cfg.win_q = g.quad;
     cfg.la = spec_env("VND_SPEC_LA", frames_per_lane >= 32 ? 4 : 6);
     cfg.win_xpose = spec_env("VND_WIN_XPOSE_PAIRS", 1) != 0 ? 1 : 0;
     cfg.exact = mode == VND_MODE_EXACT ? 1 : 0;
@@ -1530,7 +1544,7 @@ static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64
                          "nt_stores=%d mode=%d lds=%zuB workgroups=%u (%u units: %d spans x %d tiles per stream) threads=%d store_phase=%s",
                          sp.cfg.exact ? "_exact" : "", sp.cfg.win, sp.cfg.tile(), sp.cfg.la, sp.cfg.nt_stores, mode,
                          sp.cfg.lds_bytes(), sp.nblocks, sp.units, sp.spans, sp.tiles_per_span, sp.cfg.nt,
-                         sp.cfg.win_xpose ? "frame-pairs" : "planar");
+                         sp.cfg.win_q ? "frame-pairs pieces=channel-quads" : (sp.cfg.win_xpose ? "frame-pairs" : "planar"));
                 return VND_OK;
             }
             snprintf(text, (size_t)len,

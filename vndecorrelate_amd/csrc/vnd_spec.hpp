@@ -48,7 +48,8 @@ struct SpecConfig {
     // win_g = entries one base register reaches, win_lds = its LDS footprint (the halo is the table's)
     int win = 0, win_g = 0, win_lds = 0, win_per_cu = 0;    // (win_per_cu: workgroups a CU holds - LDS and registers)
     int win_xpose = 0; // the store phase transposes through LDS as interleaved frame pairs (1) or as planar chunks (0: fewer registers)
-    int tile() const { return win ? nt * win : 2 * nt * rr; }
+    int win_q = 0;     // window form on channel QUADS (signals of 4k channels): half the workgroup's lanes per channel pair
+    int tile() const { return win ? (win_q ? nt / 2 : nt) * win : 2 * nt * rr; }
     size_t lds_bytes() const
     {
         if (win) return (size_t)win_lds;
@@ -57,8 +58,8 @@ struct SpecConfig {
     }
     bool operator<(const SpecConfig &o) const
     {
-        return std::tie(nt, rr, pp, dd, la, nt_stores, exact, epi, bc, shift, win, win_g, win_xpose) <
-               std::tie(o.nt, o.rr, o.pp, o.dd, o.la, o.nt_stores, o.exact, o.epi, o.bc, o.shift, o.win, o.win_g, o.win_xpose);
+        return std::tie(nt, rr, pp, dd, la, nt_stores, exact, epi, bc, shift, win, win_g, win_xpose, win_q) <
+               std::tie(o.nt, o.rr, o.pp, o.dd, o.la, o.nt_stores, o.exact, o.epi, o.bc, o.shift, o.win, o.win_g, o.win_xpose, o.win_q);
     }
 };
 
