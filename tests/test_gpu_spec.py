@@ -60,11 +60,12 @@ def test_headline_workload_takes_the_specialised_kernel(env, golden):
 
 
 @pytest.mark.parametrize('gname', ['g48k_k30', 'g44k_k30', 'g48k_k128_l', 'g48k_k128_u', 'g44k_noenv', 'g96k_k64_c8'])
-def test_forced_small_signals_and_span_seams(env, golden, gname):
+def test_forced_small_signals_and_span_seams(env, golden, gname, monkeypatch):
     """Every length class around the tile (1024 frames) and ring (slots x tile) sizes, spans of 1 to
     7 tiles so that seams, carries and the span-end reduction all run, batches, and both span
     arithmetic extremes.  Checked against the NumPy oracle."""
     d, native, ctx = env
+    monkeypatch.setenv('VND_WIN_QUAD', '0')      # the PAIR-READ kernel on the 8-channel table too (6, 10, ... channels take it)
     fir = golden.fir(gname)
     C = fir.shape[1]
     table = _table(native, ctx, fir)
@@ -201,11 +202,12 @@ def test_linearity_and_shift_at_full_size(env, golden):
 
 # ---- VND_MODE_EXACT through the specialised kernel: bit-identical, like the generic ordered kernel ----
 @pytest.mark.parametrize('gname', ['g48k_k30', 'g44k_k30', 'g48k_k128_l', 'g44k_noenv', 'g96k_k64_c8'])
-def test_exact_mode_specialised_is_bit_identical(env, golden, gname):
+def test_exact_mode_specialised_is_bit_identical(env, golden, gname, monkeypatch):
     """Table order, separately rounded products and sums, odd offsets as two dword reads: the per-table
     kernel in exact mode must equal the oracle bit for bit - through span seams, ring wrap-arounds,
     stream tails and batches, as the fast mode's test above."""
     d, native, ctx = env
+    monkeypatch.setenv('VND_WIN_QUAD', '0')      # the pair-read kernel on the 8-channel table too
     fir = golden.fir(gname)
     C = fir.shape[1]
     table = _table(native, ctx, fir)

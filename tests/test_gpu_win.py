@@ -127,6 +127,10 @@ def test_pools_at_bench_shapes_match_the_oracle(env, golden, name):
     assert exact_text.startswith('conv_spec_exact'), exact_text
     if C == 2:
         assert fast_text.startswith('conv_spec_window'), fast_text
+    if C % 4 == 0:
+        assert fast_text.startswith('conv_spec_window') and exact_text.startswith('conv_spec_exact_window'), (fast_text, exact_text)
+        pieces = 'pieces=channel-octets' if C % 8 == 0 else 'pieces=channel-quads'
+        assert pieces in fast_text and pieces in exact_text, (fast_text, exact_text)
     x = torch.empty((pool, n, C), dtype=torch.float32, device='cuda').uniform_(-1, 1)
     y, ye = torch.empty_like(x), torch.empty_like(x)
     s = torch.cuda.current_stream().cuda_stream
@@ -206,6 +210,7 @@ def test_window_form_on_wider_signals(env, golden, monkeypatch, C, M, nt):
     fir = np.ascontiguousarray(golden.fir('g96k_k64_c8')[:, :C])
     table = _table(native, ctx, fir)
     monkeypatch.setenv('VND_SPEC_NT', str(nt))
+    monkeypatch.setenv('VND_WIN_QUAD', '0')           # (4 and 8 channels would take the quad form below)
     rng = np.random.default_rng(C * 100 + M)
     T = nt * M
     for n in sorted({1, 3, M + 1, T - 1, T, T + 1, 2 * T + 3, 5 * T + 17, 40003}):
@@ -217,6 +222,45 @@ def test_window_form_on_wider_signals(env, golden, monkeypatch, C, M, nt):
                 for mode, name in ((d.MODE_FAST, 'conv_spec_window'), (d.MODE_EXACT, 'conv_spec_exact_window')):
                     text = table.describe(batch, n, C, mode)
                     assert text.startswith(name) and f'frames_per_lane={M} ' in text and f'threads={nt}' in text, text
+                    assert 'channel-quads' not in text, text
+                    got = table.convolve_host(x, mode)
+                    where = f'C={C} M={M} n={n} batch={batch} spans=({min_span},{rounds})'
+                    if mode == d.MODE_EXACT:
+                        assert np.array_equal(got, want), where
+                    else:
+                        assert _err(got, want) <= TOL_PEAK, f'{where}: {_err(got, want):.2e}'
+    ctx.set_variant(-1)
+    table.close()
+
+
+@pytest.mark.parametrize('C,M,nt,Q', [(8, 16, 256, 1), (4, 16, 256, 1), (12, 16, 128, 1), (8, 32, 128, 1), (4, 32, 256, 1), (16, 16, 512, 1),
+                                      (8, 16, 512, 2), (16, 16, 512, 2), (8, 32, 256, 2), (8, 16, 256, 2)])
+def test_window_form_on_channel_quads(env, golden, monkeypatch, C, M, nt, Q):
+    """Signals of 4k interleaved channels: a workgroup takes a channel QUAD of a span - 16 bytes of every frame, the first
+    half of its lanes on the quad's first channel pair, the second half on the other, outputs exchanged between partner waves
+    through the tile's dead ring entries (vw_span_q).  Q = 2: signals of 8k channels, two neighbouring quads (32 bytes of every
+    frame; with 8 channels whole frames) per workgroup, a quarter of its lanes per pair.  Every pair has its own taps; lengths
+    around the tile (nt / 2Q entries of M frames), stream tails inside a run, batches, spans of one tile and span seams - fast
+    within tolerance, exact bit for bit, against the NumPy oracle."""
+    d, native, ctx = env
+    wide = golden.fir('g96k_k64_c8')
+    fir = np.ascontiguousarray(np.concatenate([wide, wide[:, ::-1]], axis=1)[:, :C])
+    table = _table(native, ctx, fir)
+    monkeypatch.setenv('VND_SPEC_NT', str(nt))
+    monkeypatch.setenv('VND_WIN_OCTET', '1' if Q == 2 else '0')
+    rng = np.random.default_rng(C * 1000 + M + Q)
+    T = (nt // (2 * Q)) * M
+    pieces = 'pieces=channel-octets' if Q == 2 else 'pieces=channel-quads'
+    for n in sorted({1, 3, M + 1, T - 1, T, T + 1, 2 * T + 3, 5 * T + 17, 40003}):
+        for batch in (1, 3):
+            x = rng.uniform(-1, 1, (batch, n, C)).astype(np.float32)
+            want = np.stack([O.convolve_velvet_noise(x[b], fir) for b in range(batch)])
+            for min_span, rounds in ((1, 7), (2, 1)):
+                ctx.set_variant(FORCE | WIN[M] | span_bits(min_span, rounds))
+                for mode, name in ((d.MODE_FAST, 'conv_spec_window'), (d.MODE_EXACT, 'conv_spec_exact_window')):
+                    text = table.describe(batch, n, C, mode)
+                    assert text.startswith(name) and f'frames_per_lane={M} ' in text and f'tile={T} ' in text, text
+                    assert f'threads={nt}' in text and pieces in text, text
                     got = table.convolve_host(x, mode)
                     where = f'C={C} M={M} n={n} batch={batch} spans=({min_span},{rounds})'
                     if mode == d.MODE_EXACT:
@@ -229,11 +273,14 @@ def test_window_form_on_wider_signals(env, golden, monkeypatch, C, M, nt):
 
 def test_stereo_tables_take_the_window_form_by_default_in_both_modes(env, golden):
     """The automatic choice for a stereo table with enough work: the window form, fast and exact, function path and class
-    path; a mono input fanned out and wider tables keep the pair-read form."""
+    path; tables of 4k channels the window form on channel quads, of 8k channels on octets; a mono input fanned out and
+    tables of 4k + 2 channels keep the pair-read form."""
     d, native, ctx = env
     ctx.set_variant(-1)
     dense, sparse = _table(native, ctx, golden.fir('g48k_k128_u')), _table(native, ctx, golden.fir('g48k_k30'))
     wide = _table(native, ctx, golden.fir('g96k_k64_c8'))
+    six = _table(native, ctx, np.ascontiguousarray(golden.fir('g96k_k64_c8')[:, :6]))
+    four = _table(native, ctx, np.ascontiguousarray(golden.fir('g96k_k64_c8')[:, :4]))
     cls = d.VelvetNoise(sample_rate_hz=48000, seed=1)._device_table()
     for table, shape in ((dense, (24, 2880000, 2)), (sparse, (128, 480000, 2)), (cls, (128, 480000, 2))):
         assert table.describe(*shape, d.MODE_EXACT).startswith('conv_spec_exact_window'), table.describe(*shape, d.MODE_EXACT)
@@ -242,8 +289,12 @@ def test_stereo_tables_take_the_window_form_by_default_in_both_modes(env, golden
         text = sparse.describe(128, 480000, 1, mode)
         assert text.startswith('conv_spec') and 'window' not in text, text
         text = wide.describe(16, 960000, 8, mode)
+        assert text.startswith('conv_spec') and 'window' in text and 'pieces=channel-octets' in text and 'frames_per_lane=16 ' in text, text
+        text = four.describe(16, 960000, 4, mode)
+        assert text.startswith('conv_spec') and 'window' in text and 'pieces=channel-quads' in text and 'frames_per_lane=16 ' in text, text
+        text = six.describe(16, 960000, 6, mode)
         assert text.startswith('conv_spec') and 'window' not in text, text
-    dense.close(); sparse.close(); wide.close()
+    dense.close(); sparse.close(); wide.close(); six.close(); four.close()
 
 
 def test_a_window_build_that_spills_is_rejected_and_the_launch_still_right(env, golden, monkeypatch):

@@ -297,3 +297,46 @@ def test_window_source_compiles_for_gfx950_with_the_intended_isa(native, golden,
     assert n_reads <= count['ds_read_b128'] <= n_reads + 2 * (M // 4)
     # ... so the tap phase carries (almost) no address arithmetic
     assert count.get('v_add_u32_e32', 0) < 200
+
+
+@pytest.mark.parametrize('mode', [2, 0])
+@pytest.mark.parametrize('Q', [1, 2])
+def test_quad_form_source_for_tables_of_4k_channels(native, golden, tmp_path, mode, Q, monkeypatch):
+    """cfg5's table (8 channels): the window form on channel QUADS - half a workgroup's lanes per channel pair, a ring of
+    nt / 2 + halo entries per pair, both pairs' plane sets in one workgroup's LDS, two workgroups of 256 lanes per CU - or on
+    OCTETS (Q = 2: all four pairs in one workgroup of 512 lanes, whole 32-byte frames; the default for 8k channels) is what
+    the generator emits; VND_WIN_QUAD=0 gives the form on channel pairs.  Cross-compiled for gfx950: no spill, one
+    instantiation of the span loop per quad / octet (prologue barrier + three per tile), every pair's taps once."""
+    offs, idx, w = _table(golden.fir('g96k_k64_c8'))
+    M, nt = 16, 256 * Q
+    monkeypatch.setenv('VND_WIN_OCTET', '1' if Q == 2 else '0')
+    src = native.window_kernel_source(offs, idx, w, mode, M, nt)
+    assert _macro(src, 'VW_Q') == Q and _macro(src, 'VW_C') == 8
+    assert _macro(src, 'VW_R') == 128 + _macro(src, 'VW_DE')
+    lds = 2 * Q * 2 * (M // 4) * _macro(src, 'VW_PLANE')
+    assert (2 // Q) * lds <= 160 * 1024 and _macro(src, 'VW_WAVES_PER_EU') == 2          # 8 waves per CU either way
+    dispatch = src.split('#define VW_DISPATCH')[1].split('\n')[0]
+    assert dispatch.count('vw_span_q<') == 2 // Q and 'vw_span<' not in dispatch
+    monkeypatch.setenv('VND_WIN_QUAD', '0')
+    pairs = native.window_kernel_source(offs, idx, w, mode, M, nt)
+    assert _macro(pairs, 'VW_Q') == 0 and _macro(pairs, 'VW_R') == nt + _macro(pairs, 'VW_DE')
+    f = tmp_path / 'k.hip'
+    f.write_text(src)
+    out = tmp_path / 'k.s'
+    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '--cuda-device-only',
+                        '-include', 'hip/hip_runtime.h', '-S', str(f), '-o', str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = out.read_text()
+    assert re.search(r'ScratchSize: 0\b', asm), 'the window kernel must not spill'
+    ops = re.findall(r'^\s+([a-z0-9_]+)', asm, re.M)
+    count = {o: ops.count(o) for o in set(ops)}
+    assert count.get('flat_load_dwordx4', 0) == 0, 'LDS reads fell back to flat loads'
+    assert count['s_barrier'] == (2 // Q) * 4
+    if mode == 2:
+        odd = int((idx & 1).sum())
+        packed = count['v_pk_fma_f32'] + count.get('v_pk_mul_f32', 0)
+        # (an odd tap's two single FMAs at the run's edges are sometimes paired up by hipcc)
+        assert len(idx) * (M // 2) - odd - 64 <= packed <= len(idx) * (M // 2)
+    # whole 16-byte pieces in both directions
+    assert count.get('buffer_load_dwordx2', 0) == 0 and count.get('buffer_store_dwordx2', 0) == 0
+    assert count['buffer_store_dwordx4'] == (2 // Q) * (M // 2)

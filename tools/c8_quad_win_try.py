@@ -27,7 +27,7 @@ def make_table(fir):
 
 
 def env_set(**env):
-    for k in ('VND_SPEC_NT', 'VND_SPEC_LA', 'VND_WIN_G', 'VND_WIN_QUAD', 'VND_WIN_WIDE', 'VND_WIN_QUAD_M', 'VND_FORCE_NT'):
+    for k in ('VND_SPEC_NT', 'VND_SPEC_LA', 'VND_WIN_G', 'VND_WIN_QUAD', 'VND_WIN_WIDE', 'VND_WIN_QUAD_M', 'VND_FORCE_NT', 'VND_WIN_QUAD_CU_PAIRS', 'VND_WIN_OCTET'):
         os.environ.pop(k, None)
     for k, v in env.items():
         os.environ[k] = str(v)
@@ -36,11 +36,13 @@ def env_set(**env):
 bad = 0
 if 'skip-small' not in sys.argv:
     rng = np.random.default_rng(5)
-    for C, M, nt in ((8, 16, 256), (4, 16, 256), (12, 16, 128), (8, 32, 128), (4, 32, 256)):
+    for C, M, nt, Q in ((8, 16, 512, 2), (16, 16, 512, 2), (8, 32, 256, 2), (8, 16, 256, 2), (8, 16, 256, 1), (4, 16, 256, 1), (12, 16, 128, 1), (8, 32, 128, 1), (4, 32, 256, 1)):
+        if 'octets-only' in sys.argv and Q != 2:
+            continue
         fir = np.concatenate([fir8, fir8[:, ::-1]], axis=1)[:, :C]
         table = make_table(fir)
-        env_set(VND_SPEC_NT=nt)
-        T = (nt // 2) * M
+        env_set(VND_SPEC_NT=nt, VND_WIN_OCTET=1 if Q == 2 else 0)
+        T = (nt // (2 * Q)) * M
         for n in sorted({1, 3, M + 1, T - 1, T, T + 1, 2 * T + 3, 5 * T + 17, 40003}):
             for batch in (1, 3):
                 x = rng.uniform(-1, 1, (batch, n, C)).astype(np.float32)
@@ -50,7 +52,7 @@ if 'skip-small' not in sys.argv:
                     ctx.set_variant(FORCE | WIN[M] | (min_span << 20) | (rounds << 28))
                     for mode in (2, 0):
                         text = table.describe(batch, n, C, mode)
-                        if 'channel-quads' not in text:
+                        if ('channel-octets' if Q == 2 else 'channel-quads') not in text or f'tile={T} ' not in text:
                             print('NOT QUAD:', C, M, nt, n, batch, text, flush=True); bad += 1
                             continue
                         got = table.convolve_host(x, mode)
@@ -65,7 +67,7 @@ if 'skip-small' not in sys.argv:
                             bad += 1
                             w = np.argwhere(~np.isclose(got, want, rtol=0, atol=2e-6 * peak))
                             print(f'FAIL C={C} M={M} nt={nt} n={n} batch={batch} spans=({min_span},{rounds}) mode={mode}: {what}; first bad {w[:4].tolist()} of {len(w)}', flush=True)
-        print(f'C={C} M={M} nt={nt}: small shapes done, failures so far {bad}', flush=True)
+        print(f'C={C} M={M} nt={nt} Q={Q}: small shapes done, failures so far {bad}', flush=True)
         ctx.set_variant(-1)
         table.close()
     env_set()
@@ -101,9 +103,8 @@ def rate(variant, mode, label):
 env_set()
 ye = run(1 << 25, 0)                       # the generic ordered kernel: oracle-identical (tests)
 peak = float(ye.abs().max())
-configs = [('quad 16x256', -1, {}), ('quad 16x256 nt-stores', -1, dict(VND_FORCE_NT=1)), ('quad 16x128', -1, dict(VND_SPEC_NT=128)),
-           ('quad 32x256', WIN[32], {}), ('quad 16x512', -1, dict(VND_SPEC_NT=512)), ('quad 16x256 la=4', -1, dict(VND_SPEC_LA=4)),
-           ('quad 16x256 la=10', -1, dict(VND_SPEC_LA=10)),
+configs = [('octet 16x512', -1, {}), ('octet 16x512 nt-stores', -1, dict(VND_FORCE_NT=1)), ('octet 16x512 la=4', -1, dict(VND_SPEC_LA=4)),
+           ('quad 16x256', -1, dict(VND_WIN_OCTET=0)), ('quad 16x512', -1, dict(VND_WIN_OCTET=0, VND_SPEC_NT=512)),
            ('pair-read', -1, dict(VND_WIN_QUAD=0)), ('pair window 32x128', WIN[32], dict(VND_WIN_QUAD=0, VND_SPEC_NT=128))]
 ok = []
 for label, variant, env in configs:
@@ -122,3 +123,13 @@ for rep in range(2):
         env_set(**env)
         rate(variant, 2, f'fast  {label}')
         rate(variant, 0, f'exact {label}')
+
+# the same pool bytes as FOUR-channel frames (the quad is the frame: whole lines per workgroup), first four channels' taps
+table4 = make_table(fir8[:, :4])
+x4 = x.view(2 * pool, n, 4); y4 = y.view(2 * pool, n, 4)
+env_set()
+ctx.set_variant(-1)
+for mode in (2, 0):
+    desc = table4.describe(2 * pool, n, 4, mode)
+    best = [table4.time_device(x4.data_ptr(), y4.data_ptr(), 2 * pool, n, 4, mode=mode, n_buffers=1, stride_elems=0, iters=40, stream=st) for _ in range(12)]
+    print(f'4-channel frames, mode {mode}: {np.mean(best[6:]):.4f} ms (min {min(best):.4f})  {desc}', flush=True)

@@ -463,7 +463,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     const bool nt_big = batch * n * C * (int64_t)sizeof(float) >= ((int64_t)64 << 20);
     auto nt_stores_of = [&](const SpecConfig &c) {
         // a channel pair (or quad) is a piece of a frame: let L2 merge the pieces - unless the quad IS the frame
-        if (C != 2 && !(c.win_q && C == 4) && !spec_env("VND_FORCE_NT", 0)) return 0;
+        if (C != 2 && !(c.win_q && C == 4 * c.win_q) && !spec_env("VND_FORCE_NT", 0)) return 0;
         return nt_big ? 1 : 0;
     };
     auto rejected = [&](const SpecConfig &c0) {
@@ -474,9 +474,12 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
         return it != t->spec_modules.end() && it->second->failed;
     };
     const bool win_mode_ok = win_m > 0 && rr_hint == 0 && (mode == VND_MODE_FAST || win_exact || (win_quad && win_exact_env != 0));
-    if (win_mode_ok && win_quad)
-        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, vw >= 2 ? win_m : spec_env("VND_WIN_QUAD_M", 16), attempt == 1,
-                                 false, &p.cfg, rejected, true);
+    // (8k channels: two neighbouring quads - with 8 channels whole frames, whole cache lines - per workgroup of 512 lanes when that fits)
+    const int quad_m = vw >= 2 ? win_m : spec_env("VND_WIN_QUAD_M", 16);
+    if (win_mode_ok && win_quad && C % 8 == 0 && spec_env("VND_WIN_OCTET", 1) != 0)
+        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, quad_m, attempt == 1, false, &p.cfg, rejected, 2);
+    if (!picked && win_mode_ok && win_quad)
+        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, quad_m, attempt == 1, false, &p.cfg, rejected, 1);
     if (!picked && win_mode_ok && win_c && (!bc || vw >= 2))
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, bc, &p.cfg, rejected);
     if (!picked && !spec_pick_config(t->spec_table, (size_t)ctx->lds_limit, rr_hint, dd_hint, &p.cfg, attempt == 1 || C != 2, bc, mode == VND_MODE_EXACT)) { p.why = "halo does not fit the ring"; return p; }
@@ -487,7 +490,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     const int64_t per_cu = p.cfg.win ? p.cfg.win_per_cu
                                      : std::min<int64_t>(std::min<int64_t>(16, 2048 / p.cfg.nt), (int64_t)(160 * 1024) / (int64_t)p.cfg.lds_bytes());
     const int64_t resident = (int64_t)cus * std::max<int64_t>(per_cu, 1);
-    const int64_t units = batch * (p.cfg.win_q ? C / 4 : C / 2);      // (stream, channel pair) - or channel quad
+    const int64_t units = batch * (p.cfg.win_q ? C / (4 * p.cfg.win_q) : C / 2);      // (stream, channel pair) - or channel quad / octet
     // a workgroup needs a span long enough to amortise filling its ring: 8 tiles when there are 16 and more per resident
     // slot; with less, shorter spans (down to 2 tiles) so that the chip still fills - a lone 60 s stream then runs 1.1x
     // (fast) to 1.75x (exact, 128 taps) faster than through the generic kernels, tools/single_stream_try.py - and below
@@ -1481,8 +1484,10 @@ vnd_status vnd_window_kernel_source(int32_t C, const int32_t *tap_offsets, const
     }
     WinGeom g;
     // (tables of 4k channels: the quad form, as the launches take it - VND_WIN_QUAD=0: channel pairs)
-    const bool quad = C % 4 == 0 && spec_env("VND_WIN_QUAD", 1) != 0 &&
-                      win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, true);
+    bool quad = C % 8 == 0 && spec_env("VND_WIN_QUAD", 1) != 0 && spec_env("VND_WIN_OCTET", 1) != 0 &&
+                win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, 2);
+    quad = quad || (C % 4 == 0 && spec_env("VND_WIN_QUAD", 1) != 0 &&
+                    win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, 1));
     if (!quad && !win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g))
         return fail(VND_ERR_UNSUPPORTED, "this window geometry does not fit the LDS");
     SpecConfig cfg;
@@ -1544,7 +1549,7 @@ static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64
                          "nt_stores=%d mode=%d lds=%zuB workgroups=%u (%u units: %d spans x %d tiles per stream) threads=%d store_phase=%s",
                          sp.cfg.exact ? "_exact" : "", sp.cfg.win, sp.cfg.tile(), sp.cfg.la, sp.cfg.nt_stores, mode,
                          sp.cfg.lds_bytes(), sp.nblocks, sp.units, sp.spans, sp.tiles_per_span, sp.cfg.nt,
-                         sp.cfg.win_q ? "frame-pairs pieces=channel-quads" : (sp.cfg.win_xpose ? "frame-pairs" : "planar"));
+                         sp.cfg.win_q == 2 ? "frame-pairs pieces=channel-octets" : (sp.cfg.win_q ? "frame-pairs pieces=channel-quads" : (sp.cfg.win_xpose ? "frame-pairs" : "planar")));
                 return VND_OK;
             }
             snprintf(text, (size_t)len,

@@ -48,8 +48,8 @@ struct SpecConfig {
     // win_g = entries one base register reaches, win_lds = its LDS footprint (the halo is the table's)
     int win = 0, win_g = 0, win_lds = 0, win_per_cu = 0;    // (win_per_cu: workgroups a CU holds - LDS and registers)
     int win_xpose = 0; // the store phase transposes through LDS as interleaved frame pairs (1) or as planar chunks (0: fewer registers)
-    int win_q = 0;     // window form on channel QUADS (signals of 4k channels): half the workgroup's lanes per channel pair
-    int tile() const { return win ? (win_q ? nt / 2 : nt) * win : 2 * nt * rr; }
+    int win_q = 0;     // window form on channel QUADS (1: signals of 4k channels, half the workgroup's lanes per channel pair) or OCTETS (2: 8k channels, a quarter)
+    int tile() const { return win ? (win_q ? nt / (2 * win_q) : nt) * win : 2 * nt * rr; }
     size_t lds_bytes() const
     {
         if (win) return (size_t)win_lds;

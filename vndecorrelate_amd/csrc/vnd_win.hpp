@@ -31,26 +31,26 @@ struct WinGeom {
     int NB = 0;          // base registers per channel
     int plane = 0;       // bytes between chunk planes
     int npl = 2;         // input planes sets (1: mono input fanned out)
-    int quad = 0;        // 1: a workgroup takes a channel QUAD (16 bytes of every frame), half its lanes per pair
-    int nh() const { return quad ? nt / 2 : nt; }            // lanes - and ring entries of a tile - per channel pair
-    size_t lds_bytes() const { return (size_t)(quad ? 2 : 1) * (size_t)npl * (size_t)(M / 4) * (size_t)plane; }
+    int quad = 0;        // 1: a workgroup takes a channel QUAD (16 bytes of every frame), half its lanes per pair; 2: an OCTET (32 bytes), a quarter
+    int nh() const { return quad ? nt / (2 * quad) : nt; }   // lanes - and ring entries of a tile - per channel pair
+    size_t lds_bytes() const { return (size_t)(quad ? 2 * quad : 1) * (size_t)npl * (size_t)(M / 4) * (size_t)plane; }
     int tile() const { return nh() * M; }
 };
 
 inline int win_workgroups_per_cu(const WinGeom &g);
 
 // Geometry of the window kernel for a table; false when it does not fit (the caller keeps the pair-read kernel).
-inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size_t lds_limit, WinGeom *g, bool quad = false)
+inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size_t lds_limit, WinGeom *g, int quad = 0)
 {
     if (!(M == 16 || M == 32 || M == 64) || nt % 64 != 0 || nt < 64 || nt > 1024 || G < 1) return false;
     // the quad form: whole channel quads, whole waves per pair, a lane of a 64-frame access inside one entry
-    if (quad && (t.C % 4 != 0 || bc || nt % 128 != 0 || M > 32)) return false;
+    if (quad && (quad > 2 || t.C % (4 * quad) != 0 || bc || nt % (128 * quad) != 0 || M > 32)) return false;
     // one lane's tap sum is straight-line code, M/2 packed instructions of 8 bytes per tap: beyond ~1000 taps per channel
     // pair it would be megabytes of code for hipRTC and the 64 KB instruction cache (cfg3's 256 taps: 33 KB) - such
     // tables keep the pair-read form
     if ((int64_t)t.idx.size() * M > 32768) return false;
     if (t.C < 2 || (t.C & 1) || (bc && t.C != 2)) return false;      // whole channel pairs
-    g->M = M; g->nt = nt; g->G = G; g->npl = bc ? 1 : 2; g->C = t.C; g->quad = quad ? 1 : 0;
+    g->M = M; g->nt = nt; g->G = G; g->npl = bc ? 1 : 2; g->C = t.C; g->quad = quad;
     const int nh = g->nh();
     const int qc = M / 4;
     auto lay_out = [&](int de) {
@@ -148,13 +148,13 @@ inline void win_traffic(const SpecTable &t, int M, size_t *lds_bytes, size_t *fm
 inline std::string win_taps_name(int pg) { return pg == 0 ? std::string("vw_taps") : "vw_taps_" + std::to_string(pg); }
 
 // vw_taps_of<PG>(): the pair's function by its number, and VW_DISPATCH: the kernel's span loop instantiated per channel pair
-inline std::string win_taps_dispatch(const SpecTable &t, bool quad = false)
+inline std::string win_taps_dispatch(const SpecTable &t, int quad = 0)
 {
     std::string s = "template <int PG> __device__ __forceinline__ void vw_taps_of(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
     for (int pg = 0; pg < t.C / 2; ++pg)
         spec_append(s, "    %sif constexpr (PG == %d) %s(b, o0, o1);\n", pg ? "else " : "", pg, win_taps_name(pg).c_str());
     s += "}\n#define VW_DISPATCH(pg) switch (pg) {";
-    if (quad) for (int qd = 0; qd < t.C / 4; ++qd) spec_append(s, " case %d: vw_span_q<%d>(a, lds, stream, span); break;", qd, qd);
+    if (quad) for (int qd = 0; qd < t.C / (4 * quad); ++qd) spec_append(s, " case %d: vw_span_q<%d>(a, lds, stream, span); break;", qd, qd);
     else for (int pg = 0; pg < t.C / 2; ++pg) spec_append(s, " case %d: vw_span<%d>(a, lds, stream, span); break;", pg, pg);
     s += " default: break; }\n";
     return s;
@@ -445,6 +445,7 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
                 g.nt, g.M, g.R, g.G, g.NB, g.DE, g.plane, c.la);
     spec_append(s, "#define VW_NT_STORES %d\n#define VW_EPI %d\n#define VW_BC %d\n#define VW_EXACT %d\n#define VW_C %d\n", c.nt_stores, c.epi, c.bc, c.exact, g.C);
     spec_append(s, "#define VW_Q %d\n", g.quad);
+    spec_append(s, "#define VW_CU_PAIRS %d\n", spec_env("VND_WIN_QUAD_CU_PAIRS", 0) != 0 ? 1 : 0);
     spec_append(s, "#define VW_NT_STORE_AUX %d\n", spec_env("VND_SPEC_STORE_AUX", 2));
     // the transposition as interleaved frame pairs (one 16-byte read-back per store, planes an odd number of slots apart) or as
     // planar chunks read back in 8-byte halves (VND_WIN_XPOSE_PAIRS=0: then 32-frame runs swizzle their lanes' pair indices)
@@ -471,7 +472,7 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
     const size_t at = fixed.find(marker);
     src += fixed.substr(0, at);
     for (int pg = 0; pg < t.C / 2; ++pg) src += c.exact ? win_taps_function_exact(t, g, c.la, pg) : win_taps_function(t, g, c.la, pg);
-    src += win_taps_dispatch(t, g.quad != 0);
+    src += win_taps_dispatch(t, g.quad);
     src += fixed.substr(at + marker.size());
     return src;
 }
@@ -479,17 +480,18 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
 // geometry choice: the largest workgroup whose ring (tile + halo, mirror) still fits; small_tiles starts lower
 // (short streams: a ring is filled once per span)
 inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool small_tiles, bool bc, SpecConfig *out,
-                            const std::function<bool(const SpecConfig &)> &rejected = nullptr, bool quad = false)
+                            const std::function<bool(const SpecConfig &)> &rejected = nullptr, int quad = 0)
 {
     // the geometry that keeps the most waves on a CU (the ring is LDS-bound: tile + halo per workgroup), the larger
     // workgroup on a tie (the halo is shared by more lanes); short streams (small_tiles: a ring is filled once per
     // span) take at most 128 threads = 4096-frame tiles
-    static const int kShapes[] = {256, 192, 128, 64};
+    static const int kShapes[] = {512, 256, 192, 128, 64};
     const int nt_env = spec_env("VND_SPEC_NT", 0), g_env = spec_env("VND_WIN_G", 0);
     int best_waves = 0;
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 5; ++k) {
         const int nt = nt_env > 0 ? nt_env : kShapes[k];
-        if (small_tiles && nt_env <= 0 && nt > (quad ? 256 : 128)) continue;
+        if (nt_env <= 0 && nt > 256 && quad < 2) continue;            // 512 lanes: octets only (a quarter of them per channel pair)
+        if (small_tiles && nt_env <= 0 && nt > (quad ? 256 * quad : 128)) continue;
         for (int G : {8, 4}) {
             if (g_env > 0) G = g_env;
             WinGeom g;
@@ -534,7 +536,7 @@ inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool sm
 inline std::string win_source_for(const SpecTable &t, const SpecConfig &cfg)
 {
     WinGeom g;
-    if (!win_geometry(t, cfg.win, cfg.nt, cfg.win_g, cfg.bc != 0, 160 * 1024, &g, cfg.win_q != 0)) return "#error window geometry does not fit\n";
+    if (!win_geometry(t, cfg.win, cfg.nt, cfg.win_g, cfg.bc != 0, 160 * 1024, &g, cfg.win_q)) return "#error window geometry does not fit\n";
     return win_source(t, g, cfg);
 }
 
