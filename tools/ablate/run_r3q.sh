@@ -1,8 +1,9 @@
 #!/bin/bash
-# round 3 (late): PMC passes of the window form on channel QUADS (vw_span_q) on cfg5, one counter group per pass;
-# VND_WIN_QUAD=0 in the environment profiles the pair-read kernel beside it (tag pairs)
+# round 3 (late): PMC passes of the window form on channel OCTETS / QUADS (vw_span_q) on cfg5, one counter group per pass.
+#   run_r3q.sh octet            (the default launch)
+#   VND_WIN_OCTET=0 run_r3q.sh quad        VND_WIN_QUAD=0 run_r3q.sh pairs   (the pair-read kernel beside them)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-tag=${1:-quad}
+tag=${1:-octet}
 out=gpurun_out/prof_r3_c8_$tag; mkdir -p $out
 run() { local name=$1; shift; timeout -k 5 150 rocprofv3 "$@" -d $out/$name -o p --output-format csv -- python3 tools/secondary_profile.py cfg5 40 > $out/$name.log 2>&1; echo "cfg5 $tag $name rc=$?"; }
 run trace --kernel-trace --stats
@@ -13,4 +14,3 @@ run fetch --pmc FETCH_SIZE GRBM_GUI_ACTIVE
 run write --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 run tcc --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_REQ_sum TCC_READ_sum
 python3 tools/summarize_profile.py $out > gpurun_out/prof_r3_c8_$tag.txt 2>&1
-cat gpurun_out/prof_r3_c8_$tag.txt
