@@ -271,6 +271,51 @@ def test_window_form_on_channel_quads(env, golden, monkeypatch, C, M, nt, Q):
     table.close()
 
 
+@pytest.mark.parametrize('gname,M,nt', [('g48k_k128_u', 32, 256), ('g48k_k30', 16, 256), ('g48k_k128_l', 32, 512), ('g44k_noenv', 32, 384)])
+def test_window_form_with_the_waves_split_over_the_channels(env, golden, monkeypatch, gname, M, nt):
+    """VND_WIN_SPLIT=2: half a workgroup's waves compute channel 0 of the tile's nt / 2 entries, the others channel 1 (one
+    channel's accumulators per lane: three waves per SIMD), outputs exchanged through the tile's dead ring entries (vw_span_s).
+    Lengths around the tile, tails, batches, one-tile spans and seams against the NumPy oracle - exact bit for bit, fast within
+    tolerance.  A fast-mode build of this form that spills is rejected like any window build: the launch takes the plain form and
+    is still right.  Off by default (profiles/r03_split_waves.txt)."""
+    d, native, ctx = env
+    fir = golden.fir(gname)
+    table = _table(native, ctx, fir)
+    monkeypatch.setenv('VND_SPEC_NT', str(nt))
+    monkeypatch.setenv('VND_WIN_SPLIT', '2')
+    tol = 2e-6 if 'k128' in gname else TOL_PEAK
+    rng = np.random.default_rng(M + nt)
+    T = (nt // 2) * M
+    split_seen = 0
+    for n in sorted({1, 3, M + 1, T - 1, T, T + 1, 2 * T + 3, 5 * T + 17, 40003}):
+        for batch in (1, 3):
+            if batch > 1 and n % 2:
+                continue
+            x = rng.uniform(-1, 1, (batch, n, 2)).astype(np.float32)
+            want = np.stack([O.convolve_velvet_noise(x[b], fir) for b in range(batch)])
+            for min_span, rounds in ((1, 7), (2, 1)):
+                ctx.set_variant(FORCE | WIN[M] | span_bits(min_span, rounds))
+                for mode, name in ((d.MODE_FAST, 'conv_spec_window'), (d.MODE_EXACT, 'conv_spec_exact_window')):
+                    text = table.describe(batch, n, 2, mode)
+                    assert text.startswith(name) and f'frames_per_lane={M} ' in text, text
+                    if 'waves=split-by-channel' in text:
+                        assert f'tile={T} ' in text and f'threads={nt}' in text, text
+                        split_seen += 1
+                    else:
+                        assert mode == d.MODE_FAST, text          # (only fast-mode builds of this form have been seen to spill)
+                    got = table.convolve_host(x, mode)
+                    where = f'{gname} M={M} n={n} batch={batch} spans=({min_span},{rounds})'
+                    if mode == d.MODE_EXACT:
+                        assert np.array_equal(got, want), where
+                    else:
+                        assert _err(got, want) <= tol, f'{where}: {_err(got, want):.2e}'
+    assert split_seen > 0
+    ctx.set_variant(-1)
+    monkeypatch.delenv('VND_WIN_SPLIT')
+    assert 'split-by-channel' not in table.describe(24, 2880000, 2, d.MODE_FAST)          # nothing takes it by default
+    table.close()
+
+
 def test_stereo_tables_take_the_window_form_by_default_in_both_modes(env, golden):
     """The automatic choice for a stereo table with enough work: the window form, fast and exact, function path and class
     path; tables of 4k channels the window form on channel quads, of 8k channels on octets; a mono input fanned out and

@@ -340,3 +340,30 @@ def test_quad_form_source_for_tables_of_4k_channels(native, golden, tmp_path, mo
     # whole 16-byte pieces in both directions
     assert count.get('buffer_load_dwordx2', 0) == 0 and count.get('buffer_store_dwordx2', 0) == 0
     assert count['buffer_store_dwordx4'] == (2 // Q) * (M // 2)
+
+
+@pytest.mark.parametrize('mode', [2, 0])
+def test_split_form_source_keeps_three_waves_per_simd(native, golden, tmp_path, mode, monkeypatch):
+    """VND_WIN_SPLIT: a wave computes ONE channel of a stereo table (vw_taps_c0 / vw_taps_c1) - one channel's accumulators per
+    lane, so the dense 128-tap table builds for three waves per SIMD (<= 168 registers) without spilling."""
+    offs, idx, w = _table(golden.fir('g48k_k128_u'))
+    M, nt = 32, 256
+    monkeypatch.setenv('VND_WIN_SPLIT', '2')
+    src = native.window_kernel_source(offs, idx, w, mode, M, nt)
+    assert _macro(src, 'VW_S') == 1 and _macro(src, 'VW_Q') == 0 and _macro(src, 'VW_WAVES_PER_EU') == 3
+    assert _macro(src, 'VW_R') == nt // 2 + _macro(src, 'VW_DE')
+    assert 3 * 2 * (M // 4) * _macro(src, 'VW_PLANE') <= 160 * 1024           # three workgroups per CU
+    assert 'vw_taps_c0(' in src and 'vw_taps_c1(' in src and '#define VW_DISPATCH(pg) vw_span_s(' in src
+    f = tmp_path / 'k.hip'
+    f.write_text(src)
+    out = tmp_path / 'k.s'
+    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '--cuda-device-only',
+                        '-include', 'hip/hip_runtime.h', '-S', str(f), '-o', str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = out.read_text()
+    assert re.search(r'ScratchSize: 0\b', asm), 'the split form of the dense table must not spill'
+    assert int(re.search(r'; NumVgprs: (\d+)', asm).group(1)) <= 168
+    ops = re.findall(r'^\s+([a-z0-9_]+)', asm, re.M)
+    assert ops.count('s_barrier') == 4                       # the prologue's and the three of a tile
+    monkeypatch.delenv('VND_WIN_SPLIT')
+    assert _macro(native.window_kernel_source(offs, idx, w, mode, M, nt), 'VW_S') == 0      # off by default

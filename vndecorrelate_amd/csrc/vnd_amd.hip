@@ -99,6 +99,7 @@ struct vnd_taps {
     bool spec_ok = false;          // the table is within the specialised kernel's scope
     bool spec_exact_ok = false;    // ... also in VND_MODE_EXACT (no empty segment)
     bool win_exact_pays = false;   // ... and its exact mode takes the window form (stereo tables)
+    bool win_split_pays = false;   // ... with the waves split over the channels (dense stereo tables: bound by vector issue)
     std::mutex spec_mutex;
     std::map<SpecConfig, std::unique_ptr<SpecModule>> spec_modules;
 };
@@ -480,6 +481,16 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, quad_m, attempt == 1, false, &p.cfg, rejected, 2);
     if (!picked && win_mode_ok && win_quad)
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, quad_m, attempt == 1, false, &p.cfg, rejected, 1);
+    // plain stereo: the waves SPLIT over the two channels (VW_S, vw_span_s: three waves per SIMD instead of two) -
+    // VND_WIN_SPLIT: 0 never (the default), 1 dense tables in the fast mode, 2 always.  Measured, 256 lanes (three workgroups
+    // per CU), two boxes: cfg3 fast +2.0 / +2.4 % (0.461 against 0.471 ms, 0.475 against 0.486), but cfg3 kappa 1 -5 %, cfg2
+    // fast -3.5 %, exact modes -3 ... +2 %; 384 lanes (six waves on four SIMDs) -17 %: occupancy is not what holds the dense
+    // tables at 0.65 of the vector issue rate (tools/win_split_try.py, profiles/r03_split_waves.txt)
+    const int split_env = spec_env("VND_WIN_SPLIT", 0);
+    const bool win_split = C == 2 && Cx == 2 && !pointwise &&
+                           (split_env == 2 || (split_env == 1 && vw == 0 && t->win_split_pays && mode == VND_MODE_FAST));
+    if (!picked && win_mode_ok && win_split)
+        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, false, &p.cfg, rejected, 0, true);
     if (!picked && win_mode_ok && win_c && (!bc || vw >= 2))
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, bc, &p.cfg, rejected);
     if (!picked && !spec_pick_config(t->spec_table, (size_t)ctx->lds_limit, rr_hint, dd_hint, &p.cfg, attempt == 1 || C != 2, bc, mode == VND_MODE_EXACT)) { p.why = "halo does not fit the ring"; return p; }
@@ -869,6 +880,8 @@ vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, 
         // odd-offset taps became single adds (cfg2 function path 4.48 against 4.20 TB/s, class path 4.77 against 4.64; cfg3
         // 1.93 against 1.40 and 2.03 against 1.74: tools/win_exact_try.py, profiles/r03_exact_window.txt)
         t->win_exact_pays = t->spec_exact_ok && C % 2 == 0;
+        // the split form (a wave per channel, three waves per SIMD): tables of 64 and more taps per channel
+        t->win_split_pays = C == 2 && total >= 128;
     }
     if (e == hipSuccess) e = upload(&t->d_taps_fast, fast.data(), fast.size());
     {   // ordered image: table order, weight first (SGPR pair layout), byte offsets, padded
@@ -1488,10 +1501,12 @@ vnd_status vnd_window_kernel_source(int32_t C, const int32_t *tap_offsets, const
                 win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, 2);
     quad = quad || (C % 4 == 0 && spec_env("VND_WIN_QUAD", 1) != 0 &&
                     win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, 1));
-    if (!quad && !win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g))
+    const bool split = !quad && C == 2 && spec_env("VND_WIN_SPLIT", 0) != 0 &&
+                       win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, 0, true);
+    if (!quad && !split && !win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g))
         return fail(VND_ERR_UNSUPPORTED, "this window geometry does not fit the LDS");
     SpecConfig cfg;
-    cfg.nt = threads; cfg.win = frames_per_lane; cfg.win_g = g.G; cfg.win_lds = (int)g.lds_bytes(); cfg.win_q = g.quad;
+    cfg.nt = threads; cfg.win = frames_per_lane; cfg.win_g = g.G; cfg.win_lds = (int)g.lds_bytes(); cfg.win_q = g.quad; cfg.win_s = g.split;
     cfg.la = spec_env("VND_SPEC_LA", frames_per_lane >= 32 ? 4 : 6);
     cfg.win_xpose = spec_env("VND_WIN_XPOSE_PAIRS", 1) != 0 ? 1 : 0;
     cfg.exact = mode == VND_MODE_EXACT ? 1 : 0;
@@ -1549,7 +1564,7 @@ static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64
                          "nt_stores=%d mode=%d lds=%zuB workgroups=%u (%u units: %d spans x %d tiles per stream) threads=%d store_phase=%s",
                          sp.cfg.exact ? "_exact" : "", sp.cfg.win, sp.cfg.tile(), sp.cfg.la, sp.cfg.nt_stores, mode,
                          sp.cfg.lds_bytes(), sp.nblocks, sp.units, sp.spans, sp.tiles_per_span, sp.cfg.nt,
-                         sp.cfg.win_q == 2 ? "frame-pairs pieces=channel-octets" : (sp.cfg.win_q ? "frame-pairs pieces=channel-quads" : (sp.cfg.win_xpose ? "frame-pairs" : "planar")));
+                         sp.cfg.win_s ? "planar waves=split-by-channel" : sp.cfg.win_q == 2 ? "frame-pairs pieces=channel-octets" : (sp.cfg.win_q ? "frame-pairs pieces=channel-quads" : (sp.cfg.win_xpose ? "frame-pairs" : "planar")));
                 return VND_OK;
             }
             snprintf(text, (size_t)len,

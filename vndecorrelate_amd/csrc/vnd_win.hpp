@@ -32,7 +32,8 @@ struct WinGeom {
     int plane = 0;       // bytes between chunk planes
     int npl = 2;         // input planes sets (1: mono input fanned out)
     int quad = 0;        // 1: a workgroup takes a channel QUAD (16 bytes of every frame), half its lanes per pair; 2: an OCTET (32 bytes), a quarter
-    int nh() const { return quad ? nt / (2 * quad) : nt; }   // lanes - and ring entries of a tile - per channel pair
+    int split = 0;       // 1: stereo, half the workgroup's waves per CHANNEL (three waves per SIMD fit the registers)
+    int nh() const { return split ? nt / 2 : (quad ? nt / (2 * quad) : nt); }   // lanes - and ring entries of a tile - per channel pair
     size_t lds_bytes() const { return (size_t)(quad ? 2 * quad : 1) * (size_t)npl * (size_t)(M / 4) * (size_t)plane; }
     int tile() const { return nh() * M; }
 };
@@ -40,8 +41,9 @@ struct WinGeom {
 inline int win_workgroups_per_cu(const WinGeom &g);
 
 // Geometry of the window kernel for a table; false when it does not fit (the caller keeps the pair-read kernel).
-inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size_t lds_limit, WinGeom *g, int quad = 0)
+inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size_t lds_limit, WinGeom *g, int quad = 0, bool split = false)
 {
+    if (split && (t.C != 2 || bc || quad || nt % 128 != 0 || M > 32)) return false;      // plain stereo, whole waves per channel
     if (!(M == 16 || M == 32 || M == 64) || nt % 64 != 0 || nt < 64 || nt > 1024 || G < 1) return false;
     // the quad form: whole channel quads, whole waves per pair, a lane of a 64-frame access inside one entry
     if (quad && (quad > 2 || t.C % (4 * quad) != 0 || bc || nt % (128 * quad) != 0 || M > 32)) return false;
@@ -50,7 +52,7 @@ inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size
     // tables keep the pair-read form
     if ((int64_t)t.idx.size() * M > 32768) return false;
     if (t.C < 2 || (t.C & 1) || (bc && t.C != 2)) return false;      // whole channel pairs
-    g->M = M; g->nt = nt; g->G = G; g->npl = bc ? 1 : 2; g->C = t.C; g->quad = quad;
+    g->M = M; g->nt = nt; g->G = G; g->npl = bc ? 1 : 2; g->C = t.C; g->quad = quad; g->split = split ? 1 : 0;
     const int nh = g->nh();
     const int qc = M / 4;
     auto lay_out = [&](int de) {
@@ -92,12 +94,12 @@ inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size
 // Workgroups a CU holds: LDS-bound, and register-bound - a lane carries its runs' accumulators, the outputs of the first
 // channel and a tile of prefetched frames (about 250 VGPRs with 32-frame runs, 150 with 16, more than 256 with 64), so
 // at most 2 / 3 / 1 waves per SIMD; a budget below that would spill the prefetch to scratch (measured: 3x slower).
-inline int win_waves_per_simd_max(int M) { return M <= 16 ? 3 : (M <= 32 ? 2 : 1); }
+inline int win_waves_per_simd_max(int M, bool split = false) { return split ? (M <= 32 ? 3 : 1) : (M <= 16 ? 3 : (M <= 32 ? 2 : 1)); }
 
 inline int win_workgroups_per_cu(const WinGeom &g)
 {
     const int by_lds = (int)std::min<size_t>(std::min<size_t>(16, 2048 / g.nt), (160 * 1024) / g.lds_bytes());
-    const int by_regs = std::max(1, win_waves_per_simd_max(g.M) * 4 / (g.nt / 64));
+    const int by_regs = std::max(1, win_waves_per_simd_max(g.M, g.split != 0) * 4 / (g.nt / 64));
     return std::max(1, std::min(by_lds, by_regs));
 }
 
@@ -160,17 +162,20 @@ inline std::string win_taps_dispatch(const SpecTable &t, int quad = 0)
     return s;
 }
 
-inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int la, int pg = 0)
+inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int la, int pg = 0, int only_ch = -1)
 {
     const int M = g.M;
     std::string s;
-    s += "__device__ __forceinline__ void " + win_taps_name(pg) + "(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
+    // (only_ch: the split form's per-channel function vw_taps_c<ch> - it leaves the other channel's outputs alone)
+    const std::string fname = only_ch < 0 ? win_taps_name(pg) : "vw_taps_c" + std::to_string(only_ch);
+    s += "__device__ __forceinline__ void " + fname + "(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
     spec_append(s, "    v4f q[%d];\n    v2f E[%d], P[%d];\n    float O0, OL;\n", la + 1, M / 2, M / 2);
     // one read stream over both channels: the pipeline stays full across the channel boundary
     std::vector<WinRead> reads;
     size_t first_of_ch[3] = {0, 0, 0};
     for (int ch = 0; ch < 2; ++ch) {
         first_of_ch[ch] = reads.size();
+        if (only_ch >= 0 && ch != only_ch) continue;
         for (WinRead &r : win_schedule(t, 2 * pg + ch, M)) { r.ch = ch; reads.push_back(std::move(r)); }      // ch: the LDS plane set
     }
     first_of_ch[2] = reads.size();
@@ -192,6 +197,7 @@ inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int l
     };
     for (size_t k = 0; k < std::min(reads.size(), (size_t)la); ++k) emit_read(k);
     for (int ch = 0; ch < 2; ++ch) {
+        if (only_ch >= 0 && ch != only_ch) continue;
         std::vector<char> e_used(M / 2, 0), p_used(M / 2, 0);
         bool o0_used = false, ol_used = false;
         for (size_t k = first_of_ch[ch]; k < first_of_ch[ch + 1]; ++k) {
@@ -325,18 +331,20 @@ inline void win_traffic_exact(const SpecTable &t, int M, size_t *lds_bytes, size
     }
 }
 
-inline std::string win_taps_function_exact(const SpecTable &t, const WinGeom &g, int la, int pg = 0)
+inline std::string win_taps_function_exact(const SpecTable &t, const WinGeom &g, int la, int pg = 0, int only_ch = -1)
 {
     const int M = g.M;
     const size_t ring = (size_t)la + 2;                  // read k lands in q[k % ring]: the previous chunk stays whole while read k + la is issued
     std::string s;
-    s += "__device__ __forceinline__ void " + win_taps_name(pg) + "(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
+    const std::string fname = only_ch < 0 ? win_taps_name(pg) : "vw_taps_c" + std::to_string(only_ch);
+    s += "__device__ __forceinline__ void " + fname + "(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
     spec_append(s, "    v4f q[%zu];\n    v2f S[%d], A[%d];\n    const v2f Z2 = {0.0f, 0.0f};\n", ring, M / 2, M / 2);
     std::vector<WinExPass> passes;
     std::vector<WinExRead> reads;
     size_t pass_first[3] = {0, 0, 0};
     for (int ch = 0; ch < 2; ++ch) {
         pass_first[ch] = passes.size();
+        if (only_ch >= 0 && ch != only_ch) continue;
         std::vector<WinExPass> ps = win_exact_passes(t, 2 * pg + ch);
         for (WinExPass &x : ps) x.ch = ch;                           // the LDS plane set
         if (!ps.empty()) win_exact_reads(ps, M, &reads, passes.size());
@@ -351,6 +359,7 @@ inline std::string win_taps_function_exact(const SpecTable &t, const WinGeom &g,
     for (size_t k = 0; k < std::min(reads.size(), (size_t)la); ++k) emit_read(k);
     size_t rk = 0;
     for (int ch = 0; ch < 2; ++ch) {
+        if (only_ch >= 0 && ch != only_ch) continue;
         std::vector<char> e_live(M, 0);          // per OUTPUT: the segment accumulator holds a value
         bool a_live = false;                     // the channel's output accumulators hold a value (class path)
         bool sum_is_output = false;
@@ -444,7 +453,7 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
     spec_append(s, "#define VW_NT %d\n#define VW_M %d\n#define VW_R %d\n#define VW_G %d\n#define VW_NB %d\n#define VW_DE %d\n#define VW_PLANE %d\n#define VW_LA %d\n",
                 g.nt, g.M, g.R, g.G, g.NB, g.DE, g.plane, c.la);
     spec_append(s, "#define VW_NT_STORES %d\n#define VW_EPI %d\n#define VW_BC %d\n#define VW_EXACT %d\n#define VW_C %d\n", c.nt_stores, c.epi, c.bc, c.exact, g.C);
-    spec_append(s, "#define VW_Q %d\n", g.quad);
+    spec_append(s, "#define VW_Q %d\n#define VW_S %d\n", g.quad, g.split);
     spec_append(s, "#define VW_CU_PAIRS %d\n", spec_env("VND_WIN_QUAD_CU_PAIRS", 0) != 0 ? 1 : 0);
     spec_append(s, "#define VW_NT_STORE_AUX %d\n", spec_env("VND_SPEC_STORE_AUX", 2));
     // the transposition as interleaved frame pairs (one 16-byte read-back per store, planes an odd number of slots apart) or as
@@ -459,7 +468,7 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
     spec_append(s, "#define VW_PRIO %d\n", spec_env("VND_WIN_PRIO", 1));
     spec_append(s, "#define VW_LOAD_AUX %d\n", spec_env("VND_SPEC_LOAD_AUX", 2));
     const int waves = (win_workgroups_per_cu(g) * (g.nt / 64) + 3) / 4;
-    spec_append(s, "#define VW_WAVES_PER_EU %d\n", std::max(1, std::min(waves, win_waves_per_simd_max(g.M))));
+    spec_append(s, "#define VW_WAVES_PER_EU %d\n", std::max(1, std::min(waves, win_waves_per_simd_max(g.M, g.split != 0))));
     return s;
 }
 
@@ -471,8 +480,14 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
     const std::string marker = "//@@VW_TAPS@@";
     const size_t at = fixed.find(marker);
     src += fixed.substr(0, at);
-    for (int pg = 0; pg < t.C / 2; ++pg) src += c.exact ? win_taps_function_exact(t, g, c.la, pg) : win_taps_function(t, g, c.la, pg);
-    src += win_taps_dispatch(t, g.quad);
+    if (g.split) {
+        for (int ch = 0; ch < 2; ++ch) src += c.exact ? win_taps_function_exact(t, g, c.la, 0, ch) : win_taps_function(t, g, c.la, 0, ch);
+        src += "template <int PG> __device__ void vw_taps_of(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M]);      // (vw_span: not instantiated)\n";
+        src += "#define VW_DISPATCH(pg) vw_span_s(a, lds, stream, span);\n";
+    } else {
+        for (int pg = 0; pg < t.C / 2; ++pg) src += c.exact ? win_taps_function_exact(t, g, c.la, pg) : win_taps_function(t, g, c.la, pg);
+        src += win_taps_dispatch(t, g.quad);
+    }
     src += fixed.substr(at + marker.size());
     return src;
 }
@@ -480,26 +495,27 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
 // geometry choice: the largest workgroup whose ring (tile + halo, mirror) still fits; small_tiles starts lower
 // (short streams: a ring is filled once per span)
 inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool small_tiles, bool bc, SpecConfig *out,
-                            const std::function<bool(const SpecConfig &)> &rejected = nullptr, int quad = 0)
+                            const std::function<bool(const SpecConfig &)> &rejected = nullptr, int quad = 0, bool split = false)
 {
     // the geometry that keeps the most waves on a CU (the ring is LDS-bound: tile + halo per workgroup), the larger
     // workgroup on a tie (the halo is shared by more lanes); short streams (small_tiles: a ring is filled once per
     // span) take at most 128 threads = 4096-frame tiles
-    static const int kShapes[] = {512, 256, 192, 128, 64};
+    static const int kShapes[] = {512, 384, 256, 192, 128, 64};
     const int nt_env = spec_env("VND_SPEC_NT", 0), g_env = spec_env("VND_WIN_G", 0);
     int best_waves = 0;
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < 6; ++k) {
         const int nt = nt_env > 0 ? nt_env : kShapes[k];
-        if (nt_env <= 0 && nt > 256 && quad < 2) continue;            // 512 lanes: octets only (a quarter of them per channel pair)
-        if (small_tiles && nt_env <= 0 && nt > (quad ? 256 * quad : 128)) continue;
+        if (nt_env <= 0 && nt > 256 && quad < 2 && !split) continue;  // 512 lanes: octets (a quarter of them per channel pair) and the split form only
+        if (nt_env <= 0 && nt == 384) continue;                       // (six waves land unevenly on four SIMDs: the split form 17 % slower than with 256 lanes)
+        if (small_tiles && nt_env <= 0 && nt > (quad ? 256 * quad : (split ? 256 : 128))) continue;
         for (int G : {8, 4}) {
             if (g_env > 0) G = g_env;
             WinGeom g;
-            if (win_geometry(t, M, nt, G, bc, lds_limit, &g, quad)) {
+            if (win_geometry(t, M, nt, G, bc, lds_limit, &g, quad, split)) {
                 const int waves = win_workgroups_per_cu(g) * (nt / 64);
                 if (waves > best_waves) {
                     SpecConfig c;
-                    c.nt = nt; c.win = M; c.win_g = G; c.win_lds = (int)g.lds_bytes(); c.bc = bc ? 1 : 0; c.win_q = g.quad;
+                    c.nt = nt; c.win = M; c.win_g = G; c.win_lds = (int)g.lds_bytes(); c.bc = bc ? 1 : 0; c.win_q = g.quad; c.win_s = g.split;
                     c.win_per_cu = win_workgroups_per_cu(g);
                     // reads kept in flight: each holds 4 registers, and 32-frame runs already live at ~240 of the 256 a lane
                     // has at two waves per SIMD (measured: 3 to 10 reads ahead run the same, tools/win_try.py)
@@ -507,7 +523,7 @@ inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool sm
                     c.rr = 0; c.pp = 0; c.dd = 0;
                     // the store phase: interleaved frame pairs (one 16-byte read-back per store) unless that build spilled
                     // before - it holds both channels' outputs interleaved - then planar chunks in 8-byte halves
-                    c.win_xpose = bc ? 0 : (spec_env("VND_WIN_XPOSE_PAIRS", 1) != 0 ? 1 : 0);
+                    c.win_xpose = (bc || split) ? 0 : (spec_env("VND_WIN_XPOSE_PAIRS", 1) != 0 ? 1 : 0);      // (the split form's outputs cross waves as planar runs)
                     if (rejected && rejected(c)) {                  // a build of this geometry failed or spilled before
                         if (!c.win_xpose) continue;
                         // (cfg2's fast kernel: 44 bytes of spill with 4 reads ahead, none with 3 - and 3 to 10 run the same)
@@ -536,7 +552,7 @@ inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool sm
 inline std::string win_source_for(const SpecTable &t, const SpecConfig &cfg)
 {
     WinGeom g;
-    if (!win_geometry(t, cfg.win, cfg.nt, cfg.win_g, cfg.bc != 0, 160 * 1024, &g, cfg.win_q)) return "#error window geometry does not fit\n";
+    if (!win_geometry(t, cfg.win, cfg.nt, cfg.win_g, cfg.bc != 0, 160 * 1024, &g, cfg.win_q, cfg.win_s != 0)) return "#error window geometry does not fit\n";
     return win_source(t, g, cfg);
 }
 
