@@ -220,6 +220,11 @@ def secondary_configs(torch, vnd, _native, ctx, mode) -> dict:
             tol = 2e-6 if kw['num_impulses'] > 64 else 1e-6           # (128 taps: the reference's own two paths differ by 1.2e-6)
             assert r['parity_vs_oracle_of_peak'] <= tol, f"{name}: timed output off by {r['parity_vs_oracle_of_peak']:.2e} of peak"
             r.update({'workload': what, 'binding_limit': limit})
+            if mode != vnd.MODE_EXACT and name != 'cfg3_kappa1':
+                # the API's default mode on the same pool: bit-identical to the oracle (asserted inside), its own per-table kernel
+                ex = device_rate(torch, t, shape, vnd.MODE_EXACT, buffers=buffers, taps=taps)
+                r['exact_mode'] = {k: ex[k] for k in ('kernel_ms', 'achieved_GBs', 'frac_of_8TBs', 'launch')}
+                r['exact_mode']['parity'] = 'bit-identical to the C oracle on the checked stream (asserted in this run)'
             out[name] = r
             t.close()
         except Exception as exc:                        # a secondary leg must never cost the headline

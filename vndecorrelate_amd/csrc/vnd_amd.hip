@@ -509,8 +509,9 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     int64_t min_span = (v >= 0 && ((v >> 20) & 7)) ? ((v >> 20) & 7) : 8;
     if (!(v >= 0 && ((v >> 20) & 7)))
         min_span = std::min<int64_t>(8, std::max<int64_t>(2, units * tiles_total / (2 * resident)));
-    if (!force && units * n < 2000000) { p.why = "too little work for persistent workgroups"; return p; }
-    p.eager = force || units * n >= 12000000;                  // enough work (frames per channel pair) to be worth building the kernel for
+    const int64_t pair_frames = batch * (C / 2) * n;           // the work, in frames per channel pair (whatever a workgroup's unit is)
+    if (!force && pair_frames < 2000000) { p.why = "too little work for persistent workgroups"; return p; }
+    p.eager = force || pair_frames >= 12000000;                // enough work to be worth building the kernel for
     // Spans per stream: the workgroups are equally long, so the grid should fill the resident slots
     // a whole number of times ("rounds") - 1.5 rounds cost as much as 2.  Fewest spans (longest
     // rings) whose last round is at least 95 % full, else the fullest.
