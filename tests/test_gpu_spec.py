@@ -47,7 +47,8 @@ def test_headline_workload_takes_the_specialised_kernel(env, golden):
     text = table.describe(128, 480000, 2, d.MODE_FAST)
     assert text.startswith('conv_spec'), text            # a silent fallback must not pass for the real thing
     exact = table.describe(128, 480000, 2, d.MODE_EXACT)
-    assert exact.startswith('conv_spec_exact_window') and 'frames_per_lane=32 ' in exact, exact     # the window form, 32-frame runs
+    # the window form: 64-frame runs with the waves split over the two channels (function-path tables, exact mode)
+    assert exact.startswith('conv_spec_exact_window') and 'frames_per_lane=64 ' in exact and 'waves=split-by-channel' in exact, exact
     ctx.set_variant(1 << 5)                                                  # window form off: the pair-read exact kernel
     exact = table.describe(128, 480000, 2, d.MODE_EXACT)
     assert exact.startswith('conv_spec_exact') and 'tile=1024' in exact, exact       # 256 threads x 2 pairs with the shifted copies

@@ -80,6 +80,10 @@ if 'skip-small' not in sys.argv:
 
 st = torch.cuda.current_stream().cuda_stream
 POOLS = {'cfg3': (24, 2880000), 'cfg3k1': (24, 2880000), 'cfg2': (128, 480000), 'class': (128, 480000)}
+if 'cfg3-only' in sys.argv:
+    POOLS = {k: v for k, v in POOLS.items() if k.startswith('cfg3')}
+if 'cfg2-only' in sys.argv:
+    POOLS = {k: v for k, v in POOLS.items() if not k.startswith('cfg3')}
 for name, (pool, n) in POOLS.items():
     if name == 'class':
         table = vnd.VelvetNoise(sample_rate_hz=48000, seed=1)._device_table()
@@ -106,20 +110,30 @@ for name, (pool, n) in POOLS.items():
     env_set(VND_WIN_SPLIT=0)
     ye, yf = run(0), run(2)
     peak = float(ye.abs().max())
-    configs = [('plain', dict(VND_WIN_SPLIT=0)), ('split 32x256', dict(VND_WIN_SPLIT=2)), ('automatic', {}), ('split 32x384', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=384)),
-               ('split 32x256 la=3', dict(VND_WIN_SPLIT=2, VND_SPEC_LA=3)), ('split 32x256 la=6', dict(VND_WIN_SPLIT=2, VND_SPEC_LA=6)),
-               ('split 32x512', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=512))]
+    configs = [('plain', dict(VND_WIN_SPLIT=0)), ('split 32x256', dict(VND_WIN_SPLIT=2)),
+               ('split 64x256 la=3 g=4', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=256, VND_SPEC_LA=3, VND_WIN_G=4, variant=4 << 5)),
+               ('split 64x256 la=2 g=4', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=256, VND_SPEC_LA=2, VND_WIN_G=4, variant=4 << 5)),
+               ('split 64x256 la=3 g=8', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=256, VND_SPEC_LA=3, VND_WIN_G=8, variant=4 << 5)),
+               ('split 64x128 la=3 g=4', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=128, VND_SPEC_LA=3, VND_WIN_G=4, variant=4 << 5))]
+    if 'all' in sys.argv:
+        configs += [('split 32x384', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=384)), ('split 32x256 la=3', dict(VND_WIN_SPLIT=2, VND_SPEC_LA=3)),
+                    ('split 32x256 la=6', dict(VND_WIN_SPLIT=2, VND_SPEC_LA=6)), ('split 32x512', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=512))]
     ok = []
     for label, env in configs:
+        env = dict(env)
+        ctx_variant = env.pop('variant', -1)
+        ctx.set_variant(ctx_variant)
         env_set(**env)
         try:
             f, e = run(2), run(0)
             print(f'{name} {label}: fast vs exact {float((f - ye).abs().max()) / peak:.2e} of peak (fast vs plain fast {float((f - yf).abs().max()) / peak:.1e}); exact bit-identical to the plain form: {bool(torch.equal(e, ye))}', flush=True)
-            ok.append((label, env))
+            ok.append((label, dict(env, variant=ctx_variant)))
         except Exception as exc:
             print(f'{name} {label}: {exc!r}', flush=True)
     for rep in range(2):
         for label, env in ok:
+            env = dict(env)
+            ctx.set_variant(env.pop('variant', -1))
             env_set(**env)
             rate(2, f'fast  {label}')
             rate(0, f'exact {label}')

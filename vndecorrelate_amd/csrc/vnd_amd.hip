@@ -99,7 +99,6 @@ struct vnd_taps {
     bool spec_ok = false;          // the table is within the specialised kernel's scope
     bool spec_exact_ok = false;    // ... also in VND_MODE_EXACT (no empty segment)
     bool win_exact_pays = false;   // ... and its exact mode takes the window form (stereo tables)
-    bool win_split_pays = false;   // ... with the waves split over the channels (dense stereo tables: bound by vector issue)
     std::mutex spec_mutex;
     std::map<SpecConfig, std::unique_ptr<SpecModule>> spec_modules;
 };
@@ -481,15 +480,19 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, quad_m, attempt == 1, false, &p.cfg, rejected, 2);
     if (!picked && win_mode_ok && win_quad)
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, quad_m, attempt == 1, false, &p.cfg, rejected, 1);
-    // plain stereo: the waves SPLIT over the two channels (VW_S, vw_span_s: three waves per SIMD instead of two) -
-    // VND_WIN_SPLIT: 0 never (the default), 1 dense tables in the fast mode, 2 always.  Measured, 256 lanes (three workgroups
-    // per CU), two boxes: cfg3 fast +2.0 / +2.4 % (0.461 against 0.471 ms, 0.475 against 0.486), but cfg3 kappa 1 -5 %, cfg2
-    // fast -3.5 %, exact modes -3 ... +2 %; 384 lanes (six waves on four SIMDs) -17 %: occupancy is not what holds the dense
-    // tables at 0.65 of the vector issue rate (tools/win_split_try.py, profiles/r03_split_waves.txt)
-    const int split_env = spec_env("VND_WIN_SPLIT", 0);
-    const bool win_split = C == 2 && Cx == 2 && !pointwise &&
-                           (split_env == 2 || (split_env == 1 && vw == 0 && t->win_split_pays && mode == VND_MODE_FAST));
-    if (!picked && win_mode_ok && win_split)
+    // plain stereo: the waves SPLIT over the two channels (VW_S, vw_span_s: a lane carries ONE channel's accumulators).
+    // VND_WIN_SPLIT: 0 never; 1 (default) where it pays; 2 always, with the frames per lane of the plain form.
+    //  * 32-frame runs, three waves per SIMD (three workgroups of 256 lanes per CU): cfg3 fast +2.0 / +2.4 % on two boxes, but
+    //    cfg3 kappa 1 -5 %, cfg2 fast -3.5 %, exact modes -3 ... +4 %; 384 lanes (six waves on four SIMDs) -17 %: not taken;
+    //  * 64-FRAME runs (half the LDS reads per FMA: every 16-byte window read costs the SIMD ~1.45 packed-FMA slots,
+    //    profiles/r03_fp32_issue_rate.txt) fit two waves per SIMD only in this form: VND_MODE_EXACT on function-path tables
+    //    +14-16 % at cfg3 (0.579 -> 0.497 ms), +6 % at cfg2 - taken there; class-path tables and the fast mode spill at 64
+    //    frames (rejected builds fall back to the plain form) (tools/win_split_try.py, profiles/r03_split_waves.txt)
+    const int split_env = spec_env("VND_WIN_SPLIT", 1);
+    const bool split_scope = C == 2 && Cx == 2 && !pointwise;
+    if (!picked && win_mode_ok && split_scope && split_env == 1 && vw == 0 && mode == VND_MODE_EXACT && !t->spec_table.has_seg)
+        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, 64, attempt == 1, false, &p.cfg, rejected, 0, true);
+    if (!picked && win_mode_ok && split_scope && split_env == 2)
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, false, &p.cfg, rejected, 0, true);
     if (!picked && win_mode_ok && win_c && (!bc || vw >= 2))
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, bc, &p.cfg, rejected);
@@ -881,8 +884,6 @@ vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, 
         // odd-offset taps became single adds (cfg2 function path 4.48 against 4.20 TB/s, class path 4.77 against 4.64; cfg3
         // 1.93 against 1.40 and 2.03 against 1.74: tools/win_exact_try.py, profiles/r03_exact_window.txt)
         t->win_exact_pays = t->spec_exact_ok && C % 2 == 0;
-        // the split form (a wave per channel, three waves per SIMD): tables of 64 and more taps per channel
-        t->win_split_pays = C == 2 && total >= 128;
     }
     if (e == hipSuccess) e = upload(&t->d_taps_fast, fast.data(), fast.size());
     {   // ordered image: table order, weight first (SGPR pair layout), byte offsets, padded

@@ -43,7 +43,7 @@ inline int win_workgroups_per_cu(const WinGeom &g);
 // Geometry of the window kernel for a table; false when it does not fit (the caller keeps the pair-read kernel).
 inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size_t lds_limit, WinGeom *g, int quad = 0, bool split = false)
 {
-    if (split && (t.C != 2 || bc || quad || nt % 128 != 0 || M > 32)) return false;      // plain stereo, whole waves per channel
+    if (split && (t.C != 2 || bc || quad || nt % 128 != 0)) return false;      // plain stereo, whole waves per channel
     if (!(M == 16 || M == 32 || M == 64) || nt % 64 != 0 || nt < 64 || nt > 1024 || G < 1) return false;
     // the quad form: whole channel quads, whole waves per pair, a lane of a 64-frame access inside one entry
     if (quad && (quad > 2 || t.C % (4 * quad) != 0 || bc || nt % (128 * quad) != 0 || M > 32)) return false;
@@ -94,7 +94,7 @@ inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size
 // Workgroups a CU holds: LDS-bound, and register-bound - a lane carries its runs' accumulators, the outputs of the first
 // channel and a tile of prefetched frames (about 250 VGPRs with 32-frame runs, 150 with 16, more than 256 with 64), so
 // at most 2 / 3 / 1 waves per SIMD; a budget below that would spill the prefetch to scratch (measured: 3x slower).
-inline int win_waves_per_simd_max(int M, bool split = false) { return split ? (M <= 32 ? 3 : 1) : (M <= 16 ? 3 : (M <= 32 ? 2 : 1)); }
+inline int win_waves_per_simd_max(int M, bool split = false) { return split ? (M <= 32 ? 3 : 2) : (M <= 16 ? 3 : (M <= 32 ? 2 : 1)); }
 
 inline int win_workgroups_per_cu(const WinGeom &g)
 {
@@ -519,7 +519,7 @@ inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool sm
                     c.win_per_cu = win_workgroups_per_cu(g);
                     // reads kept in flight: each holds 4 registers, and 32-frame runs already live at ~240 of the 256 a lane
                     // has at two waves per SIMD (measured: 3 to 10 reads ahead run the same, tools/win_try.py)
-                    c.la = spec_env("VND_SPEC_LA", M >= 32 ? 4 : 6);
+                    c.la = spec_env("VND_SPEC_LA", (split && M >= 64) ? 3 : (M >= 32 ? 4 : 6));      // (64-frame runs: 128 accumulator registers)
                     c.rr = 0; c.pp = 0; c.dd = 0;
                     // the store phase: interleaved frame pairs (one 16-byte read-back per store) unless that build spilled
                     // before - it holds both channels' outputs interleaved - then planar chunks in 8-byte halves
