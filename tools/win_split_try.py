@@ -29,7 +29,7 @@ def make_table(fir):
 
 
 def env_set(**env):
-    for k in ('VND_SPEC_NT', 'VND_SPEC_LA', 'VND_WIN_G', 'VND_WIN_SPLIT'):
+    for k in ('VND_SPEC_NT', 'VND_SPEC_LA', 'VND_WIN_G', 'VND_WIN_SPLIT', 'VND_WIN_SPLIT_LATE'):
         os.environ.pop(k, None)
     for k, v in env.items():
         os.environ[k] = str(v)
@@ -110,11 +110,10 @@ for name, (pool, n) in POOLS.items():
     env_set(VND_WIN_SPLIT=0)
     ye, yf = run(0), run(2)
     peak = float(ye.abs().max())
-    configs = [('plain', dict(VND_WIN_SPLIT=0)), ('split 32x256', dict(VND_WIN_SPLIT=2)),
-               ('split 64x256 la=3 g=4', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=256, VND_SPEC_LA=3, VND_WIN_G=4, variant=4 << 5)),
-               ('split 64x256 la=2 g=4', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=256, VND_SPEC_LA=2, VND_WIN_G=4, variant=4 << 5)),
-               ('split 64x256 la=3 g=8', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=256, VND_SPEC_LA=3, VND_WIN_G=8, variant=4 << 5)),
-               ('split 64x128 la=3 g=4', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=128, VND_SPEC_LA=3, VND_WIN_G=4, variant=4 << 5))]
+    V64 = 4 << 5
+    configs = [('plain', dict(VND_WIN_SPLIT=0)), ('default', {}),
+               ('split 64x256 forced', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=256, variant=V64)),
+               ('split 64x256 late=14 la=2', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=256, VND_WIN_SPLIT_LATE=14, VND_SPEC_LA=2, variant=V64))]
     if 'all' in sys.argv:
         configs += [('split 32x384', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=384)), ('split 32x256 la=3', dict(VND_WIN_SPLIT=2, VND_SPEC_LA=3)),
                     ('split 32x256 la=6', dict(VND_WIN_SPLIT=2, VND_SPEC_LA=6)), ('split 32x512', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=512))]

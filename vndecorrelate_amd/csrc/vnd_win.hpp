@@ -454,6 +454,10 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
                 g.nt, g.M, g.R, g.G, g.NB, g.DE, g.plane, c.la);
     spec_append(s, "#define VW_NT_STORES %d\n#define VW_EPI %d\n#define VW_BC %d\n#define VW_EXACT %d\n#define VW_C %d\n", c.nt_stores, c.epi, c.bc, c.exact, g.C);
     spec_append(s, "#define VW_Q %d\n#define VW_S %d\n", g.quad, g.split);
+    // split form: how many of a wave's M/4 refill accesses per tile are loaded late (at the start of the store phase that consumes
+    // them) instead of a tile ahead: 64-frame runs keep half of them out of the tap phase's registers
+    // (the fast mode's E / P accumulators are twice the exact mode's sums: three quarters late there)
+    spec_append(s, "#define VW_LATE %d\n", g.split ? std::min(std::max(spec_env("VND_WIN_SPLIT_LATE", g.M >= 64 ? (c.exact ? g.M / 8 : 3 * g.M / 16) : 0), 0), g.M / 4 - 1) : 0);
     spec_append(s, "#define VW_CU_PAIRS %d\n", spec_env("VND_WIN_QUAD_CU_PAIRS", 0) != 0 ? 1 : 0);
     spec_append(s, "#define VW_NT_STORE_AUX %d\n", spec_env("VND_SPEC_STORE_AUX", 2));
     // the transposition as interleaved frame pairs (one 16-byte read-back per store, planes an odd number of slots apart) or as
@@ -495,7 +499,8 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
 // geometry choice: the largest workgroup whose ring (tile + halo, mirror) still fits; small_tiles starts lower
 // (short streams: a ring is filled once per span)
 inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool small_tiles, bool bc, SpecConfig *out,
-                            const std::function<bool(const SpecConfig &)> &rejected = nullptr, int quad = 0, bool split = false)
+                            const std::function<bool(const SpecConfig &)> &rejected = nullptr, int quad = 0, bool split = false,
+                            bool exact = false)
 {
     // the geometry that keeps the most waves on a CU (the ring is LDS-bound: tile + halo per workgroup), the larger
     // workgroup on a tie (the halo is shared by more lanes); short streams (small_tiles: a ring is filled once per
@@ -519,7 +524,7 @@ inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool sm
                     c.win_per_cu = win_workgroups_per_cu(g);
                     // reads kept in flight: each holds 4 registers, and 32-frame runs already live at ~240 of the 256 a lane
                     // has at two waves per SIMD (measured: 3 to 10 reads ahead run the same, tools/win_try.py)
-                    c.la = spec_env("VND_SPEC_LA", (split && M >= 64) ? 3 : (M >= 32 ? 4 : 6));      // (64-frame runs: 128 accumulator registers)
+                    c.la = spec_env("VND_SPEC_LA", (split && M >= 64) ? (exact ? 3 : 2) : (M >= 32 ? 4 : 6));      // (64-frame runs: 64 / 128 accumulator registers)
                     c.rr = 0; c.pp = 0; c.dd = 0;
                     // the store phase: interleaved frame pairs (one 16-byte read-back per store) unless that build spilled
                     // before - it holds both channels' outputs interleaved - then planar chunks in 8-byte halves
