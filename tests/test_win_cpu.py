@@ -367,3 +367,32 @@ def test_split_form_source_keeps_three_waves_per_simd(native, golden, tmp_path, 
     assert ops.count('s_barrier') == 4                       # the prologue's and the three of a tile
     monkeypatch.delenv('VND_WIN_SPLIT')
     assert _macro(native.window_kernel_source(offs, idx, w, mode, M, nt), 'VW_S') == 0      # off by default
+
+
+@pytest.mark.parametrize('mode,late,la', [(0, 8, 3), (2, 12, 2)])
+def test_split_form_with_64_frame_runs_fits_two_waves_per_simd(native, golden, tmp_path, mode, late, la, monkeypatch):
+    """64-frame runs halve the LDS reads per FMA but need 64 (exact: sums) or 128 (fast: E and P) accumulator registers per
+    channel: only the split form - one channel per lane - holds them at two waves per SIMD, the fast mode with twelve of a
+    wave's sixteen refill accesses per tile loaded late (VW_LATE).  The dense 128-tap table, cross-compiled: no spill."""
+    offs, idx, w = _table(golden.fir('g48k_k128_u'))
+    M, nt = 64, 256
+    monkeypatch.setenv('VND_WIN_SPLIT', '2')
+    monkeypatch.setenv('VND_SPEC_LA', str(la))           # (what the launch plan picks for this form: 3 reads ahead exact, 2 fast)
+    src = native.window_kernel_source(offs, idx, w, mode, M, nt)
+    assert _macro(src, 'VW_S') == 1 and _macro(src, 'VW_M') == 64 and _macro(src, 'VW_LATE') == late and _macro(src, 'VW_LA') == la
+    assert _macro(src, 'VW_WAVES_PER_EU') == 2
+    assert 2 * 2 * (M // 4) * _macro(src, 'VW_PLANE') <= 160 * 1024           # two workgroups per CU
+    f = tmp_path / 'k.hip'
+    f.write_text(src)
+    out = tmp_path / 'k.s'
+    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '--cuda-device-only',
+                        '-include', 'hip/hip_runtime.h', '-S', str(f), '-o', str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = out.read_text()
+    assert re.search(r'ScratchSize: 0\b', asm), 'the 64-frame split form of the dense table must not spill'
+    # half the window reads of the 32-frame form for the same sums
+    monkeypatch.setenv('VND_WIN_SPLIT', '0')
+    monkeypatch.delenv('VND_SPEC_LA')
+    plain = native.window_kernel_source(offs, idx, w, mode, 32, 256)
+    reads64, reads32 = len(re.findall(r'= VW_RD\(', src)), len(re.findall(r'= VW_RD\(', plain))
+    assert reads64 < 1.1 * reads32            # ... per 64 frames instead of per 32

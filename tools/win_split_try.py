@@ -29,7 +29,7 @@ def make_table(fir):
 
 
 def env_set(**env):
-    for k in ('VND_SPEC_NT', 'VND_SPEC_LA', 'VND_WIN_G', 'VND_WIN_SPLIT', 'VND_WIN_SPLIT_LATE'):
+    for k in ('VND_SPEC_NT', 'VND_SPEC_LA', 'VND_WIN_G', 'VND_WIN_SPLIT', 'VND_WIN_SPLIT_LATE', 'VND_WIN_ALLOW_SPILL'):
         os.environ.pop(k, None)
     for k, v in env.items():
         os.environ[k] = str(v)
@@ -112,8 +112,10 @@ for name, (pool, n) in POOLS.items():
     peak = float(ye.abs().max())
     V64 = 4 << 5
     configs = [('plain', dict(VND_WIN_SPLIT=0)), ('default', {}),
-               ('split 64x256 forced', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=256, variant=V64)),
-               ('split 64x256 late=14 la=2', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=256, VND_WIN_SPLIT_LATE=14, VND_SPEC_LA=2, variant=V64))]
+               ('split 64x256 forced', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=256, variant=V64))]
+    if 'spill' in sys.argv:          # what a 64-frame fast build that spills a few registers would be worth (diagnosis)
+        configs += [('split 64 late=15 la=2 SPILLS', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=256, VND_WIN_SPLIT_LATE=15, VND_SPEC_LA=2, VND_WIN_ALLOW_SPILL=1, variant=V64)),
+                    ('split 64 late=12 la=2 SPILLS', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=256, VND_WIN_SPLIT_LATE=12, VND_SPEC_LA=2, VND_WIN_ALLOW_SPILL=1, variant=V64))]
     if 'all' in sys.argv:
         configs += [('split 32x384', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=384)), ('split 32x256 la=3', dict(VND_WIN_SPLIT=2, VND_SPEC_LA=3)),
                     ('split 32x256 la=6', dict(VND_WIN_SPLIT=2, VND_SPEC_LA=6)), ('split 32x512', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=512))]
