@@ -321,10 +321,10 @@ def test_window_form_with_the_waves_split_over_the_channels(env, golden, monkeyp
     ctx.set_variant(-1)
     monkeypatch.delenv('VND_WIN_SPLIT')
     monkeypatch.delenv('VND_SPEC_NT')
-    # by default: the exact mode of a function-path table with 64-frame runs (two waves per SIMD), the fast mode only for
-    # dense tables (96 taps per channel and more)
+    # by default: 64-frame runs in this form (two waves per SIMD) - the exact mode of a function-path table, and the fast mode
+    # wherever that build does not spill (a table whose build does spill keeps the plain 32-frame form)
     fast = table.describe(24, 2880000, 2, d.MODE_FAST)
-    assert ('waves=split-by-channel' in fast and 'frames_per_lane=64 ' in fast) == ('k128' in gname), fast
+    assert ('waves=split-by-channel' in fast and 'frames_per_lane=64 ' in fast) or ('frames_per_lane=32 ' in fast and 'split' not in fast), fast
     text = table.describe(24, 2880000, 2, d.MODE_EXACT)
     assert 'waves=split-by-channel' in text and 'frames_per_lane=64 ' in text and 'threads=256' in text, text
     table.close()
@@ -348,8 +348,12 @@ def test_stereo_tables_take_the_window_form_by_default_in_both_modes(env, golden
         assert ('waves=split-by-channel' in exact and 'frames_per_lane=64 ' in exact) == (table is not cls), exact
         fast = table.describe(*shape, d.MODE_FAST)
         assert fast.startswith('conv_spec_window'), fast
-        # (fast mode: the plain form with 32-frame runs, except for dense tables - the split form with 64)
-        assert ('frames_per_lane=64 ' in fast and 'waves=split-by-channel' in fast) if table is dense else ('frames_per_lane=32 ' in fast and 'split' not in fast), fast
+        # (fast mode: 64-frame runs in the split form - the function-path tables build without spilling; a table whose build
+        #  spills keeps the plain form with 32-frame runs)
+        if table is not cls:
+            assert 'frames_per_lane=64 ' in fast and 'waves=split-by-channel' in fast, fast
+        else:
+            assert ('frames_per_lane=64 ' in fast and 'waves=split-by-channel' in fast) or ('frames_per_lane=32 ' in fast and 'split' not in fast), fast
     for mode in (d.MODE_FAST, d.MODE_EXACT):
         text = sparse.describe(128, 480000, 1, mode)
         assert text.startswith('conv_spec') and 'window' not in text, text

@@ -113,9 +113,8 @@ for name, (pool, n) in POOLS.items():
     V64 = 4 << 5
     configs = [('plain', dict(VND_WIN_SPLIT=0)), ('default', {}),
                ('split 64x256 forced', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=256, variant=V64))]
-    if 'spill' in sys.argv:          # what a 64-frame fast build that spills a few registers would be worth (diagnosis)
-        configs += [('split 64 late=15 la=2 SPILLS', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=256, VND_WIN_SPLIT_LATE=15, VND_SPEC_LA=2, VND_WIN_ALLOW_SPILL=1, variant=V64)),
-                    ('split 64 late=12 la=2 SPILLS', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=256, VND_WIN_SPLIT_LATE=12, VND_SPEC_LA=2, VND_WIN_ALLOW_SPILL=1, variant=V64))]
+    if 'late' in sys.argv:           # the fast mode's 64-frame form with (almost) the whole refill loaded late
+        configs += [('split 64 late=15 la=2', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=256, VND_WIN_SPLIT_LATE=15, VND_SPEC_LA=2, variant=V64))]
     if 'all' in sys.argv:
         configs += [('split 32x384', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=384)), ('split 32x256 la=3', dict(VND_WIN_SPLIT=2, VND_SPEC_LA=3)),
                     ('split 32x256 la=6', dict(VND_WIN_SPLIT=2, VND_SPEC_LA=6)), ('split 32x512', dict(VND_WIN_SPLIT=2, VND_SPEC_NT=512))]

@@ -490,13 +490,13 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     //    frames (rejected builds fall back to the plain form) (tools/win_split_try.py, profiles/r03_split_waves.txt)
     const int split_env = spec_env("VND_WIN_SPLIT", 1);
     const bool split_scope = C == 2 && Cx == 2 && !pointwise;
-    //    In the FAST mode the 64-frame split form needs three quarters of its refill loaded late (VW_LATE: at the start of the
-    //    store phase, not a tile ahead - 128 accumulator registers) and builds without spilling for DENSE tables only (cfg3
-    //    +4.6 %, 0.457 -> 0.437 ms; cfg2's 30 log-spaced taps spill 128-216 bytes whatever the split): taken from 96 taps per channel
+    //    In the FAST mode (E and P: 128 accumulator registers) the 64-frame split form needs its refill loaded late (VW_LATE: 15
+    //    of a wave's 16 accesses per tile at the start of the store phase that consumes them, not a tile ahead) and the per-access
+    //    constants kept out of the tile loop's registers: cfg3 +3-4.5 % (0.457 -> 0.437 ms), cfg2 +3.8 % (0.195 -> 0.188 ms,
+    //    tools/split64_fast_probe.py); a table whose build spills all the same falls back to the plain 32-frame form
     const bool exact_now = mode == VND_MODE_EXACT;
-    const bool dense = (int64_t)t->spec_table.idx.size() >= (int64_t)96 * C;
     if (!picked && win_mode_ok && split_scope && split_env == 1 && vw == 0 &&
-        ((exact_now && !t->spec_table.has_seg) || (mode == VND_MODE_FAST && dense && spec_env("VND_WIN_SPLIT_FAST", 1) != 0)))
+        ((exact_now && !t->spec_table.has_seg) || (mode == VND_MODE_FAST && spec_env("VND_WIN_SPLIT_FAST", 1) != 0)))
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, 64, attempt == 1, false, &p.cfg, rejected, 0, true, exact_now);
     if (!picked && win_mode_ok && split_scope && split_env == 2)
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, false, &p.cfg, rejected, 0, true, exact_now);

@@ -456,8 +456,9 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
     spec_append(s, "#define VW_Q %d\n#define VW_S %d\n", g.quad, g.split);
     // split form: how many of a wave's M/4 refill accesses per tile are loaded late (at the start of the store phase that consumes
     // them) instead of a tile ahead: 64-frame runs keep half of them out of the tap phase's registers
-    // (the fast mode's E / P accumulators are twice the exact mode's sums: three quarters late there)
-    spec_append(s, "#define VW_LATE %d\n", g.split ? std::min(std::max(spec_env("VND_WIN_SPLIT_LATE", g.M >= 64 ? (c.exact ? g.M / 8 : 3 * g.M / 16) : 0), 0), g.M / 4 - 1) : 0);
+    // (the fast mode's E / P accumulators are twice the exact mode's sums: all but one late there - hipRTC's build of cfg2's table
+    //  spills 20-64 bytes with 12-14 of the 16 late and none with 15; 4 to 15 late run the same)
+    spec_append(s, "#define VW_LATE %d\n", g.split ? std::min(std::max(spec_env("VND_WIN_SPLIT_LATE", g.M >= 64 ? (c.exact ? g.M / 8 : g.M / 4 - 1) : 0), 0), g.M / 4 - 1) : 0);
     spec_append(s, "#define VW_CU_PAIRS %d\n", spec_env("VND_WIN_QUAD_CU_PAIRS", 0) != 0 ? 1 : 0);
     spec_append(s, "#define VW_NT_STORE_AUX %d\n", spec_env("VND_SPEC_STORE_AUX", 2));
     // the transposition as interleaved frame pairs (one 16-byte read-back per store, planes an odd number of slots apart) or as
