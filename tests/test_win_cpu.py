@@ -369,11 +369,12 @@ def test_split_form_source_keeps_three_waves_per_simd(native, golden, tmp_path, 
     assert _macro(native.window_kernel_source(offs, idx, w, mode, M, nt), 'VW_S') == 0      # off by default
 
 
-@pytest.mark.parametrize('mode,late,la', [(0, 8, 3), (2, 12, 2)])
+@pytest.mark.parametrize('mode,late,la', [(0, 8, 3), (2, 15, 2)])
 def test_split_form_with_64_frame_runs_fits_two_waves_per_simd(native, golden, tmp_path, mode, late, la, monkeypatch):
     """64-frame runs halve the LDS reads per FMA but need 64 (exact: sums) or 128 (fast: E and P) accumulator registers per
-    channel: only the split form - one channel per lane - holds them at two waves per SIMD, the fast mode with twelve of a
-    wave's sixteen refill accesses per tile loaded late (VW_LATE).  The dense 128-tap table, cross-compiled: no spill."""
+    channel: only the split form - one channel per lane - holds them at two waves per SIMD, the fast mode with fifteen of a
+    wave's sixteen refill accesses per tile loaded late (VW_LATE) and the per-access constants opaque per tile.  The dense
+    128-tap table and (fast mode) the headline's 30-tap table, cross-compiled: no spill."""
     offs, idx, w = _table(golden.fir('g48k_k128_u'))
     M, nt = 64, 256
     monkeypatch.setenv('VND_WIN_SPLIT', '2')
@@ -390,6 +391,7 @@ def test_split_form_with_64_frame_runs_fits_two_waves_per_simd(native, golden, t
     assert r.returncode == 0, r.stderr[-2000:]
     asm = out.read_text()
     assert re.search(r'ScratchSize: 0\b', asm), 'the 64-frame split form of the dense table must not spill'
+    assert int(re.search(r'; NumVgprs: (\d+)', asm).group(1)) <= 240            # (256 before the per-access constants left the loop)
     # half the window reads of the 32-frame form for the same sums
     monkeypatch.setenv('VND_WIN_SPLIT', '0')
     monkeypatch.delenv('VND_SPEC_LA')
