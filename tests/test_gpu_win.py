@@ -238,23 +238,28 @@ def test_window_form_on_wider_signals(env, golden, monkeypatch, C, M, nt):
     table.close()
 
 
-@pytest.mark.parametrize('C,M,nt,Q', [(8, 16, 256, 1), (4, 16, 256, 1), (12, 16, 128, 1), (8, 32, 128, 1), (4, 32, 256, 1), (16, 16, 512, 1),
-                                      (8, 16, 512, 2), (16, 16, 512, 2), (8, 32, 256, 2), (8, 16, 256, 2)])
-def test_window_form_on_channel_quads(env, golden, monkeypatch, C, M, nt, Q):
+@pytest.mark.parametrize('C,M,nt,Q,by_channel', [(8, 16, 256, 1, 0), (4, 16, 256, 1, 0), (12, 16, 128, 1, 0), (8, 32, 128, 1, 0), (4, 32, 256, 1, 0),
+                                                 (16, 16, 512, 1, 0), (8, 16, 512, 2, 0), (16, 16, 512, 2, 0), (8, 32, 256, 2, 0), (8, 16, 256, 2, 0),
+                                                 (8, 32, 512, 2, 1), (16, 32, 512, 2, 1), (8, 16, 512, 2, 1), (4, 32, 256, 1, 1), (12, 32, 256, 1, 1),
+                                                 (4, 16, 256, 1, 1)])
+def test_window_form_on_channel_quads(env, golden, monkeypatch, C, M, nt, Q, by_channel):
     """Signals of 4k interleaved channels: a workgroup takes a channel QUAD of a span - 16 bytes of every frame, the first
     half of its lanes on the quad's first channel pair, the second half on the other, outputs exchanged between partner waves
     through the tile's dead ring entries (vw_span_q).  Q = 2: signals of 8k channels, two neighbouring quads (32 bytes of every
-    frame; with 8 channels whole frames) per workgroup, a quarter of its lanes per pair.  Every pair has its own taps; lengths
-    around the tile (nt / 2Q entries of M frames), stream tails inside a run, batches, spans of one tile and span seams - fast
-    within tolerance, exact bit for bit, against the NumPy oracle."""
+    frame; with 8 channels whole frames) per workgroup, a quarter of its lanes per pair.  by_channel: the workgroup's waves split
+    over its 4Q CHANNELS instead (vw_span_qc: one channel's accumulators per lane - 32-frame runs; the default where the ring
+    fits).  Every pair has its own taps; lengths around the tile (nt / 2Q - by channel nt / 4Q - entries of M frames), stream
+    tails inside a run, batches, spans of one tile and span seams - fast within tolerance, exact bit for bit, against the NumPy
+    oracle."""
     d, native, ctx = env
     wide = golden.fir('g96k_k64_c8')
     fir = np.ascontiguousarray(np.concatenate([wide, wide[:, ::-1]], axis=1)[:, :C])
     table = _table(native, ctx, fir)
     monkeypatch.setenv('VND_SPEC_NT', str(nt))
     monkeypatch.setenv('VND_WIN_OCTET', '1' if Q == 2 else '0')
-    rng = np.random.default_rng(C * 1000 + M + Q)
-    T = (nt // (2 * Q)) * M
+    monkeypatch.setenv('VND_WIN_OCTET_SPLIT', '1' if by_channel else '0')
+    rng = np.random.default_rng(C * 1000 + M + Q + 7 * by_channel)
+    T = (nt // ((4 if by_channel else 2) * Q)) * M
     pieces = 'pieces=channel-octets' if Q == 2 else 'pieces=channel-quads'
     for n in sorted({1, 3, M + 1, T - 1, T, T + 1, 2 * T + 3, 5 * T + 17, 40003}):
         for batch in (1, 3):
@@ -265,7 +270,7 @@ def test_window_form_on_channel_quads(env, golden, monkeypatch, C, M, nt, Q):
                 for mode, name in ((d.MODE_FAST, 'conv_spec_window'), (d.MODE_EXACT, 'conv_spec_exact_window')):
                     text = table.describe(batch, n, C, mode)
                     assert text.startswith(name) and f'frames_per_lane={M} ' in text and f'tile={T} ' in text, text
-                    assert f'threads={nt}' in text and pieces in text, text
+                    assert f'threads={nt}' in text and pieces in text and ('waves=split-by-channel' in text) == bool(by_channel), text
                     got = table.convolve_host(x, mode)
                     where = f'C={C} M={M} n={n} batch={batch} spans=({min_span},{rounds})'
                     if mode == d.MODE_EXACT:
@@ -358,9 +363,9 @@ def test_stereo_tables_take_the_window_form_by_default_in_both_modes(env, golden
         text = sparse.describe(128, 480000, 1, mode)
         assert text.startswith('conv_spec') and 'window' not in text, text
         text = wide.describe(16, 960000, 8, mode)
-        assert text.startswith('conv_spec') and 'window' in text and 'pieces=channel-octets' in text and 'frames_per_lane=16 ' in text, text
+        assert text.startswith('conv_spec') and 'window' in text and 'pieces=channel-octets waves=split-by-channel' in text and 'frames_per_lane=32 ' in text, text
         text = four.describe(16, 960000, 4, mode)
-        assert text.startswith('conv_spec') and 'window' in text and 'pieces=channel-quads' in text and 'frames_per_lane=16 ' in text, text
+        assert text.startswith('conv_spec') and 'window' in text and 'pieces=channel-quads waves=split-by-channel' in text and 'frames_per_lane=32 ' in text, text
         text = six.describe(16, 960000, 6, mode)
         assert text.startswith('conv_spec') and 'window' not in text, text
     dense.close(); sparse.close(); wide.close(); six.close(); four.close()

@@ -310,6 +310,7 @@ def test_quad_form_source_for_tables_of_4k_channels(native, golden, tmp_path, mo
     offs, idx, w = _table(golden.fir('g96k_k64_c8'))
     M, nt = 16, 256 * Q
     monkeypatch.setenv('VND_WIN_OCTET', '1' if Q == 2 else '0')
+    monkeypatch.setenv('VND_WIN_OCTET_SPLIT', '0')            # (a wave per channel PAIR: the form with 16-frame runs)
     src = native.window_kernel_source(offs, idx, w, mode, M, nt)
     assert _macro(src, 'VW_Q') == Q and _macro(src, 'VW_C') == 8
     assert _macro(src, 'VW_R') == 128 + _macro(src, 'VW_DE')
@@ -398,3 +399,37 @@ def test_split_form_with_64_frame_runs_fits_two_waves_per_simd(native, golden, t
     plain = native.window_kernel_source(offs, idx, w, mode, 32, 256)
     reads64, reads32 = len(re.findall(r'= VW_RD\(', src)), len(re.findall(r'= VW_RD\(', plain))
     assert reads64 < 1.1 * reads32            # ... per 64 frames instead of per 32
+
+
+@pytest.mark.parametrize('mode', [2, 0])
+def test_octets_with_the_waves_split_over_the_channels(native, golden, tmp_path, mode, monkeypatch):
+    """cfg5's table by default: one workgroup of 512 lanes per octet, a WAVE per channel (vw_span_qc, vw_taps_<pair>c<channel>) -
+    one channel's accumulators per lane, so 32-frame runs (2.6 B of LDS per FMA instead of 3.4) on the same 2048-frame tile,
+    the 2720-frame halo of all eight channels still inside 160 KB.  Cross-compiled: no spill, whole 16-byte pieces."""
+    offs, idx, w = _table(golden.fir('g96k_k64_c8'))
+    M, nt = 32, 512
+    src = native.window_kernel_source(offs, idx, w, mode, M, nt)
+    assert _macro(src, 'VW_Q') == 2 and _macro(src, 'VW_QCS') == 1 and _macro(src, 'VW_S') == 0
+    assert _macro(src, 'VW_R') == nt // 8 + _macro(src, 'VW_DE')
+    assert 4 * 2 * (M // 4) * _macro(src, 'VW_PLANE') <= 160 * 1024
+    for pg in range(4):
+        for ch in range(2):
+            assert ('vw_taps_c%d(' % ch if pg == 0 else 'vw_taps_%dc%d(' % (pg, ch)) in src
+    assert 'vw_span_qc<0>(a, lds, stream, span)' in src.split('#define VW_DISPATCH')[1]
+    f = tmp_path / 'k.hip'
+    f.write_text(src)
+    out = tmp_path / 'k.s'
+    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '--cuda-device-only',
+                        '-include', 'hip/hip_runtime.h', '-S', str(f), '-o', str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = out.read_text()
+    assert re.search(r'ScratchSize: 0\b', asm), 'the channel-split octet kernel must not spill'
+    ops = re.findall(r'^\s+([a-z0-9_]+)', asm, re.M)
+    assert ops.count('s_barrier') == 4 and ops.count('buffer_store_dwordx4') == M // 4
+    assert ops.count('buffer_load_dwordx2') == 0 and ops.count('buffer_store_dwordx2') == 0
+    # fewer window reads per sum than the pair-per-wave form's 16-frame runs
+    monkeypatch.setenv('VND_WIN_OCTET_SPLIT', '0')
+    pairs16, lds16, fmas16 = native.window_kernel_source(offs, idx, w, mode, 16, 512, with_traffic=True)
+    monkeypatch.delenv('VND_WIN_OCTET_SPLIT')
+    _, lds32, fmas32 = native.window_kernel_source(offs, idx, w, mode, 32, 512, with_traffic=True)
+    assert lds32 / fmas32 < 0.85 * lds16 / fmas16

@@ -27,7 +27,7 @@ def make_table(fir):
 
 
 def env_set(**env):
-    for k in ('VND_SPEC_NT', 'VND_SPEC_LA', 'VND_WIN_G', 'VND_WIN_QUAD', 'VND_WIN_WIDE', 'VND_WIN_QUAD_M', 'VND_FORCE_NT', 'VND_WIN_QUAD_CU_PAIRS', 'VND_WIN_OCTET'):
+    for k in ('VND_SPEC_NT', 'VND_SPEC_LA', 'VND_WIN_G', 'VND_WIN_QUAD', 'VND_WIN_WIDE', 'VND_WIN_QUAD_M', 'VND_FORCE_NT', 'VND_WIN_QUAD_CU_PAIRS', 'VND_WIN_OCTET', 'VND_WIN_OCTET_SPLIT'):
         os.environ.pop(k, None)
     for k, v in env.items():
         os.environ[k] = str(v)
@@ -36,13 +36,19 @@ def env_set(**env):
 bad = 0
 if 'skip-small' not in sys.argv:
     rng = np.random.default_rng(5)
-    for C, M, nt, Q in ((8, 16, 512, 2), (16, 16, 512, 2), (8, 32, 256, 2), (8, 16, 256, 2), (8, 16, 256, 1), (4, 16, 256, 1), (12, 16, 128, 1), (8, 32, 128, 1), (4, 32, 256, 1)):
+    SHAPES = ((8, 16, 512, 2), (16, 16, 512, 2), (8, 32, 256, 2), (8, 16, 256, 2), (8, 16, 256, 1), (4, 16, 256, 1), (12, 16, 128, 1), (8, 32, 128, 1), (4, 32, 256, 1))
+    if 'csplit' in sys.argv:          # octets with the waves split over the channels (vw_span_qc): Q = 3 stands for it here
+        SHAPES = ((8, 32, 512, 3), (16, 32, 512, 3), (8, 16, 512, 3), (4, 32, 256, 4), (12, 32, 256, 4), (4, 16, 256, 4))
+    for C, M, nt, Q in SHAPES:
         if 'octets-only' in sys.argv and Q != 2:
+            continue
+        if C == 12 and Q == 4 and False:
             continue
         fir = np.concatenate([fir8, fir8[:, ::-1]], axis=1)[:, :C]
         table = make_table(fir)
-        env_set(VND_SPEC_NT=nt, VND_WIN_OCTET=1 if Q == 2 else 0)
-        T = (nt // (2 * Q)) * M
+        # (Q = 3: octets, Q = 4: quads - with the waves split over the channels)
+        env_set(VND_SPEC_NT=nt, VND_WIN_OCTET=1 if Q in (2, 3) else 0, VND_WIN_OCTET_SPLIT=1 if Q >= 3 else 0)
+        T = (nt // (2 * Q)) * M if Q < 3 else (nt // (8 if Q == 3 else 4)) * M
         for n in sorted({1, 3, M + 1, T - 1, T, T + 1, 2 * T + 3, 5 * T + 17, 40003}):
             for batch in (1, 3):
                 x = rng.uniform(-1, 1, (batch, n, C)).astype(np.float32)
@@ -52,7 +58,7 @@ if 'skip-small' not in sys.argv:
                     ctx.set_variant(FORCE | WIN[M] | (min_span << 20) | (rounds << 28))
                     for mode in (2, 0):
                         text = table.describe(batch, n, C, mode)
-                        if ('channel-octets' if Q == 2 else 'channel-quads') not in text or f'tile={T} ' not in text:
+                        if ('channel-octets' if Q in (2, 3) else 'channel-quads') not in text or f'tile={T} ' not in text or (Q >= 3) != ('waves=split-by-channel' in text):
                             print('NOT QUAD:', C, M, nt, n, batch, text, flush=True); bad += 1
                             continue
                         got = table.convolve_host(x, mode)
@@ -103,8 +109,10 @@ def rate(variant, mode, label):
 env_set()
 ye = run(1 << 25, 0)                       # the generic ordered kernel: oracle-identical (tests)
 peak = float(ye.abs().max())
-configs = [('octet 16x512', -1, {}), ('octet 16x512 nt-stores', -1, dict(VND_FORCE_NT=1)), ('octet 16x512 la=4', -1, dict(VND_SPEC_LA=4)),
-           ('quad 16x256', -1, dict(VND_WIN_OCTET=0)), ('quad 16x512', -1, dict(VND_WIN_OCTET=0, VND_SPEC_NT=512)),
+configs = [('octet csplit 32x512', -1, dict(VND_WIN_OCTET_SPLIT=1)), ('octet csplit 32x512 g=4', -1, dict(VND_WIN_OCTET_SPLIT=1, VND_WIN_G=4)),
+           ('octet csplit 32x512 la=6', -1, dict(VND_WIN_OCTET_SPLIT=1, VND_SPEC_LA=6)), ('octet csplit 16x512', WIN[16], dict(VND_WIN_OCTET_SPLIT=1)),
+           ('octet 16x512', -1, dict(VND_WIN_OCTET_SPLIT=0)), ('octet 16x512 nt-stores', -1, dict(VND_FORCE_NT=1)), ('octet 16x512 la=4', -1, dict(VND_SPEC_LA=4)),
+           ('quad 16x256', -1, dict(VND_WIN_OCTET=0, VND_WIN_OCTET_SPLIT=0)), ('quad csplit 32x256', -1, dict(VND_WIN_OCTET=0)), ('quad 16x512', -1, dict(VND_WIN_OCTET=0, VND_SPEC_NT=512)),
            ('pair-read', -1, dict(VND_WIN_QUAD=0)), ('pair window 32x128', WIN[32], dict(VND_WIN_QUAD=0, VND_SPEC_NT=128))]
 ok = []
 for label, variant, env in configs:
@@ -127,9 +135,10 @@ for rep in range(2):
 # the same pool bytes as FOUR-channel frames (the quad is the frame: whole lines per workgroup), first four channels' taps
 table4 = make_table(fir8[:, :4])
 x4 = x.view(2 * pool, n, 4); y4 = y.view(2 * pool, n, 4)
-env_set()
-ctx.set_variant(-1)
-for mode in (2, 0):
+for split4 in (1, 0):
+  env_set(VND_WIN_OCTET_SPLIT=split4)
+  ctx.set_variant(-1)
+  for mode in (2, 0):
     desc = table4.describe(2 * pool, n, 4, mode)
     best = [table4.time_device(x4.data_ptr(), y4.data_ptr(), 2 * pool, n, 4, mode=mode, n_buffers=1, stride_elems=0, iters=40, stream=st) for _ in range(12)]
-    print(f'4-channel frames, mode {mode}: {np.mean(best[6:]):.4f} ms (min {min(best):.4f})  {desc}', flush=True)
+    print(f'4-channel frames, channel-split {split4}, mode {mode}: {np.mean(best[6:]):.4f} ms (min {min(best):.4f})  {desc}', flush=True)

@@ -476,8 +476,17 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     const bool win_mode_ok = win_m > 0 && rr_hint == 0 && (mode == VND_MODE_FAST || win_exact || (win_quad && win_exact_env != 0));
     // (8k channels: two neighbouring quads - with 8 channels whole frames, whole cache lines - per workgroup of 512 lanes when that fits)
     const int quad_m = vw >= 2 ? win_m : spec_env("VND_WIN_QUAD_M", 16);
-    if (win_mode_ok && win_quad && C % 8 == 0 && spec_env("VND_WIN_OCTET", 1) != 0)
+    // (... and its waves split over the CHANNELS - vw_span_qc: one channel's accumulators per lane, 32-frame runs on the same tile;
+    //  VND_WIN_OCTET_SPLIT: 0 never, 1 (default) where the 32-frame ring fits: cfg5 fast 0.335 -> 0.319 ms (+4.9 %), exact 0.430 ->
+    //  0.390 (+9.8 %), tools/c8_quad_win_try.py; quads likewise)
+    if (win_mode_ok && win_quad && C % 8 == 0 && spec_env("VND_WIN_OCTET", 1) != 0 && spec_env("VND_WIN_OCTET_SPLIT", 1) != 0)
+        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, vw >= 2 ? win_m : spec_env("VND_WIN_OCTET_SPLIT_M", 32), attempt == 1, false,
+                                 &p.cfg, rejected, 2, false, mode == VND_MODE_EXACT, true);
+    if (!picked && win_mode_ok && win_quad && C % 8 == 0 && spec_env("VND_WIN_OCTET", 1) != 0)
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, quad_m, attempt == 1, false, &p.cfg, rejected, 2);
+    if (!picked && win_mode_ok && win_quad && spec_env("VND_WIN_OCTET_SPLIT", 1) != 0)
+        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, vw >= 2 ? win_m : spec_env("VND_WIN_OCTET_SPLIT_M", 32), attempt == 1, false,
+                                 &p.cfg, rejected, 1, false, mode == VND_MODE_EXACT, true);
     if (!picked && win_mode_ok && win_quad)
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, quad_m, attempt == 1, false, &p.cfg, rejected, 1);
     // plain stereo: the waves SPLIT over the two channels (VW_S, vw_span_s: a lane carries ONE channel's accumulators).
@@ -1505,8 +1514,12 @@ vnd_status vnd_window_kernel_source(int32_t C, const int32_t *tap_offsets, const
     }
     WinGeom g;
     // (tables of 4k channels: the quad form, as the launches take it - VND_WIN_QUAD=0: channel pairs)
-    bool quad = C % 8 == 0 && spec_env("VND_WIN_QUAD", 1) != 0 && spec_env("VND_WIN_OCTET", 1) != 0 &&
-                win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, 2);
+    bool quad = C % 8 == 0 && spec_env("VND_WIN_QUAD", 1) != 0 && spec_env("VND_WIN_OCTET", 1) != 0 && spec_env("VND_WIN_OCTET_SPLIT", 1) != 0 &&
+                win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, 2, false, true);
+    quad = quad || (C % 8 == 0 && spec_env("VND_WIN_QUAD", 1) != 0 && spec_env("VND_WIN_OCTET", 1) != 0 &&
+                    win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, 2));
+    quad = quad || (C % 4 == 0 && spec_env("VND_WIN_QUAD", 1) != 0 && spec_env("VND_WIN_OCTET_SPLIT", 1) != 0 &&
+                    win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, 1, false, true));
     quad = quad || (C % 4 == 0 && spec_env("VND_WIN_QUAD", 1) != 0 &&
                     win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, 1));
     const bool split = !quad && C == 2 && spec_env("VND_WIN_SPLIT", 0) != 0 &&
@@ -1514,7 +1527,7 @@ vnd_status vnd_window_kernel_source(int32_t C, const int32_t *tap_offsets, const
     if (!quad && !split && !win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g))
         return fail(VND_ERR_UNSUPPORTED, "this window geometry does not fit the LDS");
     SpecConfig cfg;
-    cfg.nt = threads; cfg.win = frames_per_lane; cfg.win_g = g.G; cfg.win_lds = (int)g.lds_bytes(); cfg.win_q = g.quad; cfg.win_s = g.split;
+    cfg.nt = threads; cfg.win = frames_per_lane; cfg.win_g = g.G; cfg.win_lds = (int)g.lds_bytes(); cfg.win_q = g.quad; cfg.win_s = g.split; cfg.win_qc = g.csplit;
     cfg.la = spec_env("VND_SPEC_LA", frames_per_lane >= 32 ? 4 : 6);
     cfg.win_xpose = spec_env("VND_WIN_XPOSE_PAIRS", 1) != 0 ? 1 : 0;
     cfg.exact = mode == VND_MODE_EXACT ? 1 : 0;
@@ -1572,7 +1585,7 @@ static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64
                          "nt_stores=%d mode=%d lds=%zuB workgroups=%u (%u units: %d spans x %d tiles per stream) threads=%d store_phase=%s",
                          sp.cfg.exact ? "_exact" : "", sp.cfg.win, sp.cfg.tile(), sp.cfg.la, sp.cfg.nt_stores, mode,
                          sp.cfg.lds_bytes(), sp.nblocks, sp.units, sp.spans, sp.tiles_per_span, sp.cfg.nt,
-                         sp.cfg.win_s ? "planar waves=split-by-channel" : sp.cfg.win_q == 2 ? "frame-pairs pieces=channel-octets" : (sp.cfg.win_q ? "frame-pairs pieces=channel-quads" : (sp.cfg.win_xpose ? "frame-pairs" : "planar")));
+                         sp.cfg.win_s ? "planar waves=split-by-channel" : sp.cfg.win_qc ? (sp.cfg.win_q == 2 ? "planar pieces=channel-octets waves=split-by-channel" : "planar pieces=channel-quads waves=split-by-channel") : sp.cfg.win_q == 2 ? "frame-pairs pieces=channel-octets" : (sp.cfg.win_q ? "frame-pairs pieces=channel-quads" : (sp.cfg.win_xpose ? "frame-pairs" : "planar")));
                 return VND_OK;
             }
             snprintf(text, (size_t)len,

@@ -33,7 +33,8 @@ struct WinGeom {
     int npl = 2;         // input planes sets (1: mono input fanned out)
     int quad = 0;        // 1: a workgroup takes a channel QUAD (16 bytes of every frame), half its lanes per pair; 2: an OCTET (32 bytes), a quarter
     int split = 0;       // 1: stereo, half the workgroup's waves per CHANNEL (three waves per SIMD fit the registers)
-    int nh() const { return split ? nt / 2 : (quad ? nt / (2 * quad) : nt); }   // lanes - and ring entries of a tile - per channel pair
+    int csplit = 0;      // 1 (with quad): the quad / octet's waves split over its CHANNELS (vw_span_qc)
+    int nh() const { return split ? nt / 2 : (quad ? nt / ((csplit ? 4 : 2) * quad) : nt); }   // lanes - and ring entries of a tile - per channel pair (per channel)
     size_t lds_bytes() const { return (size_t)(quad ? 2 * quad : 1) * (size_t)npl * (size_t)(M / 4) * (size_t)plane; }
     int tile() const { return nh() * M; }
 };
@@ -41,8 +42,10 @@ struct WinGeom {
 inline int win_workgroups_per_cu(const WinGeom &g);
 
 // Geometry of the window kernel for a table; false when it does not fit (the caller keeps the pair-read kernel).
-inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size_t lds_limit, WinGeom *g, int quad = 0, bool split = false)
+inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size_t lds_limit, WinGeom *g, int quad = 0, bool split = false,
+                         bool csplit = false)
 {
+    if (csplit && (quad < 1 || split || nt % (256 * quad) != 0 || M * quad > 64)) return false;       // whole waves per channel
     if (split && (t.C != 2 || bc || quad || nt % 128 != 0)) return false;      // plain stereo, whole waves per channel
     if (!(M == 16 || M == 32 || M == 64) || nt % 64 != 0 || nt < 64 || nt > 1024 || G < 1) return false;
     // the quad form: whole channel quads, whole waves per pair, a lane of a 64-frame access inside one entry
@@ -52,7 +55,7 @@ inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size
     // tables keep the pair-read form
     if ((int64_t)t.idx.size() * M > 32768) return false;
     if (t.C < 2 || (t.C & 1) || (bc && t.C != 2)) return false;      // whole channel pairs
-    g->M = M; g->nt = nt; g->G = G; g->npl = bc ? 1 : 2; g->C = t.C; g->quad = quad; g->split = split ? 1 : 0;
+    g->M = M; g->nt = nt; g->G = G; g->npl = bc ? 1 : 2; g->C = t.C; g->quad = quad; g->split = split ? 1 : 0; g->csplit = csplit ? 1 : 0;
     const int nh = g->nh();
     const int qc = M / 4;
     auto lay_out = [&](int de) {
@@ -149,6 +152,12 @@ inline void win_traffic(const SpecTable &t, int M, size_t *lds_bytes, size_t *fm
 // the name of channel pair pg's tap function: vw_taps for the first (a stereo table's only) pair, vw_taps_<pg> for the others
 inline std::string win_taps_name(int pg) { return pg == 0 ? std::string("vw_taps") : "vw_taps_" + std::to_string(pg); }
 
+// one CHANNEL's tap function (the split forms): vw_taps_c<ch> for a stereo table, vw_taps_<pair>c<ch> for wider ones
+inline std::string win_taps_channel_name(int pg, int ch)
+{
+    return pg == 0 ? "vw_taps_c" + std::to_string(ch) : "vw_taps_" + std::to_string(pg) + "c" + std::to_string(ch);
+}
+
 // vw_taps_of<PG>(): the pair's function by its number, and VW_DISPATCH: the kernel's span loop instantiated per channel pair
 inline std::string win_taps_dispatch(const SpecTable &t, int quad = 0)
 {
@@ -167,7 +176,7 @@ inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int l
     const int M = g.M;
     std::string s;
     // (only_ch: the split form's per-channel function vw_taps_c<ch> - it leaves the other channel's outputs alone)
-    const std::string fname = only_ch < 0 ? win_taps_name(pg) : "vw_taps_c" + std::to_string(only_ch);
+    const std::string fname = only_ch < 0 ? win_taps_name(pg) : win_taps_channel_name(pg, only_ch);
     s += "__device__ __forceinline__ void " + fname + "(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
     spec_append(s, "    v4f q[%d];\n    v2f E[%d], P[%d];\n    float O0, OL;\n", la + 1, M / 2, M / 2);
     // one read stream over both channels: the pipeline stays full across the channel boundary
@@ -336,7 +345,7 @@ inline std::string win_taps_function_exact(const SpecTable &t, const WinGeom &g,
     const int M = g.M;
     const size_t ring = (size_t)la + 2;                  // read k lands in q[k % ring]: the previous chunk stays whole while read k + la is issued
     std::string s;
-    const std::string fname = only_ch < 0 ? win_taps_name(pg) : "vw_taps_c" + std::to_string(only_ch);
+    const std::string fname = only_ch < 0 ? win_taps_name(pg) : win_taps_channel_name(pg, only_ch);
     s += "__device__ __forceinline__ void " + fname + "(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
     spec_append(s, "    v4f q[%zu];\n    v2f S[%d], A[%d];\n    const v2f Z2 = {0.0f, 0.0f};\n", ring, M / 2, M / 2);
     std::vector<WinExPass> passes;
@@ -453,7 +462,7 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
     spec_append(s, "#define VW_NT %d\n#define VW_M %d\n#define VW_R %d\n#define VW_G %d\n#define VW_NB %d\n#define VW_DE %d\n#define VW_PLANE %d\n#define VW_LA %d\n",
                 g.nt, g.M, g.R, g.G, g.NB, g.DE, g.plane, c.la);
     spec_append(s, "#define VW_NT_STORES %d\n#define VW_EPI %d\n#define VW_BC %d\n#define VW_EXACT %d\n#define VW_C %d\n", c.nt_stores, c.epi, c.bc, c.exact, g.C);
-    spec_append(s, "#define VW_Q %d\n#define VW_S %d\n", g.quad, g.split);
+    spec_append(s, "#define VW_Q %d\n#define VW_S %d\n#define VW_QCS %d\n", g.quad, g.split, g.csplit);
     // split form: how many of a wave's M/4 refill accesses per tile are loaded late (at the start of the store phase that consumes
     // them) instead of a tile ahead: 64-frame runs keep half of them out of the tap phase's registers
     // (the fast mode's E / P accumulators are twice the exact mode's sums: all but one late there - hipRTC's build of cfg2's table
@@ -485,7 +494,24 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
     const std::string marker = "//@@VW_TAPS@@";
     const size_t at = fixed.find(marker);
     src += fixed.substr(0, at);
-    if (g.split) {
+    if (g.csplit) {
+        // channel-split quads / octets: one function per channel, the workgroup's 4Q of them picked by the wave's channel number
+        const int nch = 4 * g.quad;
+        for (int pg = 0; pg < t.C / 2; ++pg)
+            for (int ch = 0; ch < 2; ++ch) src += c.exact ? win_taps_function_exact(t, g, c.la, pg, ch) : win_taps_function(t, g, c.la, pg, ch);
+        src += "template <int PG> __device__ void vw_taps_of(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M]);      // (vw_span, vw_span_q: not instantiated)\n";
+        src += "template <int QD> __device__ __forceinline__ void vw_taps_of_channel(int pc, vw_lchar *const (&b)[2][VW_NB], float (&o)[VW_M])\n{\n";
+        for (int qd = 0; qd < t.C / nch; ++qd) {
+            spec_append(src, "    %sif constexpr (QD == %d) {\n        switch (pc) {\n", qd ? "else " : "", qd);
+            for (int pc = 0; pc < nch; ++pc)
+                spec_append(src, "        %s %s(b, o, o); break;\n", pc + 1 < nch ? ("case " + std::to_string(pc) + ":").c_str() : "default:",
+                            win_taps_channel_name(qd * nch / 2 + pc / 2, pc & 1).c_str());
+            src += "        }\n    }\n";
+        }
+        src += "}\n#define VW_TAPS_OF_CHANNEL(pc) vw_taps_of_channel<QD>(pc, b, o);\n#define VW_DISPATCH(pg) switch (pg) {";
+        for (int qd = 0; qd < t.C / nch; ++qd) spec_append(src, " case %d: vw_span_qc<%d>(a, lds, stream, span); break;", qd, qd);
+        src += " default: break; }\n";
+    } else if (g.split) {
         for (int ch = 0; ch < 2; ++ch) src += c.exact ? win_taps_function_exact(t, g, c.la, 0, ch) : win_taps_function(t, g, c.la, 0, ch);
         src += "template <int PG> __device__ void vw_taps_of(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M]);      // (vw_span: not instantiated)\n";
         src += "#define VW_DISPATCH(pg) vw_span_s(a, lds, stream, span);\n";
@@ -501,7 +527,7 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
 // (short streams: a ring is filled once per span)
 inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool small_tiles, bool bc, SpecConfig *out,
                             const std::function<bool(const SpecConfig &)> &rejected = nullptr, int quad = 0, bool split = false,
-                            bool exact = false)
+                            bool exact = false, bool csplit = false)
 {
     // the geometry that keeps the most waves on a CU (the ring is LDS-bound: tile + halo per workgroup), the larger
     // workgroup on a tie (the halo is shared by more lanes); short streams (small_tiles: a ring is filled once per
@@ -517,11 +543,11 @@ inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool sm
         for (int G : {8, 4}) {
             if (g_env > 0) G = g_env;
             WinGeom g;
-            if (win_geometry(t, M, nt, G, bc, lds_limit, &g, quad, split)) {
+            if (win_geometry(t, M, nt, G, bc, lds_limit, &g, quad, split, csplit)) {
                 const int waves = win_workgroups_per_cu(g) * (nt / 64);
                 if (waves > best_waves) {
                     SpecConfig c;
-                    c.nt = nt; c.win = M; c.win_g = G; c.win_lds = (int)g.lds_bytes(); c.bc = bc ? 1 : 0; c.win_q = g.quad; c.win_s = g.split;
+                    c.nt = nt; c.win = M; c.win_g = G; c.win_lds = (int)g.lds_bytes(); c.bc = bc ? 1 : 0; c.win_q = g.quad; c.win_s = g.split; c.win_qc = g.csplit;
                     c.win_per_cu = win_workgroups_per_cu(g);
                     // reads kept in flight: each holds 4 registers, and 32-frame runs already live at ~240 of the 256 a lane
                     // has at two waves per SIMD (measured: 3 to 10 reads ahead run the same, tools/win_try.py)
@@ -529,7 +555,7 @@ inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool sm
                     c.rr = 0; c.pp = 0; c.dd = 0;
                     // the store phase: interleaved frame pairs (one 16-byte read-back per store) unless that build spilled
                     // before - it holds both channels' outputs interleaved - then planar chunks in 8-byte halves
-                    c.win_xpose = (bc || split) ? 0 : (spec_env("VND_WIN_XPOSE_PAIRS", 1) != 0 ? 1 : 0);      // (the split form's outputs cross waves as planar runs)
+                    c.win_xpose = (bc || split || csplit) ? 0 : (spec_env("VND_WIN_XPOSE_PAIRS", 1) != 0 ? 1 : 0);      // (the split form's outputs cross waves as planar runs)
                     if (rejected && rejected(c)) {                  // a build of this geometry failed or spilled before
                         if (!c.win_xpose) continue;
                         // (cfg2's fast kernel: 44 bytes of spill with 4 reads ahead, none with 3 - and 3 to 10 run the same)
@@ -558,7 +584,7 @@ inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool sm
 inline std::string win_source_for(const SpecTable &t, const SpecConfig &cfg)
 {
     WinGeom g;
-    if (!win_geometry(t, cfg.win, cfg.nt, cfg.win_g, cfg.bc != 0, 160 * 1024, &g, cfg.win_q, cfg.win_s != 0)) return "#error window geometry does not fit\n";
+    if (!win_geometry(t, cfg.win, cfg.nt, cfg.win_g, cfg.bc != 0, 160 * 1024, &g, cfg.win_q, cfg.win_s != 0, cfg.win_qc != 0)) return "#error window geometry does not fit\n";
     return win_source(t, g, cfg);
 }
 
