@@ -205,10 +205,10 @@ def secondary_configs(torch, vnd, _native, ctx, mode) -> dict:
          'as cfg3'),
         ('cfg5', dict(duration_seconds=0.03, num_impulses=64, num_outs=8, sample_rate_hz=96000, seed=1),
          (16, 960000, 8), 1, '96 kHz 8-channel, 10 s, 64 log-distributed taps; pool of 16',
-         'LDS reads and vector issue of 16-frame runs (3.4 B of LDS per FMA): the window form on channel OCTETS moves whole 32-byte '
-         'frames per workgroup (512 lanes, a quarter per channel pair; 8 waves per CU hold the 2720-frame halo of all 8 channels in '
-         '157 KB of LDS) - at the rate of the same taps on 4-channel frames; until late round 3 a workgroup owned one channel pair '
-         '(8-byte pieces, 0.44-0.48 ms: profiles/r03_cfg5_request_floor.txt, profiles/r03_cfg5_octets.txt)'),
+         'LDS reads (2.6 B per FMA with 32-frame runs; a fifth of the LDS cycles are bank conflicts of the wave at the ring\'s end) and '
+         'vector issue: the window form on channel OCTETS moves whole 32-byte frames per workgroup (512 lanes, a wave per channel; 8 '
+         'waves per CU hold the 2720-frame halo of all 8 channels in 158 KB of LDS); until late round 3 a workgroup owned one channel '
+         'pair (8-byte pieces, 0.44-0.48 ms: profiles/r03_cfg5_request_floor.txt, profiles/r03_cfg5_octets.txt)'),
         ('cfg4', dict(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1),
          (1024, 48000, 2), 2, '1024 independent 1 s stereo streams, 30 taps, one launch; 2 rotating pools',
          'board power cap, as cfg2'),
