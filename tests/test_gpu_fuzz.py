@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 FORCE = 1 << 23
 GENERIC = 1 << 25
-WIN = {0: 1 << 5, 16: 2 << 5, 32: 3 << 5}
+WIN = {0: 1 << 5, 16: 2 << 5, 32: 3 << 5, 64: 4 << 5}
 
 
 def span_bits(min_span, rounds):
@@ -25,7 +25,7 @@ CASES = [(2, 700, 40), (8, 700, 24), (3, 64, 20), (2, 2500, 40), (4, 1500, 30), 
 
 
 @pytest.mark.parametrize('seed', range(len(CASES)))
-def test_random_tables_through_every_kernel_family(seed):
+def test_random_tables_through_every_kernel_family(seed, monkeypatch):
     import vndecorrelate_amd.decorrelation as d
     from vndecorrelate_amd import _native
     from vndecorrelate_amd.taps import function_path_arrays
@@ -44,6 +44,15 @@ def test_random_tables_through_every_kernel_family(seed):
     table = _native.TapTable.create(ctx, a.tap_offsets, a.tap_index, a.tap_weight)
     variants = [('automatic', -1), ('pair-read', FORCE | WIN[0] | span_bits(1, 3)), ('window 32', FORCE | WIN[32] | span_bits(1, 3)),
                 ('window 16', FORCE | WIN[16] | span_bits(2, 1)), ('generic', GENERIC)]
+    # the forms that environment switches select (read live under VND_TUNING): stereo - 64-frame runs with the waves split over the
+    # two channels; 4k / 8k channels - a wave per channel PAIR (the default there is a wave per channel)
+    env_of = {}
+    if C == 2:
+        variants.append(('window 64 split', FORCE | WIN[64] | span_bits(1, 3)))
+        env_of['window 64 split'] = {'VND_WIN_SPLIT': '2', 'VND_SPEC_NT': '256'}
+    if C % 4 == 0:
+        variants.append(('window 16 by pair', FORCE | WIN[16] | span_bits(1, 3)))
+        env_of['window 16 by pair'] = {'VND_WIN_OCTET_SPLIT': '0'}
     try:
         # (the largest length is a multiple of 4 frames: streams of a batch then start 16-byte aligned, which the per-table
         #  kernels ask for - the odd lengths before it go through the generic kernels whatever is asked)
@@ -57,6 +66,10 @@ def test_random_tables_through_every_kernel_family(seed):
                 peak = float(np.max(np.abs(want))) or 1.0
                 for name, variant in variants:
                     ctx.set_variant(variant)
+                    for key in ('VND_WIN_SPLIT', 'VND_SPEC_NT', 'VND_WIN_OCTET_SPLIT'):
+                        monkeypatch.delenv(key, raising=False)
+                    for key, value in env_of.get(name, {}).items():
+                        monkeypatch.setenv(key, value)
                     for mode in (d.MODE_EXACT, d.MODE_FAST):
                         got = table.convolve_host(x, mode)
                         where = f'seed {seed} C={C} span={span} taps={len(a.tap_index)} n={n} batch={batch} {name}: {table.describe(batch, n, C, mode)[:60]}'
@@ -73,6 +86,8 @@ def test_random_tables_through_every_kernel_family(seed):
                             assert err <= 1e-6, f'{where}: {err:.2e}'
     finally:
         ctx.set_variant(-1)
+        for key in ('VND_WIN_SPLIT', 'VND_SPEC_NT', 'VND_WIN_OCTET_SPLIT'):
+            monkeypatch.delenv(key, raising=False)
         table.close()
 
 
