@@ -539,7 +539,7 @@ inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool sm
         const int nt = nt_env > 0 ? nt_env : kShapes[k];
         if (nt_env <= 0 && nt > 256 && quad < 2 && !split) continue;  // 512 lanes: octets (a quarter of them per channel pair) and the split form only
         if (nt_env <= 0 && nt == 384) continue;                       // (six waves land unevenly on four SIMDs: the split form 17 % slower than with 256 lanes)
-        if (small_tiles && nt_env <= 0 && nt > (quad ? 256 * quad : (split ? 256 : 128))) continue;
+        if (small_tiles && nt_env <= 0 && nt > (quad ? 256 * quad : (split ? spec_env("VND_WIN_SPLIT_SMALL_NT", 256) : 128))) continue;
         for (int G : {8, 4}) {
             if (g_env > 0) G = g_env;
             WinGeom g;
