@@ -463,6 +463,7 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
                 g.nt, g.M, g.R, g.G, g.NB, g.DE, g.plane, c.la);
     spec_append(s, "#define VW_NT_STORES %d\n#define VW_EPI %d\n#define VW_BC %d\n#define VW_EXACT %d\n#define VW_C %d\n", c.nt_stores, c.epi, c.bc, c.exact, g.C);
     spec_append(s, "#define VW_Q %d\n#define VW_S %d\n#define VW_QCS %d\n", g.quad, g.split, g.csplit);
+    spec_append(s, "#define VW_OPAQUE %d\n", spec_env("VND_WIN_OPAQUE", 1) != 0 ? 1 : 0);      // (plain form: per-access constants kept out of the tile loop's registers)
     // split form: how many of a wave's M/4 refill accesses per tile are loaded late (at the start of the store phase that consumes
     // them) instead of a tile ahead: 64-frame runs keep half of them out of the tap phase's registers
     // (the fast mode's E / P accumulators are twice the exact mode's sums: all but one late there - hipRTC's build of cfg2's table
