@@ -26,7 +26,7 @@
  *    overlap them).  "*_dev" calls only enqueue on the caller's stream and may run
  *    concurrently.  A tap table is immutable and may be shared by threads; it must
  *    outlive every call that uses it and must live on the context's device.
- *    vnd_set_variant (tuning) is not synchronised.
+ *    vnd_set_variant (tuning, vnd_amd_internal.h) is not synchronised.
  */
 #ifndef VND_AMD_H
 #define VND_AMD_H
@@ -38,7 +38,8 @@
 extern "C" {
 #endif
 
-#define VND_ABI_VERSION 1
+#define VND_ABI_VERSION 2          /* 2: measurement / tuning hooks moved to vnd_amd_internal.h */
+#define VND_TAPS_IMAGE_VERSION 1   /* format of vnd_taps_serialize images (unchanged since ABI 1) */
 
 typedef enum vnd_status {
     VND_OK = 0,
@@ -254,52 +255,9 @@ vnd_status vnd_host_free(void *ptr);
  * in VND_MODE_EXACT; VND_MODE_FAST within its tolerance - the kernel may be cut into other launches). */
 vnd_status vnd_host_buffers_mapped(const void *x, int64_t x_bytes, const void *y, int64_t y_bytes, int32_t *mapped);
 
-/* ---- measurement helpers (used by bench.py; not on the data path) ---------- */
-/* Launches the convolve `iters` times back to back on `hip_stream`, cycling
- * through `n_buffers` (x,y) pairs laid out at x_dev + i*stride_elems, and
- * returns the average kernel milliseconds between two hipEvents recorded on
- * that same stream.                                                          */
-vnd_status vnd_time_convolve_f32_dev(vnd_ctx *ctx, const vnd_taps *taps, const float *x_dev,
-                                     float *y_dev, int64_t batch, int64_t n_frames,
-                                     int32_t n_channels, int32_t mode, int32_t n_buffers,
-                                     int64_t stride_elems, int32_t iters, void *hip_stream,
-                                     float *avg_ms);
-/* Bytes of private (scratch) memory per lane the kernel `kernel` of a gfx950 code object (an ELF image)
- * asks for, read from its kernel descriptor: > 0 means the compiler spilled registers.  The library
- * rejects such builds of the window form of its per-table kernels (the registers ARE that kernel);
- * exposed so that the check can be tested without a device.  -1: no such kernel in the image.        */
-vnd_status vnd_code_object_private_bytes(const void *code, int64_t bytes, const char *kernel,
-                                         int64_t *private_bytes);
-/* The box's streaming ceiling, as a companion of the 8 TB/s figure: `iters` plain copies of `elems`
- * floats (a multiple of 4; 16-byte aligned buffers) with 16-byte non-temporal accesses, the average
- * kernel milliseconds between two hipEvents on `hip_stream`.                                    */
-vnd_status vnd_time_copy_f32_dev(vnd_ctx *ctx, const float *x_dev, float *y_dev, int64_t elems,
-                                 int32_t iters, void *hip_stream, float *avg_ms);
-/* VND_MODE_FAST and VND_MODE_EXACT compile a kernel PER TAP TABLE with hipRTC on first use
- * (offsets become LDS-read immediates, weights literals; persistent workgroups over an LDS ring;
- * `mode` picks the arithmetic: free summation order, or the reference's own association bit for
- * bit); the generic kernels take over whenever that is not possible.  This returns the HIP source the
- * library would hand to hipRTC for a function-path table - no device needed - so that it can be
- * audited or compiled offline (`hipcc --offload-arch=gfx950 -include hip/hip_runtime.h`).
- * text == NULL queries the size.  Even channel counts only (channel pairs share a workgroup). */
-vnd_status vnd_spec_kernel_source(int32_t num_channels, const int32_t *tap_offsets,
-                                  const int32_t *tap_index, const float *tap_weight, int32_t mode,
-                                  char *text, int64_t capacity, int64_t *bytes);
-/* The WINDOW form of the per-table kernel (stereo tables): a lane owns `frames_per_lane` (16 | 32 | 64)
- * consecutive output frames and reads the union of its taps' windows from LDS once.
- * Same contract as vnd_spec_kernel_source; the table as for vnd_taps_create (seg_* NULL: function path);
- * `threads` = workgroup size (multiple of 64).  When `lds_bytes_per_tile` / `fmas_per_tile` are non-NULL
- * they receive what ONE lane reads from LDS for its tap sums per tile and the (tap, output) products that
- * feeds - the kernel's figure of merit. */
-vnd_status vnd_window_kernel_source(int32_t num_channels, const int32_t *tap_offsets,
-                                    const int32_t *tap_index, const float *tap_weight,
-                                    const int32_t *seg_offsets, const int32_t *seg_end,
-                                    const float *seg_gain, int32_t apply_gain, int32_t mode,
-                                    int32_t frames_per_lane, int32_t threads, char *text,
-                                    int64_t capacity, int64_t *bytes, int64_t *lds_bytes_per_tile,
-                                    int64_t *fmas_per_tile);
-/* Kernel variant override for tuning runs: -1 = automatic choice. */
-vnd_status vnd_set_variant(vnd_ctx *ctx, int32_t variant);
+/* ---- launch introspection -------------------------------------------------
+ * (Measurement, tuning and diagnosis hooks - timing loops, the generated kernel sources, the
+ *  variant override - are declared in vnd_amd_internal.h: exported, but not part of this ABI.) */
 /* Describes the launch the library would make (for DESIGN.md / bench output). */
 vnd_status vnd_describe_launch(vnd_ctx *ctx, const vnd_taps *taps, int64_t batch,
                                int64_t n_frames, int32_t n_channels, int32_t mode,

@@ -19,8 +19,11 @@ def lib():
     return _native.load_library()
 
 
-def declared_functions():
-    text = re.sub(r'/\*.*?\*/', '', HEADER.read_text(), flags=re.S)
+INTERNAL = REPO / 'include' / 'vnd_amd_internal.h'
+
+
+def declared_functions(header=HEADER):
+    text = re.sub(r'/\*.*?\*/', '', header.read_text(), flags=re.S)
     return sorted(set(re.findall(r'\b(vnd_[a-z0-9_]+)\s*\(', text)))
 
 
@@ -41,10 +44,17 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(lib, name), f'{name} declared in vnd_amd.h but not exported'
     # and the Python binding covers the whole header, nothing more
     assert sorted(_native.SIGNATURES) == names
+    assert len(names) <= 35, 'the drop-in ABI stays small: measurement and tuning hooks belong in vnd_amd_internal.h'
+    # the measurement / tuning / diagnosis hooks: their own header, exported by the same library, bound separately
+    internal = declared_functions(INTERNAL)
+    assert internal and not set(internal) & set(names)
+    for name in internal:
+        assert hasattr(lib, name), f'{name} declared in vnd_amd_internal.h but not exported'
+    assert sorted(_native.INTERNAL_SIGNATURES) == internal
 
 
 def test_abi_version_and_error_channel(lib):
-    assert lib.vnd_abi_version() == 1
+    assert lib.vnd_abi_version() == 2
     assert isinstance(lib.vnd_last_error(), bytes)
     n = ctypes.c_int32(-1)
     rc = lib.vnd_device_count(ctypes.byref(n))

@@ -164,7 +164,7 @@ def test_every_channel_pair_of_a_wider_table_gets_its_own_tap_function(native, g
     M, nt = 32, 128
     src, lds_bytes, fmas = native.window_kernel_source(offs, idx, w, 2 if mode == 'fast' else 0, M, nt, with_traffic=True)
     assert '#define VW_C 6' in src and fmas == M * len(idx)
-    assert all(f'if constexpr (PG == {g}) ' in src and f'case {g}: vw_span<{g}>(a, lds, stream, span); break;' in src for g in range(3))
+    assert all(f'if constexpr (PG == {g}) ' in src and f'case {g}: vw_span<{g}>(a, lds, stream, t_first, ntiles, flags); break;' in src for g in range(3))
     assert 'vw_taps_3(' not in src
     R, G, plane = _macro(src, 'VW_R'), _macro(src, 'VW_G'), _macro(src, 'VW_PLANE')
     need = nt + (int(idx.max()) + M - 1) // M                   # the halo of the farthest tap of ANY pair
@@ -415,7 +415,7 @@ def test_octets_with_the_waves_split_over_the_channels(native, golden, tmp_path,
     for pg in range(4):
         for ch in range(2):
             assert ('vw_taps_c%d(' % ch if pg == 0 else 'vw_taps_%dc%d(' % (pg, ch)) in src
-    assert 'vw_span_qc<0>(a, lds, stream, span)' in src.split('#define VW_DISPATCH')[1]
+    assert 'vw_span_qc<0>(a, lds, stream, t_first, ntiles, flags)' in src.split('#define VW_DISPATCH')[1]
     f = tmp_path / 'k.hip'
     f.write_text(src)
     out = tmp_path / 'k.s'

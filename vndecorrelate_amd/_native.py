@@ -15,7 +15,7 @@ from typing import Optional
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MODE_EXACT = 0   # acc = f32(acc + f32(x*w)) : bit-identical to the reference's NumPy paths
 MODE_FMA = 1     # acc = fma(x, w, acc), table order
 MODE_FAST = 2    # fma, free summation order, gains folded into weights: the throughput mode
@@ -102,6 +102,19 @@ SIGNATURES = {
     'vnd_convolve_promote_host': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, _c_i32p, _c_i32p,
                                                  ctypes.POINTER(ctypes.c_double), ctypes.c_void_p, ctypes.c_int32,
                                                  _c_f32p, ctypes.c_int64, ctypes.c_int64]),
+    'vnd_host_alloc': (ctypes.c_int, [ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
+    'vnd_host_buffers_mapped': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                               ctypes.POINTER(ctypes.c_int32)]),
+    'vnd_host_free': (ctypes.c_int, [ctypes.c_void_p]),
+    'vnd_prepare_launch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+                                          ctypes.c_int32]),
+    'vnd_describe_launch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                           ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                           ctypes.c_char_p, ctypes.c_int32]),
+}
+
+# include/vnd_amd_internal.h: measurement, tuning and diagnosis hooks (bench.py, tools/, tests) - not the drop-in ABI
+INTERNAL_SIGNATURES = {
     'vnd_time_convolve_f32_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                  ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
@@ -110,10 +123,6 @@ SIGNATURES = {
     'vnd_time_copy_f32_dev': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                              ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
     'vnd_code_object_private_bytes': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int64, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
-    'vnd_host_alloc': (ctypes.c_int, [ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
-    'vnd_host_buffers_mapped': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
-                                               ctypes.POINTER(ctypes.c_int32)]),
-    'vnd_host_free': (ctypes.c_int, [ctypes.c_void_p]),
     'vnd_spec_kernel_source': (ctypes.c_int, [ctypes.c_int32, _c_i32p, _c_i32p, _c_f32p, ctypes.c_int32, ctypes.c_char_p,
                                               ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
     'vnd_window_kernel_source': (ctypes.c_int, [ctypes.c_int32, _c_i32p, _c_i32p, _c_f32p, _c_i32p, _c_i32p, _c_f32p,
@@ -121,12 +130,9 @@ SIGNATURES = {
                                                 ctypes.c_int32, ctypes.c_char_p, ctypes.c_int64,
                                                 ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                                 ctypes.POINTER(ctypes.c_int64)]),
-    'vnd_prepare_launch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
-                                          ctypes.c_int32]),
     'vnd_set_variant': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
-    'vnd_describe_launch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
-                                           ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
-                                           ctypes.c_char_p, ctypes.c_int32]),
+    'vnd_debug_read_stamps': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+                                             ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
 }
 
 _lib = None
@@ -174,7 +180,7 @@ def load_library():
                 f'g.build()"` (hipcc --offload-arch=gfx950).  vndecorrelate_amd has no CPU fallback.')
         _preload_hip_runtime()
         lib = ctypes.CDLL(str(LIB_PATH))
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(INTERNAL_SIGNATURES.items()):
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
@@ -518,6 +524,19 @@ class TapTable:
                     (self._lib.vnd_describe_fanout_launch, 'vnd_describe_fanout_launch'))
         _check(fn(self.ctx.handle, self.handle, batch, n, channels, int(mode), buf, 512), name)
         return buf.value.decode()
+
+    def read_stamps(self, batch: int, n: int, channels: int, mode: int = MODE_EXACT) -> np.ndarray:
+        """Phase stamps of the window-form kernel of this launch shape (``vnd_debug_read_stamps``; diagnosis builds
+        under ``VND_TUNING=1 VND_WIN_STAMPS=<workgroups>``): ``(workgroups, 16)`` uint64, empty without such a build."""
+        count = ctypes.c_int64()
+        _check(self._lib.vnd_debug_read_stamps(self.ctx.handle, self.handle, batch, n, channels, int(mode), None, 0,
+                                               ctypes.byref(count)), 'vnd_debug_read_stamps')
+        out = np.zeros(count.value, np.uint64)
+        if count.value:
+            _check(self._lib.vnd_debug_read_stamps(self.ctx.handle, self.handle, batch, n, channels, int(mode),
+                                                   out.ctypes.data_as(ctypes.c_void_p), count.value, ctypes.byref(count)),
+                   'vnd_debug_read_stamps')
+        return out.reshape(-1, 16)
 
 
 def decorrelate_workspace_bytes(batch: int, n: int, channels: int) -> int:

@@ -8,6 +8,7 @@
 #include <atomic>
 #include <functional>
 #include "../../include/vnd_amd.h"
+#include "../../include/vnd_amd_internal.h"
 
 #include <dlfcn.h>
 
@@ -385,6 +386,9 @@ struct SpecPlan {
     SpecConfig cfg;
     int tiles_total = 0, tiles_per_span = 0, spans = 0;
     uint32_t nblocks = 0, units = 0;
+    // a small launch's CU chunks (window form, stereo): chunk_tiles consecutive tiles per CU, its first-dispatched workgroup takes
+    // chunk_len0 of them, the second the rest (0: uniform spans)
+    int chunk_tiles = 0, chunk_len0 = 0, chunk_len1 = 0, chunk_rounds = 0, chunks_per_stream = 0, cus_per_xcd = 0, stagger_ticks = 0;
     const char *why = "";           // when !use: the reason, for vnd_describe_launch
 };
 
@@ -460,7 +464,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     // pair-read kernel (or, with VND_WIN_WIDE=1 / variant bits 5-7, the window form on channel pairs)
     const bool win_quad = C % 4 == 0 && Cx == C && !pointwise && spec_env("VND_WIN_QUAD", 1) != 0;
     // (a geometry whose build failed or spilled is remembered in the table's module map: skipped, the next best taken)
-    const bool nt_big = batch * n * C * (int64_t)sizeof(float) >= ((int64_t)64 << 20);
+    const bool nt_big = batch * n * C * (int64_t)sizeof(float) >= ((int64_t)spec_env("VND_NT_MIN_MB", 64) << 20);
     auto nt_stores_of = [&](const SpecConfig &c) {
         // a channel pair (or quad) is a piece of a frame: let L2 merge the pieces - unless the quad IS the frame
         if (C != 2 && !(c.win_q && C == 4 * c.win_q) && !spec_env("VND_FORCE_NT", 0)) return 0;
@@ -566,10 +570,43 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     // one round of workgroups: at most the resident slots, each walking units w, w + nblocks, ...
     p.units = (uint32_t)(units * spans);
     p.nblocks = (uint32_t)std::min<int64_t>(units * spans, resident);
+    // ---- one round of workgroups that does not fill evenly: CU chunks ----------------------------------------------
+    // cfg4's N = 8 shard (128 one-second streams: 768 tiles of 8192 frames) is 3 tiles per CU.  Uniform spans of 2 tiles make 384
+    // workgroups: every CU gets one, half of them a second - and a CU's second workgroup runs in what the first leaves of the SIMDs
+    // and the memory pipeline (phase stamps, profiles/r04_shard_timeline.txt: its tile period is 1.2x the first's), so those CUs
+    // finish 4-5 us after the others.  Instead every CU takes a CHUNK of consecutive tiles of one stream and splits it between its
+    // two co-resident workgroups - the longer piece to the one dispatched first.  The split minimises a small model of the two
+    // (prologue 0.55 / 0.8 of a tile period, period 1 / 1.2); taken only when the model puts it ahead of the uniform plan.
+    p.chunk_tiles = 0;
+    if (p.cfg.win && C == 2 && per_cu >= 2 && cus % 8 == 0 && units <= cus && cus % units == 0 && units * spans <= resident &&
+        !(v >= 0 && ((v >> 28) & 7)) && spec_env("VND_WIN_CHUNKS", 1) != 0) {
+        const int64_t cps = cus / units;                              // chunks per stream: one per CU
+        const int64_t w = (tiles_total + cps - 1) / cps;              // tiles per chunk
+        auto cost2 = [](int64_t a, int64_t b) { return std::max(0.55 + (double)a, b > 0 ? 0.8 + 1.2 * (double)b : 0.0); };
+        // the uniform plan: its workgroups land on the CUs in dispatch order - every CU one, then a second one on the first few
+        const int64_t wgs = units * spans, doubled = std::max<int64_t>(0, wgs - cus);
+        const double uniform = doubled > 0 ? cost2(per_span, per_span) : cost2(per_span, 0);
+        int64_t best_len0 = 0;
+        double best = 1e30;
+        for (int64_t a0 = (w + 1) / 2; a0 <= w; ++a0) {
+            const double c = cost2(a0, w - a0);
+            if (c < best - 1e-9) { best = c; best_len0 = a0; }
+        }
+        const int len0_env = spec_env("VND_WIN_CHUNK_LEN0", 0), len1_env = spec_env("VND_WIN_CHUNK_LEN1", -1);      // (tuning: force the split; LEN1 >= 0: three workgroups per CU)
+        if (len0_env > 0 && len0_env < w) { best_len0 = len0_env; best = -1.0; }
+        if (w >= 2 && best < uniform - 1e-9 && best_len0 < w && w * (cps - 1) < tiles_total) {
+            p.chunk_tiles = (int)w; p.chunk_len0 = (int)best_len0; p.chunks_per_stream = (int)cps; p.cus_per_xcd = cus / 8;
+            p.chunk_len1 = (int)(w - best_len0); p.chunk_rounds = 2;
+            if (len1_env >= 0 && per_cu >= 3 && best_len0 + len1_env < w) { p.chunk_len1 = len1_env; p.chunk_rounds = 3; }
+            p.stagger_ticks = std::max(0, spec_env("VND_WIN_STAGGER_TICKS", 0));
+            p.units = (uint32_t)(p.chunk_rounds * cus);
+            p.nblocks = p.units;
+        }
+    }
     p.use = true;
     // (window form: 8192-frame tiles down to 3 per span - 256 one-second streams 42.6 us with them, 45.7 with 4096-frame
     //  tiles; at 2 per span - 128 such streams - the smaller tiles win, 26.3 against 28.1 us: tools/shard_try.py)
-    if (per_span >= (p.cfg.win ? 3 : 12) || rr_hint > 0) break;
+    if (per_span >= (p.cfg.win ? 3 : 12) || rr_hint > 0 || p.chunk_tiles > 0) break;
     }
     return p;
 }
@@ -604,6 +641,8 @@ static vnd_status launch_spec(vnd_ctx *ctx, const vnd_taps *t, const SpecPlan &p
     a.x = x; a.y = y; a.n = n;
     a.tiles_total = p.tiles_total; a.tiles_per_span = p.tiles_per_span; a.spans = p.spans; a.nblocks = p.nblocks;
     a.units = p.units;
+    a.chunk_tiles = p.chunk_tiles; a.chunk_len0 = p.chunk_len0; a.chunk_len1 = p.chunk_len1; a.chunks_per_stream = p.chunks_per_stream; a.cus_per_xcd = p.cus_per_xcd;
+    a.stagger_ticks = p.stagger_ticks; a.chunk_prio = spec_env("VND_WIN_CHUNK_PRIO", 0) != 0 ? 1 : 0;
     if (epi != nullptr && p.cfg.epi) {
         a.epi_ms_encode = epi->ms_encode; a.epi_use_width = epi->use_width; a.epi_w_mid = epi->w_mid; a.epi_w_side = epi->w_side;
     }
@@ -956,7 +995,7 @@ vnd_status vnd_taps_serialize(const vnd_taps *t, void *buf, int64_t capacity, in
     if (!buf) return VND_OK;                     // size query
     if (capacity < *bytes) return fail(VND_ERR_INVALID, "buffer too small: need %lld bytes", (long long)*bytes);
     int32_t *p = (int32_t *)buf;
-    const int32_t hdr[8] = {kMagic, VND_ABI_VERSION, t->C, t->total, t->total_segs,
+    const int32_t hdr[8] = {kMagic, VND_TAPS_IMAGE_VERSION, t->C, t->total, t->total_segs,
                             t->has_seg, t->has_flags, t->apply_gain};
     memcpy(p, hdr, sizeof hdr); p += 8;
     memcpy(p, t->tap_off.data(), (t->C + 1) * 4); p += t->C + 1;
@@ -977,7 +1016,7 @@ vnd_status vnd_taps_deserialize(vnd_ctx *ctx, const void *buf, int64_t bytes, vn
     *out = nullptr;
     if (!buf || bytes < 32) return fail(VND_ERR_INVALID, "tap image too short");
     const int32_t *p = (const int32_t *)buf;
-    if (p[0] != kMagic || p[1] != VND_ABI_VERSION) return fail(VND_ERR_INVALID, "not a tap image of this ABI version");
+    if (p[0] != kMagic || p[1] != VND_TAPS_IMAGE_VERSION) return fail(VND_ERR_INVALID, "not a tap image of this format version");
     const int32_t C = p[2], total = p[3], segs = p[4], has_seg = p[5], has_flags = p[6], gain = p[7];
     if (C <= 0 || total < 0 || segs < 0) return fail(VND_ERR_INVALID, "corrupt tap image header");
     const int64_t flag_words = has_flags ? (C + 3) / 4 : 0;
@@ -1124,7 +1163,7 @@ vnd_status vnd_taps_broadcast_rccl(vnd_ctx *ctx, vnd_taps **taps, int32_t root, 
             // what arrived must be a tap image of exactly the announced length before anything is built from it
             // (a communicator whose ranks disagree on the root, or a torn transfer, shows up here, loudly)
             const int32_t *hd = (const int32_t *)image.data();
-            if (hd[0] != kMagic || hd[1] != VND_ABI_VERSION) { st = fail(VND_ERR_INVALID, "rank %d received %lld bytes that are not a tap image (magic %08x, ABI %d)", rank, (long long)bytes, (unsigned)hd[0], hd[1]); break; }
+            if (hd[0] != kMagic || hd[1] != VND_TAPS_IMAGE_VERSION) { st = fail(VND_ERR_INVALID, "rank %d received %lld bytes that are not a tap image (magic %08x, version %d)", rank, (long long)bytes, (unsigned)hd[0], hd[1]); break; }
             const int64_t words = 8 + ((int64_t)hd[2] + 1) + 2 * (int64_t)hd[3] + (hd[5] ? ((int64_t)hd[2] + 1) + 2 * (int64_t)hd[4] : 0) + (hd[6] ? ((int64_t)hd[2] + 3) / 4 : 0);
             if (hd[2] <= 0 || hd[3] < 0 || hd[4] < 0 || words * 4 != bytes) { st = fail(VND_ERR_INVALID, "rank %d: the tap image's header (%d channels, %d taps, %d segments) does not match its %lld bytes", rank, hd[2], hd[3], hd[4], (long long)bytes); break; }
             st = vnd_taps_deserialize(ctx, image.data(), bytes, taps);
@@ -1528,7 +1567,7 @@ vnd_status vnd_window_kernel_source(int32_t C, const int32_t *tap_offsets, const
         return fail(VND_ERR_UNSUPPORTED, "this window geometry does not fit the LDS");
     SpecConfig cfg;
     cfg.nt = threads; cfg.win = frames_per_lane; cfg.win_g = g.G; cfg.win_lds = (int)g.lds_bytes(); cfg.win_q = g.quad; cfg.win_s = g.split; cfg.win_qc = g.csplit;
-    cfg.la = spec_env("VND_SPEC_LA", frames_per_lane >= 32 ? 4 : 6);
+    cfg.la = spec_env("VND_SPEC_LA", (split && frames_per_lane >= 64) ? (mode == VND_MODE_EXACT ? 3 : 2) : (frames_per_lane >= 32 ? 4 : 6));      // (as win_pick_config)
     cfg.win_xpose = spec_env("VND_WIN_XPOSE_PAIRS", 1) != 0 ? 1 : 0;
     cfg.exact = mode == VND_MODE_EXACT ? 1 : 0;
     if (lds_bytes_per_tile || fmas_per_tile) {
@@ -1580,11 +1619,15 @@ static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64
         }
         if (m && !m->failed) {
             if (sp.cfg.win) {
+                char split[96];
+                if (sp.chunk_tiles > 0 && sp.chunk_rounds == 3) snprintf(split, sizeof split, "a chunk of %d tiles per CU as %d + %d + %d, %d chunks", sp.chunk_tiles, sp.chunk_len0, sp.chunk_len1, sp.chunk_tiles - sp.chunk_len0 - sp.chunk_len1, sp.chunks_per_stream);
+                else if (sp.chunk_tiles > 0) snprintf(split, sizeof split, "a chunk of %d tiles per CU as %d + %d, %d chunks", sp.chunk_tiles, sp.chunk_len0, sp.chunk_len1, sp.chunks_per_stream);
+                else snprintf(split, sizeof split, "%d spans x %d tiles", sp.spans, sp.tiles_per_span);
                 snprintf(text, (size_t)len,
                          "conv_spec%s_window (hipRTC, per table) frames_per_lane=%d tile=%d reads_ahead=%d "
-                         "nt_stores=%d mode=%d lds=%zuB workgroups=%u (%u units: %d spans x %d tiles per stream) threads=%d store_phase=%s",
+                         "nt_stores=%d mode=%d lds=%zuB workgroups=%u (%u units: %s per stream) threads=%d store_phase=%s",
                          sp.cfg.exact ? "_exact" : "", sp.cfg.win, sp.cfg.tile(), sp.cfg.la, sp.cfg.nt_stores, mode,
-                         sp.cfg.lds_bytes(), sp.nblocks, sp.units, sp.spans, sp.tiles_per_span, sp.cfg.nt,
+                         sp.cfg.lds_bytes(), sp.nblocks, sp.units, split, sp.cfg.nt,
                          sp.cfg.win_s ? "planar waves=split-by-channel" : sp.cfg.win_qc ? (sp.cfg.win_q == 2 ? "planar pieces=channel-octets waves=split-by-channel" : "planar pieces=channel-quads waves=split-by-channel") : sp.cfg.win_q == 2 ? "frame-pairs pieces=channel-octets" : (sp.cfg.win_q ? "frame-pairs pieces=channel-quads" : (sp.cfg.win_xpose ? "frame-pairs" : "planar")));
                 return VND_OK;
             }
@@ -1639,6 +1682,28 @@ vnd_status vnd_prepare_launch(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, in
         if (!sp.cfg.win) break;
     }
     return VND_OK;                                                 // the generic kernels take such launches
+}
+
+vnd_status vnd_debug_read_stamps(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64_t n, int32_t in_channels, int32_t mode,
+                                 uint64_t *stamps, int64_t capacity, int64_t *count)
+{
+    if (!ctx || !t || !count || capacity < 0 || (capacity > 0 && !stamps)) return fail(VND_ERR_INVALID, "bad arguments");
+    *count = 0;
+    vnd_status st = check_shape(ctx, t, batch, n, t->C, mode, in_channels);
+    if (st != VND_OK) return st;
+    DeviceScope on(ctx->device);
+    const SpecPlan sp = make_spec_plan(ctx, t, nullptr, nullptr, batch, n, t->C, in_channels, mode, nullptr);
+    if (!sp.use || !sp.cfg.win) return VND_OK;
+    SpecModule *m = spec_module(ctx, t, sp.cfg, true);
+    if (!m || m->failed || !m->module) return VND_OK;
+    hipDeviceptr_t at = nullptr;
+    size_t bytes = 0;
+    if (hipModuleGetGlobal(&at, &bytes, m->module, "vw_stamps") != hipSuccess) { (void)hipGetLastError(); return VND_OK; }
+    *count = (int64_t)(bytes / sizeof(uint64_t));
+    const size_t take = std::min<size_t>(bytes, (size_t)capacity * sizeof(uint64_t));
+    HIP_TRY(hipDeviceSynchronize());
+    if (take) HIP_TRY(hipMemcpy(stamps, at, take, hipMemcpyDeviceToHost));
+    return VND_OK;
 }
 
 static int64_t epi_chunks(int64_t n) { return (n + kEpiChunk - 1) / kEpiChunk; }

@@ -366,6 +366,9 @@ struct SpecArgs {
     unsigned nblocks, units;
     int epi_ms_encode, epi_use_width;
     float epi_w_mid, epi_w_side;
+    // window form only (VWArgs): a small launch's CU chunks - see vnd_win_kernel.inc
+    int chunk_tiles, chunk_len0, chunks_per_stream, cus_per_xcd;
+    int stagger_ticks, chunk_prio, chunk_len1;
 };
 
 struct SpecModule {
@@ -575,6 +578,7 @@ inline bool spec_compile(const SpecTable &t, const SpecConfig &cfg, int device, 
             m->module = nullptr; m->fn = nullptr;
             m->failed = true;
             m->log += " (window form spills " + std::to_string(local) + " bytes of registers per lane: rejected)";
+            if (getenv("VND_SPEC_VERBOSE")) fprintf(stderr, "vnd: window build frames_per_lane=%d threads=%d split=%d reads_ahead=%d:%s\n", cfg.win, cfg.nt, cfg.win_s, cfg.la, m->log.c_str());
             return false;
         }
     }

@@ -165,8 +165,8 @@ inline std::string win_taps_dispatch(const SpecTable &t, int quad = 0)
     for (int pg = 0; pg < t.C / 2; ++pg)
         spec_append(s, "    %sif constexpr (PG == %d) %s(b, o0, o1);\n", pg ? "else " : "", pg, win_taps_name(pg).c_str());
     s += "}\n#define VW_DISPATCH(pg) switch (pg) {";
-    if (quad) for (int qd = 0; qd < t.C / (4 * quad); ++qd) spec_append(s, " case %d: vw_span_q<%d>(a, lds, stream, span); break;", qd, qd);
-    else for (int pg = 0; pg < t.C / 2; ++pg) spec_append(s, " case %d: vw_span<%d>(a, lds, stream, span); break;", pg, pg);
+    if (quad) for (int qd = 0; qd < t.C / (4 * quad); ++qd) spec_append(s, " case %d: vw_span_q<%d>(a, lds, stream, t_first, ntiles, flags); break;", qd, qd);
+    else for (int pg = 0; pg < t.C / 2; ++pg) spec_append(s, " case %d: vw_span<%d>(a, lds, stream, t_first, ntiles, flags); break;", pg, pg);
     s += " default: break; }\n";
     return s;
 }
@@ -479,6 +479,12 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
     // diagnosis builds (WRONG results on purpose: no stores / every load from one place - see the kernel): only in a tuning session
     const char *tuning = getenv("VND_TUNING");
     spec_append(s, "#define VW_DEBUG %d\n", (tuning && *tuning && *tuning != '0') ? spec_env("VND_WIN_DEBUG", 0) : 0);
+    // prologue: loads a wave keeps in flight before its first staging write; the store phase's read-backs per batch; the last tile of a
+    // workgroup's last unit skips its (useless) refill and the barrier behind it
+    spec_append(s, "#define VW_FILL_BATCH %d\n#define VW_RB_BATCH %d\n#define VW_SKIP_FINAL %d\n", spec_env("VND_WIN_FILL_BATCH", 8), spec_env("VND_WIN_RB_BATCH", 1),
+                spec_env("VND_WIN_SKIP_FINAL", 0) != 0 ? 1 : 0);
+    spec_append(s, "#define VW_STAMP_PHASES %d\n", spec_env("VND_WIN_STAMP_PHASES", 1) != 0 ? 1 : 0);
+    spec_append(s, "#define VW_STAMPS %d\n", (tuning && *tuning && *tuning != '0') ? std::min(std::max(spec_env("VND_WIN_STAMPS", 0), 0), 4096) : 0);
     // s_setprio of the store / refill phase (0: none): cfg2 +1.0 % fast, +0.5 % exact at 1, 2 or 3; cfg3 unchanged (tools/win_phase_try.py)
     spec_append(s, "#define VW_PRIO %d\n", spec_env("VND_WIN_PRIO", 1));
     spec_append(s, "#define VW_LOAD_AUX %d\n", spec_env("VND_SPEC_LOAD_AUX", 2));
@@ -510,12 +516,12 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
             src += "        }\n    }\n";
         }
         src += "}\n#define VW_TAPS_OF_CHANNEL(pc) vw_taps_of_channel<QD>(pc, b, o);\n#define VW_DISPATCH(pg) switch (pg) {";
-        for (int qd = 0; qd < t.C / nch; ++qd) spec_append(src, " case %d: vw_span_qc<%d>(a, lds, stream, span); break;", qd, qd);
+        for (int qd = 0; qd < t.C / nch; ++qd) spec_append(src, " case %d: vw_span_qc<%d>(a, lds, stream, t_first, ntiles, flags); break;", qd, qd);
         src += " default: break; }\n";
     } else if (g.split) {
         for (int ch = 0; ch < 2; ++ch) src += c.exact ? win_taps_function_exact(t, g, c.la, 0, ch) : win_taps_function(t, g, c.la, 0, ch);
         src += "template <int PG> __device__ void vw_taps_of(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M]);      // (vw_span: not instantiated)\n";
-        src += "#define VW_DISPATCH(pg) vw_span_s(a, lds, stream, span);\n";
+        src += "#define VW_DISPATCH(pg) vw_span_s(a, lds, stream, t_first, ntiles, flags);\n";
     } else {
         for (int pg = 0; pg < t.C / 2; ++pg) src += c.exact ? win_taps_function_exact(t, g, c.la, pg) : win_taps_function(t, g, c.la, pg);
         src += win_taps_dispatch(t, g.quad);

@@ -43,18 +43,18 @@ class TapArrays:
                     chan_flags=self.chan_flags, apply_gain=self.apply_gain)
 
     # ---- transport image: byte-identical to vnd_taps_serialize (csrc/vnd_amd.hip) ----
-    # int32 header[8] = {magic "VNDT", ABI version, C, taps, segments, has_seg, has_flags,
+    # int32 header[8] = {magic "VNDT", image version (VND_TAPS_IMAGE_VERSION), C, taps, segments, has_seg, has_flags,
     # apply_gain}, then tap_offsets[C+1], tap_index, tap_weight, (seg_offsets[C+1], seg_end,
     # seg_gain), (chan_flags padded to 4 bytes).  This is what travels over RCCL.
     _MAGIC = 0x564E4454
-    _ABI = 1
+    _IMAGE_VERSION = 1
 
     def to_bytes(self) -> bytes:
         channels, total = self.num_channels, len(self.tap_index)
         has_seg = self.seg_offsets is not None
         has_flags = self.chan_flags is not None
         segs = len(self.seg_end) if has_seg else 0
-        head = np.array([self._MAGIC, self._ABI, channels, total, segs, int(has_seg), int(has_flags),
+        head = np.array([self._MAGIC, self._IMAGE_VERSION, channels, total, segs, int(has_seg), int(has_flags),
                          int(bool(self.apply_gain))], np.int32)
         parts = [head, self.tap_offsets.astype(np.int32), self.tap_index.astype(np.int32),
                  self.tap_weight.astype(np.float32)]
@@ -71,8 +71,8 @@ class TapArrays:
     @classmethod
     def from_bytes(cls, image: bytes) -> 'TapArrays':
         head = np.frombuffer(image, np.int32, 8)
-        if head[0] != cls._MAGIC or head[1] != cls._ABI:
-            raise ValueError('not a tap-table image of this ABI version')
+        if head[0] != cls._MAGIC or head[1] != cls._IMAGE_VERSION:
+            raise ValueError('not a tap-table image of this format version')
         channels, total, segs, has_seg, has_flags, gain = (int(v) for v in head[2:8])
         pos = 32
 
