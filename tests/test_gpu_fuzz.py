@@ -44,15 +44,12 @@ def test_random_tables_through_every_kernel_family(seed, monkeypatch):
     table = _native.TapTable.create(ctx, a.tap_offsets, a.tap_index, a.tap_weight)
     variants = [('automatic', -1), ('pair-read', FORCE | WIN[0] | span_bits(1, 3)), ('window 32', FORCE | WIN[32] | span_bits(1, 3)),
                 ('window 16', FORCE | WIN[16] | span_bits(2, 1)), ('generic', GENERIC)]
-    # the forms that environment switches select (read live under VND_TUNING): stereo - 64-frame runs with the waves split over the
-    # two channels; 4k / 8k channels - a wave per channel PAIR (the default there is a wave per channel)
+    # the form that an environment switch selects (read live under VND_TUNING): stereo - 64-frame runs with the waves split over the
+    # two channels
     env_of = {}
     if C == 2:
         variants.append(('window 64 split', FORCE | WIN[64] | span_bits(1, 3)))
         env_of['window 64 split'] = {'VND_WIN_SPLIT': '2', 'VND_SPEC_NT': '256'}
-    if C % 4 == 0:
-        variants.append(('window 16 by pair', FORCE | WIN[16] | span_bits(1, 3)))
-        env_of['window 16 by pair'] = {'VND_WIN_OCTET_SPLIT': '0'}
     try:
         # (the largest length is a multiple of 4 frames: streams of a batch then start 16-byte aligned, which the per-table
         #  kernels ask for - the odd lengths before it go through the generic kernels whatever is asked)
@@ -66,7 +63,7 @@ def test_random_tables_through_every_kernel_family(seed, monkeypatch):
                 peak = float(np.max(np.abs(want))) or 1.0
                 for name, variant in variants:
                     ctx.set_variant(variant)
-                    for key in ('VND_WIN_SPLIT', 'VND_SPEC_NT', 'VND_WIN_OCTET_SPLIT'):
+                    for key in ('VND_WIN_SPLIT', 'VND_SPEC_NT'):
                         monkeypatch.delenv(key, raising=False)
                     for key, value in env_of.get(name, {}).items():
                         monkeypatch.setenv(key, value)
@@ -86,7 +83,7 @@ def test_random_tables_through_every_kernel_family(seed, monkeypatch):
                             assert err <= 1e-6, f'{where}: {err:.2e}'
     finally:
         ctx.set_variant(-1)
-        for key in ('VND_WIN_SPLIT', 'VND_SPEC_NT', 'VND_WIN_OCTET_SPLIT'):
+        for key in ('VND_WIN_SPLIT', 'VND_SPEC_NT'):
             monkeypatch.delenv(key, raising=False)
         table.close()
 

@@ -238,28 +238,22 @@ def test_window_form_on_wider_signals(env, golden, monkeypatch, C, M, nt):
     table.close()
 
 
-@pytest.mark.parametrize('C,M,nt,Q,by_channel', [(8, 16, 256, 1, 0), (4, 16, 256, 1, 0), (12, 16, 128, 1, 0), (8, 32, 128, 1, 0), (4, 32, 256, 1, 0),
-                                                 (16, 16, 512, 1, 0), (8, 16, 512, 2, 0), (16, 16, 512, 2, 0), (8, 32, 256, 2, 0), (8, 16, 256, 2, 0),
-                                                 (8, 32, 512, 2, 1), (16, 32, 512, 2, 1), (8, 16, 512, 2, 1), (4, 32, 256, 1, 1), (12, 32, 256, 1, 1),
-                                                 (4, 16, 256, 1, 1)])
-def test_window_form_on_channel_quads(env, golden, monkeypatch, C, M, nt, Q, by_channel):
-    """Signals of 4k interleaved channels: a workgroup takes a channel QUAD of a span - 16 bytes of every frame, the first
-    half of its lanes on the quad's first channel pair, the second half on the other, outputs exchanged between partner waves
-    through the tile's dead ring entries (vw_span_q).  Q = 2: signals of 8k channels, two neighbouring quads (32 bytes of every
-    frame; with 8 channels whole frames) per workgroup, a quarter of its lanes per pair.  by_channel: the workgroup's waves split
-    over its 4Q CHANNELS instead (vw_span_qc: one channel's accumulators per lane - 32-frame runs; the default where the ring
-    fits).  Every pair has its own taps; lengths around the tile (nt / 2Q - by channel nt / 4Q - entries of M frames), stream
-    tails inside a run, batches, spans of one tile and span seams - fast within tolerance, exact bit for bit, against the NumPy
-    oracle."""
+@pytest.mark.parametrize('C,M,nt,Q', [(8, 32, 512, 2), (16, 32, 512, 2), (8, 16, 512, 2), (4, 32, 256, 1), (12, 32, 256, 1), (4, 16, 256, 1), (8, 32, 256, 1), (16, 16, 256, 1)])
+def test_window_form_on_channel_quads(env, golden, monkeypatch, C, M, nt, Q):
+    """Signals of 4k interleaved channels: a workgroup takes a channel QUAD of a span - 16 bytes of every frame - or (Q = 2, signals
+    of 8k channels) an OCTET: two neighbouring quads, 32 bytes of every frame, with 8 channels whole frames.  Its waves are split
+    over its 4Q CHANNELS (vw_span_qc: one channel's accumulators per lane, 32-frame runs), outputs exchanged between the partner
+    waves through the tile's dead ring entries.  Every channel has its own taps; lengths around the tile (nt / 4Q entries of M
+    frames), stream tails inside a run, batches, spans of one tile and span seams - fast within tolerance, exact bit for bit,
+    against the NumPy oracle."""
     d, native, ctx = env
     wide = golden.fir('g96k_k64_c8')
     fir = np.ascontiguousarray(np.concatenate([wide, wide[:, ::-1]], axis=1)[:, :C])
     table = _table(native, ctx, fir)
     monkeypatch.setenv('VND_SPEC_NT', str(nt))
     monkeypatch.setenv('VND_WIN_OCTET', '1' if Q == 2 else '0')
-    monkeypatch.setenv('VND_WIN_OCTET_SPLIT', '1' if by_channel else '0')
-    rng = np.random.default_rng(C * 1000 + M + Q + 7 * by_channel)
-    T = (nt // ((4 if by_channel else 2) * Q)) * M
+    rng = np.random.default_rng(C * 1000 + M + Q + 7)
+    T = (nt // (4 * Q)) * M
     pieces = 'pieces=channel-octets' if Q == 2 else 'pieces=channel-quads'
     for n in sorted({1, 3, M + 1, T - 1, T, T + 1, 2 * T + 3, 5 * T + 17, 40003}):
         for batch in (1, 3):
@@ -270,7 +264,7 @@ def test_window_form_on_channel_quads(env, golden, monkeypatch, C, M, nt, Q, by_
                 for mode, name in ((d.MODE_FAST, 'conv_spec_window'), (d.MODE_EXACT, 'conv_spec_exact_window')):
                     text = table.describe(batch, n, C, mode)
                     assert text.startswith(name) and f'frames_per_lane={M} ' in text and f'tile={T} ' in text, text
-                    assert f'threads={nt}' in text and pieces in text and ('waves=split-by-channel' in text) == bool(by_channel), text
+                    assert f'threads={nt}' in text and pieces in text and 'waves=split-by-channel' in text, text
                     got = table.convolve_host(x, mode)
                     where = f'C={C} M={M} n={n} batch={batch} spans=({min_span},{rounds})'
                     if mode == d.MODE_EXACT:
@@ -439,4 +433,56 @@ def test_mono_fan_out_through_the_window_form_when_forced(env, golden, M):
             assert table.describe(batch, n, 1, d.MODE_EXACT).startswith('conv_spec_exact_window')
             assert np.array_equal(table.convolve_host(x, d.MODE_EXACT), want), (n, batch, spans)
     ctx.set_variant(-1)
+    table.close()
+
+
+@pytest.mark.parametrize('streams,n', [(128, 48000), (64, 96000), (256, 20000), (128, 40004)])
+def test_small_one_round_launches_are_cut_into_cu_chunks(env, golden, streams, n):
+    """A launch whose tiles do not fill one round of workgroups evenly (cfg4's N = 8 shard: 3 tiles of 8192 frames per CU) gives
+    every CU a CHUNK of consecutive tiles, split between its two co-resident workgroups - the longer piece to the one dispatched
+    first, the other starting a few microseconds later (make_spec_plan, vnd_win_kernel.inc).  Every stream of such launches
+    against the C oracle: exact mode bit for bit (function- and class-path tables), fast mode within tolerance; the pieces'
+    seams fall inside streams, the last chunk of a stream is ragged, and the plan says what it did."""
+    d, native, ctx = env
+    from vndecorrelate_amd.taps import function_path_arrays
+    ctx.set_variant(-1)
+    fir = golden.fir('g48k_k30')
+    a = function_path_arrays(fir)
+    table = native.TapTable.create(ctx, a.tap_offsets, a.tap_index, a.tap_weight)
+    cls = d.VelvetNoise(sample_rate_hz=48000, seed=1)
+    cls_table = cls._device_table()
+    rng = np.random.default_rng(streams + n)
+    x = rng.uniform(-1, 1, (streams, n, 2)).astype(np.float32)
+    want = c_oracle.convolve(x, a.tap_offsets, a.tap_index, a.tap_weight, threads=8)
+    for mode in (d.MODE_FAST, d.MODE_EXACT):
+        table.prepare(streams, n, 2, mode)
+        text = table.describe(streams, n, 2, mode)
+        assert text.startswith('conv_spec') and '_window' in text and 'a chunk of 3 tiles per CU as 2 + 1' in text, text
+        got = table.convolve_host(x, mode)
+        if mode == d.MODE_EXACT:
+            assert np.array_equal(got, want), f'{streams} x {n}'
+        else:
+            worst = max(_err(got[b], want[b]) for b in range(streams))
+            assert worst <= TOL_PEAK, f'{streams} x {n}: {worst:.2e}'
+    # the class path's table (segments, +-1 weights: the plain 32-frame form in exact mode)
+    taps = O.generate_class_taps(sample_rate_hz=48000, seed=1)
+    cls_table.prepare(streams, n, 2, d.MODE_EXACT)
+    text = cls_table.describe(streams, n, 2, d.MODE_EXACT)
+    assert 'a chunk of 3 tiles per CU as 2 + 1' in text, text
+    got = cls_table.convolve_host(x, d.MODE_EXACT)
+    for b in sorted({0, 1, streams // 2, streams - 1}):
+        assert np.array_equal(got[b], O.class_convolve(x[b], taps, tuple(O.DEFAULT_ENVELOPE), 2)), (streams, n, b)
+    # ... and a mono input fanned out (one ring plane), forced into the window form
+    xm = np.ascontiguousarray(x[:, :, :1])
+    ctx.set_variant(WIN[32])
+    try:
+        table.prepare(streams, n, 1, d.MODE_EXACT)
+        text = table.describe(streams, n, 1, d.MODE_EXACT)
+        if '_window' in text:
+            assert 'a chunk of' in text, text
+        got = table.convolve_host(xm, d.MODE_EXACT)
+        wantm = c_oracle.convolve(np.ascontiguousarray(np.repeat(xm, 2, axis=2)), a.tap_offsets, a.tap_index, a.tap_weight, threads=8)
+        assert np.array_equal(got, wantm)
+    finally:
+        ctx.set_variant(-1)
     table.close()

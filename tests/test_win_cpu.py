@@ -300,50 +300,6 @@ def test_window_source_compiles_for_gfx950_with_the_intended_isa(native, golden,
 
 
 @pytest.mark.parametrize('mode', [2, 0])
-@pytest.mark.parametrize('Q', [1, 2])
-def test_quad_form_source_for_tables_of_4k_channels(native, golden, tmp_path, mode, Q, monkeypatch):
-    """cfg5's table (8 channels): the window form on channel QUADS - half a workgroup's lanes per channel pair, a ring of
-    nt / 2 + halo entries per pair, both pairs' plane sets in one workgroup's LDS, two workgroups of 256 lanes per CU - or on
-    OCTETS (Q = 2: all four pairs in one workgroup of 512 lanes, whole 32-byte frames; the default for 8k channels) is what
-    the generator emits; VND_WIN_QUAD=0 gives the form on channel pairs.  Cross-compiled for gfx950: no spill, one
-    instantiation of the span loop per quad / octet (prologue barrier + three per tile), every pair's taps once."""
-    offs, idx, w = _table(golden.fir('g96k_k64_c8'))
-    M, nt = 16, 256 * Q
-    monkeypatch.setenv('VND_WIN_OCTET', '1' if Q == 2 else '0')
-    monkeypatch.setenv('VND_WIN_OCTET_SPLIT', '0')            # (a wave per channel PAIR: the form with 16-frame runs)
-    src = native.window_kernel_source(offs, idx, w, mode, M, nt)
-    assert _macro(src, 'VW_Q') == Q and _macro(src, 'VW_C') == 8
-    assert _macro(src, 'VW_R') == 128 + _macro(src, 'VW_DE')
-    lds = 2 * Q * 2 * (M // 4) * _macro(src, 'VW_PLANE')
-    assert (2 // Q) * lds <= 160 * 1024 and _macro(src, 'VW_WAVES_PER_EU') == 2          # 8 waves per CU either way
-    dispatch = src.split('#define VW_DISPATCH')[1].split('\n')[0]
-    assert dispatch.count('vw_span_q<') == 2 // Q and 'vw_span<' not in dispatch
-    monkeypatch.setenv('VND_WIN_QUAD', '0')
-    pairs = native.window_kernel_source(offs, idx, w, mode, M, nt)
-    assert _macro(pairs, 'VW_Q') == 0 and _macro(pairs, 'VW_R') == nt + _macro(pairs, 'VW_DE')
-    f = tmp_path / 'k.hip'
-    f.write_text(src)
-    out = tmp_path / 'k.s'
-    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '--cuda-device-only',
-                        '-include', 'hip/hip_runtime.h', '-S', str(f), '-o', str(out)], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
-    asm = out.read_text()
-    assert re.search(r'ScratchSize: 0\b', asm), 'the window kernel must not spill'
-    ops = re.findall(r'^\s+([a-z0-9_]+)', asm, re.M)
-    count = {o: ops.count(o) for o in set(ops)}
-    assert count.get('flat_load_dwordx4', 0) == 0, 'LDS reads fell back to flat loads'
-    assert count['s_barrier'] == (2 // Q) * 4
-    if mode == 2:
-        odd = int((idx & 1).sum())
-        packed = count['v_pk_fma_f32'] + count.get('v_pk_mul_f32', 0)
-        # (an odd tap's two single FMAs at the run's edges are sometimes paired up by hipcc)
-        assert len(idx) * (M // 2) - odd - 64 <= packed <= len(idx) * (M // 2)
-    # whole 16-byte pieces in both directions
-    assert count.get('buffer_load_dwordx2', 0) == 0 and count.get('buffer_store_dwordx2', 0) == 0
-    assert count['buffer_store_dwordx4'] == (2 // Q) * (M // 2)
-
-
-@pytest.mark.parametrize('mode', [2, 0])
 def test_split_form_source_keeps_three_waves_per_simd(native, golden, tmp_path, mode, monkeypatch):
     """VND_WIN_SPLIT: a wave computes ONE channel of a stereo table (vw_taps_c0 / vw_taps_c1) - one channel's accumulators per
     lane, so the dense 128-tap table builds for three waves per SIMD (<= 168 registers) without spilling."""
@@ -402,20 +358,25 @@ def test_split_form_with_64_frame_runs_fits_two_waves_per_simd(native, golden, t
 
 
 @pytest.mark.parametrize('mode', [2, 0])
-def test_octets_with_the_waves_split_over_the_channels(native, golden, tmp_path, mode, monkeypatch):
-    """cfg5's table by default: one workgroup of 512 lanes per octet, a WAVE per channel (vw_span_qc, vw_taps_<pair>c<channel>) -
-    one channel's accumulators per lane, so 32-frame runs (2.6 B of LDS per FMA instead of 3.4) on the same 2048-frame tile,
-    the 2720-frame halo of all eight channels still inside 160 KB.  Cross-compiled: no spill, whole 16-byte pieces."""
+@pytest.mark.parametrize('Q', [2, 1])
+def test_quads_and_octets_with_a_wave_per_channel(native, golden, tmp_path, mode, Q, monkeypatch):
+    """cfg5's table by default: one workgroup of 512 lanes per OCTET (Q = 2: whole 32-byte frames), a WAVE per channel (vw_span_qc,
+    vw_taps_<pair>c<channel>) - one channel's accumulators per lane, 32-frame runs on a 2048-frame tile, the 2720-frame halo of
+    all eight channels still inside 160 KB; VND_WIN_OCTET=0 (and tables of 4k channels): a QUAD per workgroup of 256 lanes;
+    VND_WIN_QUAD=0: the form on channel pairs.  Cross-compiled: no spill, whole 16-byte pieces both ways, one instantiation of
+    the span loop per quad / octet (prologue barrier + three per tile)."""
     offs, idx, w = _table(golden.fir('g96k_k64_c8'))
-    M, nt = 32, 512
+    M, nt = 32, 256 * Q
+    monkeypatch.setenv('VND_WIN_OCTET', '1' if Q == 2 else '0')
     src = native.window_kernel_source(offs, idx, w, mode, M, nt)
-    assert _macro(src, 'VW_Q') == 2 and _macro(src, 'VW_QCS') == 1 and _macro(src, 'VW_S') == 0
-    assert _macro(src, 'VW_R') == nt // 8 + _macro(src, 'VW_DE')
-    assert 4 * 2 * (M // 4) * _macro(src, 'VW_PLANE') <= 160 * 1024
+    assert _macro(src, 'VW_Q') == Q and _macro(src, 'VW_S') == 0 and _macro(src, 'VW_C') == 8
+    assert _macro(src, 'VW_R') == nt // (4 * Q) + _macro(src, 'VW_DE')
+    assert 2 * Q * 2 * (M // 4) * _macro(src, 'VW_PLANE') <= 160 * 1024
     for pg in range(4):
         for ch in range(2):
             assert ('vw_taps_c%d(' % ch if pg == 0 else 'vw_taps_%dc%d(' % (pg, ch)) in src
-    assert 'vw_span_qc<0>(a, lds, stream, t_first, ntiles, flags)' in src.split('#define VW_DISPATCH')[1]
+    dispatch = src.split('#define VW_DISPATCH')[1].split('\n')[0]
+    assert dispatch.count('vw_span_qc<') == 2 // Q and 'vw_span_qc<0>(a, lds, stream, t_first, ntiles, flags)' in dispatch
     f = tmp_path / 'k.hip'
     f.write_text(src)
     out = tmp_path / 'k.s'
@@ -423,13 +384,12 @@ def test_octets_with_the_waves_split_over_the_channels(native, golden, tmp_path,
                         '-include', 'hip/hip_runtime.h', '-S', str(f), '-o', str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     asm = out.read_text()
-    assert re.search(r'ScratchSize: 0\b', asm), 'the channel-split octet kernel must not spill'
+    assert re.search(r'ScratchSize: 0\b', asm), 'the quad / octet kernel must not spill'
     ops = re.findall(r'^\s+([a-z0-9_]+)', asm, re.M)
-    assert ops.count('s_barrier') == 4 and ops.count('buffer_store_dwordx4') == M // 4
+    assert ops.count('flat_load_dwordx4') == 0, 'LDS reads fell back to flat loads'
+    assert ops.count('s_barrier') == (2 // Q) * 4 and ops.count('buffer_store_dwordx4') == (2 // Q) * (M // 4)
     assert ops.count('buffer_load_dwordx2') == 0 and ops.count('buffer_store_dwordx2') == 0
-    # fewer window reads per sum than the pair-per-wave form's 16-frame runs
-    monkeypatch.setenv('VND_WIN_OCTET_SPLIT', '0')
-    pairs16, lds16, fmas16 = native.window_kernel_source(offs, idx, w, mode, 16, 512, with_traffic=True)
-    monkeypatch.delenv('VND_WIN_OCTET_SPLIT')
-    _, lds32, fmas32 = native.window_kernel_source(offs, idx, w, mode, 32, 512, with_traffic=True)
-    assert lds32 / fmas32 < 0.85 * lds16 / fmas16
+    # VND_WIN_QUAD=0: a workgroup per channel PAIR (8-byte pieces)
+    monkeypatch.setenv('VND_WIN_QUAD', '0')
+    pairs = native.window_kernel_source(offs, idx, w, mode, M, 256)
+    assert _macro(pairs, 'VW_Q') == 0 and _macro(pairs, 'VW_R') == 256 + _macro(pairs, 'VW_DE')

@@ -459,9 +459,9 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     //  the same tables on planar channel pairs run 0.33 against 0.39: tools/c8_win_try.py, profiles/r03_cfg5_request_floor.txt)
     const int win_wide_env = spec_env("VND_WIN_WIDE", 0);
     const bool win_c = C == 2 || (C % 2 == 0 && (win_wide_env != 0 || vw >= 2));
-    // signals of 4k channels: the window form on channel QUADS (VW_Q, vw_span_q: a workgroup moves 16 bytes of every frame, half
-    // its lanes per channel pair, 16-frame runs so that two workgroups of 256 lanes share a CU) - VND_WIN_QUAD=0 keeps the
-    // pair-read kernel (or, with VND_WIN_WIDE=1 / variant bits 5-7, the window form on channel pairs)
+    // signals of 4k channels: the window form on channel QUADS / OCTETS (VW_Q, vw_span_qc: a workgroup moves 16 / 32 bytes of every
+    // frame, a wave per channel) - VND_WIN_QUAD=0 keeps the pair-read kernel (or, with VND_WIN_WIDE=1 / variant bits 5-7, the
+    // window form on channel pairs)
     const bool win_quad = C % 4 == 0 && Cx == C && !pointwise && spec_env("VND_WIN_QUAD", 1) != 0;
     // (a geometry whose build failed or spilled is remembered in the table's module map: skipped, the next best taken)
     const bool nt_big = batch * n * C * (int64_t)sizeof(float) >= ((int64_t)spec_env("VND_NT_MIN_MB", 64) << 20);
@@ -478,21 +478,13 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
         return it != t->spec_modules.end() && it->second->failed;
     };
     const bool win_mode_ok = win_m > 0 && rr_hint == 0 && (mode == VND_MODE_FAST || win_exact || (win_quad && win_exact_env != 0));
-    // (8k channels: two neighbouring quads - with 8 channels whole frames, whole cache lines - per workgroup of 512 lanes when that fits)
-    const int quad_m = vw >= 2 ? win_m : spec_env("VND_WIN_QUAD_M", 16);
-    // (... and its waves split over the CHANNELS - vw_span_qc: one channel's accumulators per lane, 32-frame runs on the same tile;
-    //  VND_WIN_OCTET_SPLIT: 0 never, 1 (default) where the 32-frame ring fits: cfg5 fast 0.335 -> 0.319 ms (+4.9 %), exact 0.430 ->
-    //  0.390 (+9.8 %), tools/c8_quad_win_try.py; quads likewise)
-    if (win_mode_ok && win_quad && C % 8 == 0 && spec_env("VND_WIN_OCTET", 1) != 0 && spec_env("VND_WIN_OCTET_SPLIT", 1) != 0)
-        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, vw >= 2 ? win_m : spec_env("VND_WIN_OCTET_SPLIT_M", 32), attempt == 1, false,
-                                 &p.cfg, rejected, 2, false, mode == VND_MODE_EXACT, true);
-    if (!picked && win_mode_ok && win_quad && C % 8 == 0 && spec_env("VND_WIN_OCTET", 1) != 0)
-        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, quad_m, attempt == 1, false, &p.cfg, rejected, 2);
-    if (!picked && win_mode_ok && win_quad && spec_env("VND_WIN_OCTET_SPLIT", 1) != 0)
-        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, vw >= 2 ? win_m : spec_env("VND_WIN_OCTET_SPLIT_M", 32), attempt == 1, false,
-                                 &p.cfg, rejected, 1, false, mode == VND_MODE_EXACT, true);
+    // (8k channels: two neighbouring quads - with 8 channels whole frames, whole cache lines - per workgroup of 512 lanes when that ring
+    //  fits, else and for 4k channels a quad per workgroup of 256; a wave per CHANNEL, 32-frame runs: vw_span_qc)
+    const int quad_m = vw >= 2 ? win_m : spec_env("VND_WIN_QUAD_M", 32);
+    if (win_mode_ok && win_quad && C % 8 == 0 && spec_env("VND_WIN_OCTET", 1) != 0)
+        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, quad_m, attempt == 1, false, &p.cfg, rejected, 2, false, mode == VND_MODE_EXACT);
     if (!picked && win_mode_ok && win_quad)
-        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, quad_m, attempt == 1, false, &p.cfg, rejected, 1);
+        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, quad_m, attempt == 1, false, &p.cfg, rejected, 1, false, mode == VND_MODE_EXACT);
     // plain stereo: the waves SPLIT over the two channels (VW_S, vw_span_s: a lane carries ONE channel's accumulators).
     // VND_WIN_SPLIT: 0 never; 1 (default) where it pays; 2 always, with the frames per lane of the plain form.
     //  * 32-frame runs, three waves per SIMD (three workgroups of 256 lanes per CU): cfg3 fast +2.0 / +2.4 % on two boxes, but
@@ -598,7 +590,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
             p.chunk_tiles = (int)w; p.chunk_len0 = (int)best_len0; p.chunks_per_stream = (int)cps; p.cus_per_xcd = cus / 8;
             p.chunk_len1 = (int)(w - best_len0); p.chunk_rounds = 2;
             if (len1_env >= 0 && per_cu >= 3 && best_len0 + len1_env < w) { p.chunk_len1 = len1_env; p.chunk_rounds = 3; }
-            p.stagger_ticks = std::max(0, spec_env("VND_WIN_STAGGER_TICKS", 0));
+            p.stagger_ticks = std::max(0, spec_env("VND_WIN_STAGGER_TICKS", 300));      // 3 us: about the first workgroup's ring fill - the later one loads while that one computes (tools/ablate/run_r4b.sh, run_r4c.sh)
             p.units = (uint32_t)(p.chunk_rounds * cus);
             p.nblocks = p.units;
         }
@@ -642,7 +634,7 @@ static vnd_status launch_spec(vnd_ctx *ctx, const vnd_taps *t, const SpecPlan &p
     a.tiles_total = p.tiles_total; a.tiles_per_span = p.tiles_per_span; a.spans = p.spans; a.nblocks = p.nblocks;
     a.units = p.units;
     a.chunk_tiles = p.chunk_tiles; a.chunk_len0 = p.chunk_len0; a.chunk_len1 = p.chunk_len1; a.chunks_per_stream = p.chunks_per_stream; a.cus_per_xcd = p.cus_per_xcd;
-    a.stagger_ticks = p.stagger_ticks; a.chunk_prio = spec_env("VND_WIN_CHUNK_PRIO", 0) != 0 ? 1 : 0;
+    a.stagger_ticks = p.stagger_ticks; a.chunk_prio = spec_env("VND_WIN_CHUNK_PRIO", 1) != 0 ? 1 : 0;
     if (epi != nullptr && p.cfg.epi) {
         a.epi_ms_encode = epi->ms_encode; a.epi_use_width = epi->use_width; a.epi_w_mid = epi->w_mid; a.epi_w_side = epi->w_side;
     }
@@ -1552,13 +1544,9 @@ vnd_status vnd_window_kernel_source(int32_t C, const int32_t *tap_offsets, const
         }
     }
     WinGeom g;
-    // (tables of 4k channels: the quad form, as the launches take it - VND_WIN_QUAD=0: channel pairs)
-    bool quad = C % 8 == 0 && spec_env("VND_WIN_QUAD", 1) != 0 && spec_env("VND_WIN_OCTET", 1) != 0 && spec_env("VND_WIN_OCTET_SPLIT", 1) != 0 &&
-                win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, 2, false, true);
-    quad = quad || (C % 8 == 0 && spec_env("VND_WIN_QUAD", 1) != 0 && spec_env("VND_WIN_OCTET", 1) != 0 &&
-                    win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, 2));
-    quad = quad || (C % 4 == 0 && spec_env("VND_WIN_QUAD", 1) != 0 && spec_env("VND_WIN_OCTET_SPLIT", 1) != 0 &&
-                    win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, 1, false, true));
+    // (tables of 4k channels: the quad / octet form, as the launches take it - VND_WIN_QUAD=0: channel pairs)
+    bool quad = C % 8 == 0 && spec_env("VND_WIN_QUAD", 1) != 0 && spec_env("VND_WIN_OCTET", 1) != 0 &&
+                win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, 2);
     quad = quad || (C % 4 == 0 && spec_env("VND_WIN_QUAD", 1) != 0 &&
                     win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, 1));
     const bool split = !quad && C == 2 && spec_env("VND_WIN_SPLIT", 0) != 0 &&
@@ -1566,7 +1554,7 @@ vnd_status vnd_window_kernel_source(int32_t C, const int32_t *tap_offsets, const
     if (!quad && !split && !win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g))
         return fail(VND_ERR_UNSUPPORTED, "this window geometry does not fit the LDS");
     SpecConfig cfg;
-    cfg.nt = threads; cfg.win = frames_per_lane; cfg.win_g = g.G; cfg.win_lds = (int)g.lds_bytes(); cfg.win_q = g.quad; cfg.win_s = g.split; cfg.win_qc = g.csplit;
+    cfg.nt = threads; cfg.win = frames_per_lane; cfg.win_g = g.G; cfg.win_lds = (int)g.lds_bytes(); cfg.win_q = g.quad; cfg.win_s = g.split;
     cfg.la = spec_env("VND_SPEC_LA", (split && frames_per_lane >= 64) ? (mode == VND_MODE_EXACT ? 3 : 2) : (frames_per_lane >= 32 ? 4 : 6));      // (as win_pick_config)
     cfg.win_xpose = spec_env("VND_WIN_XPOSE_PAIRS", 1) != 0 ? 1 : 0;
     cfg.exact = mode == VND_MODE_EXACT ? 1 : 0;
@@ -1628,7 +1616,7 @@ static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64
                          "nt_stores=%d mode=%d lds=%zuB workgroups=%u (%u units: %s per stream) threads=%d store_phase=%s",
                          sp.cfg.exact ? "_exact" : "", sp.cfg.win, sp.cfg.tile(), sp.cfg.la, sp.cfg.nt_stores, mode,
                          sp.cfg.lds_bytes(), sp.nblocks, sp.units, split, sp.cfg.nt,
-                         sp.cfg.win_s ? "planar waves=split-by-channel" : sp.cfg.win_qc ? (sp.cfg.win_q == 2 ? "planar pieces=channel-octets waves=split-by-channel" : "planar pieces=channel-quads waves=split-by-channel") : sp.cfg.win_q == 2 ? "frame-pairs pieces=channel-octets" : (sp.cfg.win_q ? "frame-pairs pieces=channel-quads" : (sp.cfg.win_xpose ? "frame-pairs" : "planar")));
+                         sp.cfg.win_s ? "planar waves=split-by-channel" : sp.cfg.win_q == 2 ? "planar pieces=channel-octets waves=split-by-channel" : (sp.cfg.win_q ? "planar pieces=channel-quads waves=split-by-channel" : (sp.cfg.win_xpose ? "frame-pairs" : "planar")));
                 return VND_OK;
             }
             snprintf(text, (size_t)len,

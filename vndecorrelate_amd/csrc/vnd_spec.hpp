@@ -48,10 +48,9 @@ struct SpecConfig {
     // win_g = entries one base register reaches, win_lds = its LDS footprint (the halo is the table's)
     int win = 0, win_g = 0, win_lds = 0, win_per_cu = 0;    // (win_per_cu: workgroups a CU holds - LDS and registers)
     int win_xpose = 0; // the store phase transposes through LDS as interleaved frame pairs (1) or as planar chunks (0: fewer registers)
-    int win_q = 0;     // window form on channel QUADS (1: signals of 4k channels, half the workgroup's lanes per channel pair) or OCTETS (2: 8k channels, a quarter)
-    int win_s = 0;     // window form with the waves SPLIT over the two channels of a stereo signal (three waves per SIMD)
-    int win_qc = 0;    // quads / octets with the waves split over the channels (32-frame runs)
-    int tile() const { return win ? (win_s ? nt / 2 : (win_q ? nt / ((win_qc ? 4 : 2) * win_q) : nt)) * win : 2 * nt * rr; }
+    int win_q = 0;     // window form on channel QUADS (1: signals of 4k channels, a quarter of the workgroup's lanes per channel) or OCTETS (2: 8k channels, an eighth)
+    int win_s = 0;     // window form with the waves SPLIT over the two channels of a stereo signal
+    int tile() const { return win ? (win_s ? nt / 2 : (win_q ? nt / (4 * win_q) : nt)) * win : 2 * nt * rr; }
     size_t lds_bytes() const
     {
         if (win) return (size_t)win_lds;
@@ -60,8 +59,8 @@ struct SpecConfig {
     }
     bool operator<(const SpecConfig &o) const
     {
-        return std::tie(nt, rr, pp, dd, la, nt_stores, exact, epi, bc, shift, win, win_g, win_xpose, win_q, win_s, win_qc) <
-               std::tie(o.nt, o.rr, o.pp, o.dd, o.la, o.nt_stores, o.exact, o.epi, o.bc, o.shift, o.win, o.win_g, o.win_xpose, o.win_q, o.win_s, o.win_qc);
+        return std::tie(nt, rr, pp, dd, la, nt_stores, exact, epi, bc, shift, win, win_g, win_xpose, win_q, win_s) <
+               std::tie(o.nt, o.rr, o.pp, o.dd, o.la, o.nt_stores, o.exact, o.epi, o.bc, o.shift, o.win, o.win_g, o.win_xpose, o.win_q, o.win_s);
     }
 };
 

@@ -31,10 +31,9 @@ struct WinGeom {
     int NB = 0;          // base registers per channel
     int plane = 0;       // bytes between chunk planes
     int npl = 2;         // input planes sets (1: mono input fanned out)
-    int quad = 0;        // 1: a workgroup takes a channel QUAD (16 bytes of every frame), half its lanes per pair; 2: an OCTET (32 bytes), a quarter
-    int split = 0;       // 1: stereo, half the workgroup's waves per CHANNEL (three waves per SIMD fit the registers)
-    int csplit = 0;      // 1 (with quad): the quad / octet's waves split over its CHANNELS (vw_span_qc)
-    int nh() const { return split ? nt / 2 : (quad ? nt / ((csplit ? 4 : 2) * quad) : nt); }   // lanes - and ring entries of a tile - per channel pair (per channel)
+    int quad = 0;        // 1: a workgroup takes a channel QUAD (16 bytes of every frame), a quarter of its lanes per CHANNEL; 2: an OCTET (32 bytes), an eighth
+    int split = 0;       // 1: stereo, half the workgroup's waves per CHANNEL
+    int nh() const { return split ? nt / 2 : (quad ? nt / (4 * quad) : nt); }   // lanes - and ring entries of a tile - per channel pair (split, quad: per channel)
     size_t lds_bytes() const { return (size_t)(quad ? 2 * quad : 1) * (size_t)npl * (size_t)(M / 4) * (size_t)plane; }
     int tile() const { return nh() * M; }
 };
@@ -42,20 +41,18 @@ struct WinGeom {
 inline int win_workgroups_per_cu(const WinGeom &g);
 
 // Geometry of the window kernel for a table; false when it does not fit (the caller keeps the pair-read kernel).
-inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size_t lds_limit, WinGeom *g, int quad = 0, bool split = false,
-                         bool csplit = false)
+inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size_t lds_limit, WinGeom *g, int quad = 0, bool split = false)
 {
-    if (csplit && (quad < 1 || split || nt % (256 * quad) != 0 || M * quad > 64)) return false;       // whole waves per channel
     if (split && (t.C != 2 || bc || quad || nt % 128 != 0)) return false;      // plain stereo, whole waves per channel
     if (!(M == 16 || M == 32 || M == 64) || nt % 64 != 0 || nt < 64 || nt > 1024 || G < 1) return false;
-    // the quad form: whole channel quads, whole waves per pair, a lane of a 64-frame access inside one entry
-    if (quad && (quad > 2 || t.C % (4 * quad) != 0 || bc || nt % (128 * quad) != 0 || M > 32)) return false;
+    // the quad / octet form: whole channel quads, whole waves per channel, a lane of a 64-frame access inside one entry
+    if (quad && (quad > 2 || t.C % (4 * quad) != 0 || bc || nt % (256 * quad) != 0 || M * quad > 64 || M > 32)) return false;
     // one lane's tap sum is straight-line code, M/2 packed instructions of 8 bytes per tap: beyond ~1000 taps per channel
     // pair it would be megabytes of code for hipRTC and the 64 KB instruction cache (cfg3's 256 taps: 33 KB) - such
     // tables keep the pair-read form
     if ((int64_t)t.idx.size() * M > 32768) return false;
     if (t.C < 2 || (t.C & 1) || (bc && t.C != 2)) return false;      // whole channel pairs
-    g->M = M; g->nt = nt; g->G = G; g->npl = bc ? 1 : 2; g->C = t.C; g->quad = quad; g->split = split ? 1 : 0; g->csplit = csplit ? 1 : 0;
+    g->M = M; g->nt = nt; g->G = G; g->npl = bc ? 1 : 2; g->C = t.C; g->quad = quad; g->split = split ? 1 : 0;
     const int nh = g->nh();
     const int qc = M / 4;
     auto lay_out = [&](int de) {
@@ -159,14 +156,13 @@ inline std::string win_taps_channel_name(int pg, int ch)
 }
 
 // vw_taps_of<PG>(): the pair's function by its number, and VW_DISPATCH: the kernel's span loop instantiated per channel pair
-inline std::string win_taps_dispatch(const SpecTable &t, int quad = 0)
+inline std::string win_taps_dispatch(const SpecTable &t)
 {
     std::string s = "template <int PG> __device__ __forceinline__ void vw_taps_of(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
     for (int pg = 0; pg < t.C / 2; ++pg)
         spec_append(s, "    %sif constexpr (PG == %d) %s(b, o0, o1);\n", pg ? "else " : "", pg, win_taps_name(pg).c_str());
     s += "}\n#define VW_DISPATCH(pg) switch (pg) {";
-    if (quad) for (int qd = 0; qd < t.C / (4 * quad); ++qd) spec_append(s, " case %d: vw_span_q<%d>(a, lds, stream, t_first, ntiles, flags); break;", qd, qd);
-    else for (int pg = 0; pg < t.C / 2; ++pg) spec_append(s, " case %d: vw_span<%d>(a, lds, stream, t_first, ntiles, flags); break;", pg, pg);
+    for (int pg = 0; pg < t.C / 2; ++pg) spec_append(s, " case %d: vw_span<%d>(a, lds, stream, t_first, ntiles, flags); break;", pg, pg);
     s += " default: break; }\n";
     return s;
 }
@@ -462,27 +458,24 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
     spec_append(s, "#define VW_NT %d\n#define VW_M %d\n#define VW_R %d\n#define VW_G %d\n#define VW_NB %d\n#define VW_DE %d\n#define VW_PLANE %d\n#define VW_LA %d\n",
                 g.nt, g.M, g.R, g.G, g.NB, g.DE, g.plane, c.la);
     spec_append(s, "#define VW_NT_STORES %d\n#define VW_EPI %d\n#define VW_BC %d\n#define VW_EXACT %d\n#define VW_C %d\n", c.nt_stores, c.epi, c.bc, c.exact, g.C);
-    spec_append(s, "#define VW_Q %d\n#define VW_S %d\n#define VW_QCS %d\n", g.quad, g.split, g.csplit);
+    spec_append(s, "#define VW_Q %d\n#define VW_S %d\n", g.quad, g.split);
     spec_append(s, "#define VW_OPAQUE %d\n", spec_env("VND_WIN_OPAQUE", 1) != 0 ? 1 : 0);      // (plain form: per-access constants kept out of the tile loop's registers)
     // split form: how many of a wave's M/4 refill accesses per tile are loaded late (at the start of the store phase that consumes
     // them) instead of a tile ahead: 64-frame runs keep half of them out of the tap phase's registers
     // (the fast mode's E / P accumulators are twice the exact mode's sums: all but one late there - hipRTC's build of cfg2's table
     //  spills 20-64 bytes with 12-14 of the 16 late and none with 15; 4 to 15 late run the same)
     spec_append(s, "#define VW_LATE %d\n", g.split ? std::min(std::max(spec_env("VND_WIN_SPLIT_LATE", g.M >= 64 ? (c.exact ? g.M / 8 : g.M / 4 - 1) : 0), 0), g.M / 4 - 1) : 0);
-    spec_append(s, "#define VW_CU_PAIRS %d\n", spec_env("VND_WIN_QUAD_CU_PAIRS", 0) != 0 ? 1 : 0);
     spec_append(s, "#define VW_NT_STORE_AUX %d\n", spec_env("VND_SPEC_STORE_AUX", 2));
     // the transposition as interleaved frame pairs (one 16-byte read-back per store, planes an odd number of slots apart) or as
     // planar chunks read back in 8-byte halves (VND_WIN_XPOSE_PAIRS=0: then 32-frame runs swizzle their lanes' pair indices)
     const int xpose = (!c.bc && c.win_xpose) ? 1 : 0;
     spec_append(s, "#define VW_XPOSE_PAIRS %d\n", xpose);
     spec_append(s, "#define VW_LANE_SWIZZLE %d\n", (g.M == 32 && spec_env("VND_WIN_LANE_SWIZZLE", 1) != 0) ? 1 : 0);
-    // diagnosis builds (WRONG results on purpose: no stores / every load from one place - see the kernel): only in a tuning session
     const char *tuning = getenv("VND_TUNING");
-    spec_append(s, "#define VW_DEBUG %d\n", (tuning && *tuning && *tuning != '0') ? spec_env("VND_WIN_DEBUG", 0) : 0);
     // prologue: loads a wave keeps in flight before its first staging write; the store phase's read-backs per batch; the last tile of a
     // workgroup's last unit skips its (useless) refill and the barrier behind it
     spec_append(s, "#define VW_FILL_BATCH %d\n#define VW_RB_BATCH %d\n#define VW_SKIP_FINAL %d\n", spec_env("VND_WIN_FILL_BATCH", 8), spec_env("VND_WIN_RB_BATCH", 1),
-                spec_env("VND_WIN_SKIP_FINAL", 0) != 0 ? 1 : 0);
+                spec_env("VND_WIN_SKIP_FINAL", 1) != 0 ? 1 : 0);
     spec_append(s, "#define VW_STAMP_PHASES %d\n", spec_env("VND_WIN_STAMP_PHASES", 1) != 0 ? 1 : 0);
     spec_append(s, "#define VW_STAMPS %d\n", (tuning && *tuning && *tuning != '0') ? std::min(std::max(spec_env("VND_WIN_STAMPS", 0), 0), 4096) : 0);
     // s_setprio of the store / refill phase (0: none): cfg2 +1.0 % fast, +0.5 % exact at 1, 2 or 3; cfg3 unchanged (tools/win_phase_try.py)
@@ -501,8 +494,8 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
     const std::string marker = "//@@VW_TAPS@@";
     const size_t at = fixed.find(marker);
     src += fixed.substr(0, at);
-    if (g.csplit) {
-        // channel-split quads / octets: one function per channel, the workgroup's 4Q of them picked by the wave's channel number
+    if (g.quad) {
+        // quads / octets: one function per channel, the workgroup's 4Q of them picked by the wave's channel number
         const int nch = 4 * g.quad;
         for (int pg = 0; pg < t.C / 2; ++pg)
             for (int ch = 0; ch < 2; ++ch) src += c.exact ? win_taps_function_exact(t, g, c.la, pg, ch) : win_taps_function(t, g, c.la, pg, ch);
@@ -524,7 +517,7 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
         src += "#define VW_DISPATCH(pg) vw_span_s(a, lds, stream, t_first, ntiles, flags);\n";
     } else {
         for (int pg = 0; pg < t.C / 2; ++pg) src += c.exact ? win_taps_function_exact(t, g, c.la, pg) : win_taps_function(t, g, c.la, pg);
-        src += win_taps_dispatch(t, g.quad);
+        src += win_taps_dispatch(t);
     }
     src += fixed.substr(at + marker.size());
     return src;
@@ -534,7 +527,7 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
 // (short streams: a ring is filled once per span)
 inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool small_tiles, bool bc, SpecConfig *out,
                             const std::function<bool(const SpecConfig &)> &rejected = nullptr, int quad = 0, bool split = false,
-                            bool exact = false, bool csplit = false)
+                            bool exact = false)
 {
     // the geometry that keeps the most waves on a CU (the ring is LDS-bound: tile + halo per workgroup), the larger
     // workgroup on a tie (the halo is shared by more lanes); short streams (small_tiles: a ring is filled once per
@@ -544,17 +537,17 @@ inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool sm
     int best_waves = 0;
     for (int k = 0; k < 6; ++k) {
         const int nt = nt_env > 0 ? nt_env : kShapes[k];
-        if (nt_env <= 0 && nt > 256 && quad < 2 && !split) continue;  // 512 lanes: octets (a quarter of them per channel pair) and the split form only
+        if (nt_env <= 0 && nt > 256 && quad < 2 && !split) continue;  // 512 lanes: octets (an eighth of them per channel) and the split form only
         if (nt_env <= 0 && nt == 384) continue;                       // (six waves land unevenly on four SIMDs: the split form 17 % slower than with 256 lanes)
         if (small_tiles && nt_env <= 0 && nt > (quad ? 256 * quad : (split ? spec_env("VND_WIN_SPLIT_SMALL_NT", 256) : 128))) continue;
         for (int G : {8, 4}) {
             if (g_env > 0) G = g_env;
             WinGeom g;
-            if (win_geometry(t, M, nt, G, bc, lds_limit, &g, quad, split, csplit)) {
+            if (win_geometry(t, M, nt, G, bc, lds_limit, &g, quad, split)) {
                 const int waves = win_workgroups_per_cu(g) * (nt / 64);
                 if (waves > best_waves) {
                     SpecConfig c;
-                    c.nt = nt; c.win = M; c.win_g = G; c.win_lds = (int)g.lds_bytes(); c.bc = bc ? 1 : 0; c.win_q = g.quad; c.win_s = g.split; c.win_qc = g.csplit;
+                    c.nt = nt; c.win = M; c.win_g = G; c.win_lds = (int)g.lds_bytes(); c.bc = bc ? 1 : 0; c.win_q = g.quad; c.win_s = g.split;
                     c.win_per_cu = win_workgroups_per_cu(g);
                     // reads kept in flight: each holds 4 registers, and 32-frame runs already live at ~240 of the 256 a lane
                     // has at two waves per SIMD (measured: 3 to 10 reads ahead run the same, tools/win_try.py)
@@ -562,7 +555,7 @@ inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool sm
                     c.rr = 0; c.pp = 0; c.dd = 0;
                     // the store phase: interleaved frame pairs (one 16-byte read-back per store) unless that build spilled
                     // before - it holds both channels' outputs interleaved - then planar chunks in 8-byte halves
-                    c.win_xpose = (bc || split || csplit) ? 0 : (spec_env("VND_WIN_XPOSE_PAIRS", 1) != 0 ? 1 : 0);      // (the split form's outputs cross waves as planar runs)
+                    c.win_xpose = (bc || split || quad) ? 0 : (spec_env("VND_WIN_XPOSE_PAIRS", 1) != 0 ? 1 : 0);      // (the split form's outputs cross waves as planar runs)
                     if (rejected && rejected(c)) {                  // a build of this geometry failed or spilled before
                         if (!c.win_xpose) continue;
                         // (cfg2's fast kernel: 44 bytes of spill with 4 reads ahead, none with 3 - and 3 to 10 run the same)
@@ -591,7 +584,7 @@ inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool sm
 inline std::string win_source_for(const SpecTable &t, const SpecConfig &cfg)
 {
     WinGeom g;
-    if (!win_geometry(t, cfg.win, cfg.nt, cfg.win_g, cfg.bc != 0, 160 * 1024, &g, cfg.win_q, cfg.win_s != 0, cfg.win_qc != 0)) return "#error window geometry does not fit\n";
+    if (!win_geometry(t, cfg.win, cfg.nt, cfg.win_g, cfg.bc != 0, 160 * 1024, &g, cfg.win_q, cfg.win_s != 0)) return "#error window geometry does not fit\n";
     return win_source(t, g, cfg);
 }
 
