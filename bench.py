@@ -316,6 +316,60 @@ def next_rows(torch, vnd, _native) -> dict:
         out['f1_decorrelate_exact'] = rec
     except Exception as exc:
         out['f1_decorrelate_exact'] = {'error': repr(exc)}
+    # f1 at pool scale: the whole stage (side-channel encode + RMS normaliser) over a resident pool of cfg2 signals in one call
+    try:
+        from oracle import vnd_oracle as O
+        vn = vnd.VelvetNoise(sample_rate_hz=SAMPLE_RATE, seed=1)
+        table = vn._device_table()
+        st = torch.cuda.current_stream().cuda_stream
+        rec = {}
+        for pool in (256, 128):
+            x = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1)
+            y = torch.empty_like(x)
+            ws_bytes = _native.decorrelate_workspace_bytes(pool, n, 2)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device='cuda')
+            for label, mode, normalize, bytes_per_sample in (('exact', vnd.MODE_EXACT, 1, 24), ('fast_fused', vnd.MODE_FAST, 1, 16)):
+                table.prepare(pool, n, 2, mode)
+
+                def run():
+                    table.decorrelate_device(x.data_ptr(), y.data_ptr(), pool, n, 2, mode=mode, ms_encode=True, width=None,
+                                             normalize=normalize, workspace_ptr=ws.data_ptr(), workspace_bytes=ws_bytes, stream=st)
+                for _ in range(5):
+                    run()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                reps = 20
+                for _ in range(reps):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / reps
+                moved = bytes_per_sample * pool * n * 2
+                worst = 0.0
+                for b in sorted({0, pool // 2, pool - 1}):
+                    want = O.decorrelate(x[b].cpu().numpy(), sample_rate_hz=SAMPLE_RATE, seed=1)
+                    got = y[b].cpu().numpy()
+                    if mode == vnd.MODE_EXACT:
+                        assert np.array_equal(got, want), f'f1_pool: exact stage differs from the oracle (stream {b})'
+                    else:
+                        worst = max(worst, float(np.max(np.abs(got.astype(np.float64) - want)) / np.max(np.abs(want))))
+                assert worst <= 5e-4, f'f1_pool: fused fast stage off by {worst:.2e} of peak'
+                rec[f'pool{pool}_{label}'] = {
+                    'ms_per_call': round(ms, 4), 'bytes_per_sample_moved': bytes_per_sample, 'achieved_GBs': round(moved / (ms * 1e-3) / 1e9, 1),
+                    'frac_of_8TBs': round(moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'Msamples_s': round(pool * n * 2 / (ms * 1e-3) / 1e6, 1),
+                    'parity': ('bit-identical to the oracle\'s whole stage on streams 0 / middle / last (asserted in this run)' if mode == vnd.MODE_EXACT
+                               else f'{worst:.1e} of peak from the oracle\'s stage (its RMS is the correctly rounded one: bar 5e-4)'),
+                    'launch': table.describe(pool, n, 2, mode)[:200]}
+            del x, y, ws
+            torch.cuda.empty_cache()
+        rec['what'] = ('vnd_decorrelate_f32_dev (MS encode + RMS normalise) over a resident pool of 10 s stereo signals, one call.  exact: convolution '
+                       'with the pointwise steps in its store phase (8 B/sample) + NumPy-order sums (x and y read once: 8) + scale pass (8) = 24 B/sample; '
+                       'pools below 256 streams take the block-parallel sums, whose per-block predictions the convolution leaves on its way; '
+                       'fast_fused: per-tile float64 partial sums in the store phase + scale pass = 16 B/sample')
+        out['f1_pool'] = rec
+    except Exception as exc:
+        out['f1_pool'] = {'error': repr(exc)}
     # fan-out: mono in, stereo out (decorrelation.py:431-432) on the cfg2 shape, device resident, throughput mode
     try:
         from vndecorrelate_amd.taps import function_path_arrays

@@ -8,6 +8,8 @@ at the boundary) stay within 1e-6 of the output peak - the north-star tolerance.
 import json
 import pathlib
 
+import os
+
 import numpy as np
 import pytest
 
@@ -788,3 +790,52 @@ def test_stage_batches_beyond_the_grid_limit(vnd):
     assert got.shape == x.shape
     for b in (0, 32767, 32768, 65535, 65536, 69999):
         assert np.array_equal(got[b], vn.decorrelate(x[b])), b
+
+
+def test_block_sums_from_the_convolutions_store_phase(vnd):
+    """Batches of 65 to 255 streams: the per-table window kernel's store phase leaves the per-block sums of squares of x and of
+    the finished y (the predictions the block-parallel exact sums start from), so rms_par_sum_kernel's pass over both arrays is not
+    run (decorrelate_dev, EpiFuse::blk_sum).  The stage's sums and output against the one-workgroup-per-stream kernel (variant
+    bit 19) bit for bit, streams with ties (16-bit audio), silent starts and growing levels among them, and three streams against
+    the oracle's whole stage; a launch the window kernel does not take (unprepared: generic kernel) gives the same bytes."""
+    import torch
+    from oracle import vnd_oracle as O
+    from vndecorrelate_amd import _native
+    ctx = _native.default_context()
+    vn = vnd.VelvetNoise(sample_rate_hz=48000, seed=1)
+    rng = np.random.default_rng(321)
+    batch, n = 96, 50000 + 37 * 2
+    x = rng.uniform(-1, 1, (batch, n, 2)).astype(np.float32)
+    x[1] = np.round(x[1] * 32767) / 32768                         # ties in most blocks
+    x[2, :20000] = 0                                               # silent start
+    x[3] *= np.linspace(0.001, 40, n, dtype=np.float32)[:, None]   # crossings late in the signal
+    x[4] *= 1e-4
+    st = torch.cuda.current_stream().cuda_stream
+    xd = torch.from_numpy(x).cuda()
+    ws_bytes = _native.decorrelate_workspace_bytes(batch, n, 2)
+    out = {}
+    for label, variant, prepare in (('generic', -1, False), ('per-stream', 1 << 19, True), ('from the store phase', -1, True),
+                                    ('block sums off', -1, True)):
+        table = _native.TapTable.create(ctx, *[getattr(vn._tap_arrays(), k) for k in ('tap_offsets', 'tap_index', 'tap_weight')], **vn._tap_arrays().kwargs())
+        ctx.set_variant(variant)
+        if prepare:
+            table.prepare(batch, n, 2, vnd.MODE_EXACT)
+            assert table.describe(batch, n, 2, vnd.MODE_EXACT).startswith('conv_spec_exact_window')
+        if label == 'block sums off':
+            os.environ['VND_EPI_BLOCK_SUMS'] = '0'
+        try:
+            yd = torch.empty_like(xd)
+            ws = torch.zeros(ws_bytes // 8 + 1, dtype=torch.float64, device='cuda')
+            table.decorrelate_device(xd.data_ptr(), yd.data_ptr(), batch, n, 2, mode=vnd.MODE_EXACT, ms_encode=True, width=None,
+                                     normalize=True, workspace_ptr=ws.data_ptr(), workspace_bytes=ws_bytes, stream=st)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop('VND_EPI_BLOCK_SUMS', None)
+            ctx.set_variant(-1)
+        out[label] = (ws[:4 * batch].cpu().numpy().copy(), yd.cpu().numpy())
+        table.close()
+    for label, (sums, y) in out.items():
+        assert np.array_equal(sums, out['per-stream'][0]), label
+        assert np.array_equal(y, out['per-stream'][1]), label
+    for b in (0, 1, 3):
+        assert np.array_equal(out['from the store phase'][1][b], O.decorrelate(x[b], sample_rate_hz=48000, seed=1)), b

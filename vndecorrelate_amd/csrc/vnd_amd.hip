@@ -403,6 +403,13 @@ struct EpiFuse {                 // non-null => launch the fused-epilogue instan
     int ms_encode, use_width, normalize;
     float w_mid, w_side;
     double *sink = nullptr;      // moments sink: [tiles][groups][8]; the output is reduced, not written
+    // exact RMS sums, block-parallel form: where the convolution may leave the per-block sums of squares ([batch][4][nblocks] doubles,
+    // the predictions rms_par_tally_kernel starts from) - the window form's store phase has x and the finished y at hand; *blk_done
+    // says whether it did (else rms_par_sum_kernel reads both arrays for them)
+    double *blk_sum = nullptr;
+    int nblocks = 0;
+    int rows_major = 0;          // 1: [stream][block][x0 x1 y0 y1] - rows for epilogue_reduce_kernel (the fused fast stage's sums)
+    int *path = nullptr;         // out: 0 a generic kernel ran, 1 the per-table kernel and it left the block sums, 2 the per-table kernel without them
 };
 
 // variant word, specialised kernel: bit 25 forces the generic kernel; bits 26-27 prefetch depth
@@ -417,7 +424,8 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     if (mode != VND_MODE_FAST && mode != VND_MODE_EXACT) { p.why = "neither the fast nor the exact mode"; return p; }
     // a fused epilogue is within scope when it is the pointwise steps alone (no sums, no moments sink) on a stereo output:
     // they ride in the per-table kernels' store phase (VS_EPI)
-    const bool pointwise = epi != nullptr && !epi->normalize && epi->sink == nullptr && C == 2;
+    // (... with the normaliser's sums too where the caller offers room for per-block sums: the window form's store phase leaves them)
+    const bool pointwise = epi != nullptr && (!epi->normalize || epi->blk_sum != nullptr) && epi->sink == nullptr && C == 2;
     // fan-out: a mono input through a stereo table is in scope (one LDS plane, VS_BC); wider fan-outs are not
     const bool bc = Cx == 1 && C == 2;
     if ((epi != nullptr && !pointwise) || (Cx != C && !bc)) { p.why = "fused epilogue or fan-out launch"; return p; }
@@ -637,6 +645,10 @@ static vnd_status launch_spec(vnd_ctx *ctx, const vnd_taps *t, const SpecPlan &p
     a.stagger_ticks = p.stagger_ticks; a.chunk_prio = spec_env("VND_WIN_CHUNK_PRIO", 1) != 0 ? 1 : 0;
     if (epi != nullptr && p.cfg.epi) {
         a.epi_ms_encode = epi->ms_encode; a.epi_use_width = epi->use_width; a.epi_w_mid = epi->w_mid; a.epi_w_side = epi->w_side;
+        // a wave of the plain 32-frame form owns one 2048-frame block of the sums (kParFrames)
+        if (epi->blk_sum != nullptr && p.cfg.win == 32 && !p.cfg.win_s && !p.cfg.win_q && p.cfg.tile() % kParFrames == 0) {
+            a.epi_blk_sum = epi->blk_sum; a.epi_nblocks = epi->nblocks; a.epi_rows_major = epi->rows_major;
+        }
     }
     void *params[] = {&a};
     hipError_t e = hipModuleLaunchKernel(m->fn, p.nblocks, 1, 1, p.cfg.nt, 1, 1, (unsigned)p.cfg.lds_bytes(), stream, params,
@@ -649,6 +661,7 @@ static vnd_status launch_spec(vnd_ctx *ctx, const vnd_taps *t, const SpecPlan &p
         return VND_OK;
     }
     *launched = true;
+    if (epi != nullptr && epi->path != nullptr) *epi->path = a.epi_blk_sum != nullptr ? 1 : 2;
     return VND_OK;
 }
 
@@ -1741,6 +1754,7 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
     e.ms_encode = ms_encode ? 1 : 0; e.use_width = use_width ? 1 : 0;
     e.w_mid = (float)(1.0 - width); e.w_side = (float)width;   // float32(python float), as NumPy's in-place multiply
     e.normalize = normalize ? 1 : 0; e.eps = eps;
+    e.wide = (((uintptr_t)y & 15) == 0 && ((uintptr_t)x & (Cx == 1 ? 7 : 15)) == 0 && (batch == 1 || n % 2 == 0) && spec_env("VND_EPI_WIDE", 1) != 0) ? 1 : 0;
     const dim3 grid((unsigned)epi_chunks(n), (unsigned)batch);
 
     // Fused form: the fast kernel applies the pointwise steps and writes one row of sums per tile.
@@ -1757,13 +1771,50 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
     const bool want_seq = (seq_ok || pair_ok) && (mode == VND_MODE_EXACT || normalize == VND_NORMALIZE_RMS_REFERENCE_ORDER);
     const bool fused = any && mode == VND_MODE_FAST && ctx->variant_nofuse == 0 && fast_epi_kernel(p) != nullptr &&
                        (!(ms_encode || use_width) || p.cg == 2) && !(want_seq && !(ms_encode || use_width));
+    // stereo: the reference-order sums parallel over the stream's 2048-frame blocks (vnd_epilogue.hpp, rms_par_*).  They start from
+    // per-block sums of squares (predictions of the running sum's binade) - which the window kernel's store phase leaves on its way
+    // (x still in the ring, the finished y in registers: EpiFuse::blk_sum) where that kernel runs; rms_par_sum_kernel reads both
+    // arrays for them otherwise.  Which form, by batch (tools/rms_batch_rate.py, 10 s signals, ms per stage: per-stream / block-parallel):
+    //   up to 64 streams the one-workgroup-per-stream kernel leaves most CUs dark (16: 0.49 / 0.17);
+    //   65 .. 255: it still fills less than every CU once (128: 0.80 / 0.82, and 0.66 once the block sums come from the convolution);
+    //   256 and more: it fills the chip by itself and reads the data once instead of twice (1024: 4.36 / 6.76).
+    // variant bit 19 keeps the per-stream kernel, bit 17 forces the block-parallel form (A/B runs).
+    const bool par_ok = want_seq && C == 2 && par_blocks(n) <= kParMaxBlocks && !(ctx->variant >= 0 && ((ctx->variant >> 19) & 1));
+    const bool par_forced = ctx->variant >= 0 && ((ctx->variant >> 17) & 1);
+    RArgs r{};
+    int conv_path = 0;                                     // EpiFuse::path of the convolution launch
+    if (par_ok) {
+        r.x = x; r.y = y; r.n = n; r.Cx = Cx; r.nblocks = (int32_t)par_blocks(n);
+        char *extra = (char *)((float *)((double *)workspace + batch * epi_rows_max(n) * 2 * C) + batch * C);
+        extra += (16 - ((uintptr_t)extra & 15)) & 15;
+        r.blk_sum = (double *)extra;
+        r.rec = (ParRec *)(r.blk_sum + batch * 4 * (int64_t)r.nblocks);
+        r.grp = (ParGrp *)(r.rec + batch * 4 * (int64_t)r.nblocks);
+        r.first = (float *)(r.grp + batch * 4 * (int64_t)r.nblocks);
+        r.partials = (double *)workspace;
+        r.prefixed = r.nblocks > kParPrefixBlocks ? 1 : 0;
+        r.wide = e.wide;
+    }
+    const bool want_blk = par_ok && (batch < 256 || par_forced) && spec_env("VND_EPI_BLOCK_SUMS", 1) != 0;
     bool sums_pending = false;                             // the sequential sums still have to run
     if (fused) {
         // with reference-order sums the fused kernel only applies the pointwise steps
         EpiFuse f{(double *)workspace, e.ms_encode, e.use_width, want_seq ? 0 : e.normalize, e.w_mid, e.w_side};
+        f.path = &conv_path;
+        if (want_blk && want_seq) { f.blk_sum = r.blk_sum; f.nblocks = r.nblocks; }
+        // the fully fused stage: the window kernel writes one row of sums per 2048-frame block where it runs (the generic fast
+        // kernel one per tile), and one streaming pass scales
+        else if (!want_seq && e.normalize && C == 2 && spec_env("VND_EPI_BLOCK_SUMS", 1) != 0) { f.blk_sum = (double *)workspace; f.nblocks = (int)par_blocks(n); f.rows_major = 1; }
         st = launch(ctx, t, x, y, batch, n, C, mode, stream, &f, Cx);
         if (st != VND_OK) return st;
         e.rows = p.tiles;
+        if (!want_seq && e.normalize && conv_path == 1) e.rows = (int32_t)par_blocks(n);
+        if (!want_seq && e.normalize && conv_path == 2) {
+            // (the pair-read per-table kernel took the launch: pointwise steps done, no sums - one more pass for them)
+            e.ms_encode = e.use_width = 0;
+            e.rows = (int32_t)epi_chunks(n);
+            hipLaunchKernelGGL(epilogue_pointwise_kernel, grid, dim3(kEpiThreads), 0, stream, e);
+        }
         sums_pending = want_seq;
     } else {
         // table-order modes: the pointwise steps ride in the ordered kernel's store phase when the
@@ -1773,6 +1824,8 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
                                ordered_epi_kernel(p, arithmetic_of(t, mode)) != nullptr;
         if (in_kernel) {
             EpiFuse f{nullptr, e.ms_encode, e.use_width, 0, e.w_mid, e.w_side};
+            f.path = &conv_path;
+            if (want_blk) { f.blk_sum = r.blk_sum; f.nblocks = r.nblocks; }
             st = launch(ctx, t, x, y, batch, n, C, mode, stream, &f, Cx);
             e.ms_encode = e.use_width = 0;                 // done
         } else {
@@ -1788,35 +1841,21 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
             hipLaunchKernelGGL(epilogue_pointwise_kernel, grid, dim3(kEpiThreads), 0, stream, e);
         sums_pending = seq;
     }
-    // stereo: the sums parallel over the stream's blocks (vnd_epilogue.hpp, rms_par_*); variant bit 19
-    // keeps the one-workgroup-per-stream kernel (A/B runs)
-    // (up to 64 streams: beyond that the one-workgroup-per-stream kernel fills the chip by itself and
-    // reads the data once instead of twice; bit 17 forces the block-parallel form for any batch)
-    const bool par_sums = sums_pending && C == 2 && !(ctx->variant >= 0 && ((ctx->variant >> 19) & 1)) &&
-                          par_blocks(n) <= kParMaxBlocks && (batch <= 64 || (ctx->variant >= 0 && ((ctx->variant >> 17) & 1)));
+    const bool blk_done = conv_path == 1 && want_blk;
+    const bool par_sums = sums_pending && par_ok && (batch <= 64 || par_forced || blk_done);
     if (par_sums) {
         e.rows = 1;
         e.exact_rms = 1;
         e.normalize = 1;
-        RArgs r{};
-        r.x = x; r.y = y; r.n = n; r.Cx = Cx; r.nblocks = (int32_t)par_blocks(n);
-        char *extra = (char *)(e.scales + batch * C);
-        extra += (16 - ((uintptr_t)extra & 15)) & 15;
-        r.blk_sum = (double *)extra;
-        r.rec = (ParRec *)(r.blk_sum + batch * 4 * (int64_t)r.nblocks);
-        r.grp = (ParGrp *)(r.rec + batch * 4 * (int64_t)r.nblocks);
-        r.first = (float *)(r.grp + batch * 4 * (int64_t)r.nblocks);
-        r.partials = e.partials;
-        r.prefixed = r.nblocks > kParPrefixBlocks ? 1 : 0;
         const dim3 pgrid((unsigned)r.nblocks, (unsigned)batch), tgrid((unsigned)r.nblocks, (unsigned)batch);     // tally: blocks 1.., plus block 0's chain
         const dim3 sgrid((unsigned)(batch * 4));
         if (Cx == 1) {
-            hipLaunchKernelGGL(rms_par_sum_kernel<true>, pgrid, dim3(kParThreads), 0, stream, r);
+            if (!blk_done) hipLaunchKernelGGL(rms_par_sum_kernel<true>, pgrid, dim3(kParThreads), 0, stream, r);
             if (r.prefixed) hipLaunchKernelGGL(rms_par_prefix_kernel, dim3((unsigned)(batch * 4)), dim3(kParThreads), 0, stream, r);
             hipLaunchKernelGGL(rms_par_tally_kernel<true>, tgrid, dim3(kParThreads), 0, stream, r);
             hipLaunchKernelGGL(rms_par_stitch_kernel<true>, sgrid, dim3(64), 0, stream, r);
         } else {
-            hipLaunchKernelGGL(rms_par_sum_kernel<false>, pgrid, dim3(kParThreads), 0, stream, r);
+            if (!blk_done) hipLaunchKernelGGL(rms_par_sum_kernel<false>, pgrid, dim3(kParThreads), 0, stream, r);
             if (r.prefixed) hipLaunchKernelGGL(rms_par_prefix_kernel, dim3((unsigned)(batch * 4)), dim3(kParThreads), 0, stream, r);
             hipLaunchKernelGGL(rms_par_tally_kernel<false>, tgrid, dim3(kParThreads), 0, stream, r);
             hipLaunchKernelGGL(rms_par_stitch_kernel<false>, sgrid, dim3(64), 0, stream, r);

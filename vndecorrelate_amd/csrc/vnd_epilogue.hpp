@@ -39,6 +39,7 @@ struct EArgs {
     int32_t normalize;
     int32_t exact_rms;               // sums are the reference's sequential float32 sums (one row per stream)
     float eps;
+    int32_t wide;                    // every stream of x and y starts 16-byte aligned (8-byte for a mono x): the sums kernel loads two frames per access
 };
 
 __device__ __forceinline__ double block_sum(double v, double *scratch)
@@ -442,6 +443,22 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
             const v4i ry = make_rsrc(ys + f0 * 2, (n - f0) * 8);
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
+                if (a.wide) {                                  // streams start 16-byte aligned: two frames per access
+#pragma unroll
+                    for (int k = 0; k < 4; k += 2) {
+                        const int fr = u * (BF / PER) + 4 * tid + k;
+                        const v4f ty = buf_load4(ry, fr * 8, 0, 0);
+                        yr[u][k] = v2f{ty.x, ty.y}; yr[u][k + 1] = v2f{ty.z, ty.w};
+                        if constexpr (MONO) {
+                            const v2f v = buf_load2(rx, fr * 4, 0, 0);
+                            xr[u][k] = v2f{v.x, v.x}; xr[u][k + 1] = v2f{v.y, v.y};
+                        } else {
+                            const v4f tx = buf_load4(rx, fr * 8, 0, 0);
+                            xr[u][k] = v2f{tx.x, tx.y}; xr[u][k + 1] = v2f{tx.z, tx.w};
+                        }
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int fr = u * (BF / PER) + 4 * tid + k;
@@ -548,6 +565,7 @@ struct RArgs {
     ParGrp *__restrict__ grp;        // [batch][4][nblocks]
     float *__restrict__ first;       // [batch][4]: the sum after block 0
     int32_t prefixed;                // blk_sum already holds EXCLUSIVE prefix sums (rms_par_prefix_kernel ran)
+    int32_t wide;                    // every stream of x and y starts 16-byte aligned: the staging loads are whole 16-byte accesses
     double *__restrict__ partials;   // [batch][4]: the sums, as the sequential kernel writes them
 };
 
@@ -561,15 +579,21 @@ __device__ __forceinline__ void par_stage(const RArgs &a, int64_t b, int blk, fl
     const float *ys = a.y + (b * a.n + f0) * 2;
     const v4i rx = make_rsrc(xs, (a.n - f0) * (MONO ? 4 : 8));
     const v4i ry = make_rsrc(ys, (a.n - f0) * 8);
-    // 8 bytes per access: a stream's first sample is only 8-byte aligned when n is odd
+    // 8 bytes per access where a stream's first sample is only 8-byte aligned (n odd, or a misaligned base): a.wide says when whole
+    // 16-byte accesses are safe - they move the same bytes at 1.4-1.8x the rate (MI355X_MICROARCH.md: 8-byte accesses 0.54-0.70x)
     v4f yv[2][2], xv[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {                         // frames 4*tid + 1024*u + {0..3}
         const int fr = 4 * tid + 1024 * u;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const v2f y0 = buf_load2(ry, (fr + 2 * h) * 8, 0, 0), y1 = buf_load2(ry, (fr + 2 * h + 1) * 8, 0, 0);
-            yv[u][h] = v4f{y0.x, y0.y, y1.x, y1.y};
+            if (a.wide) {
+                yv[u][h] = buf_load4(ry, (fr + 2 * h) * 8, 0, 0);
+                if constexpr (!MONO) { xv[u][h] = buf_load4(rx, (fr + 2 * h) * 8, 0, 0); continue; }
+            } else {
+                const v2f y0 = buf_load2(ry, (fr + 2 * h) * 8, 0, 0), y1 = buf_load2(ry, (fr + 2 * h + 1) * 8, 0, 0);
+                yv[u][h] = v4f{y0.x, y0.y, y1.x, y1.y};
+            }
             if constexpr (MONO) {
                 const float m0 = buf_load1(rx, (fr + 2 * h) * 4, 0, 0), m1 = buf_load1(rx, (fr + 2 * h + 1) * 4, 0, 0);
                 xv[u][h] = v4f{m0, m0, m1, m1};

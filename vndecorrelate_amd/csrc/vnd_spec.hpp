@@ -368,6 +368,8 @@ struct SpecArgs {
     // window form only (VWArgs): a small launch's CU chunks - see vnd_win_kernel.inc
     int chunk_tiles, chunk_len0, chunks_per_stream, cus_per_xcd;
     int stagger_ticks, chunk_prio, chunk_len1;
+    double *epi_blk_sum;          // VW_EPI with 32-frame runs: per-block sums of squares for the block-parallel exact RMS sums
+    int epi_nblocks, epi_rows_major;
 };
 
 struct SpecModule {
