@@ -370,6 +370,11 @@ def test_mono_fan_out_through_the_specialised_kernels(env, golden, which):
             for mode in (d.MODE_FAST, d.MODE_EXACT):
                 launch = table.describe(pool, n, 1, mode)
                 assert launch.startswith('conv_spec'), launch
+                if which == 'function_path':
+                    # round 4: the window forms - fast: the plain form with ONE read stream for both output channels (their taps lie
+                    # almost alike: win_taps_function_merged), 16-byte mono loads; exact: 64-frame runs, a wave per OUTPUT channel,
+                    # the input staged into both plane sets (vw_span_s, VW_BC)
+                    assert '_window' in launch and ('frames_per_lane=32' in launch if mode == d.MODE_FAST else 'waves=split-by-channel' in launch), launch
                 y = table.convolve_host(x, mode)
                 if mode == d.MODE_EXACT:
                     assert np.array_equal(y, want), (which, spans)

@@ -501,8 +501,14 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     //    profiles/r03_fp32_issue_rate.txt) fit two waves per SIMD only in this form: VND_MODE_EXACT on function-path tables
     //    +14-16 % at cfg3 (0.579 -> 0.497 ms), +6 % at cfg2 - taken there; class-path tables and the fast mode spill at 64
     //    frames (rejected builds fall back to the plain form) (tools/win_split_try.py, profiles/r03_split_waves.txt)
+    // a mono input fanned out, fast mode: the plain form with ONE read stream for both output channels (win_taps_function_merged:
+    // the two channels' taps lie almost alike, their windows' union is little more than one channel's - 1.48 B of LDS per FMA)
+    if (!picked && win_mode_ok && bc && mode == VND_MODE_FAST && vw == 0 && spec_env("VND_WIN_FANOUT_MERGED", 1) != 0)
+        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, true, &p.cfg, rejected);
     const int split_env = spec_env("VND_WIN_SPLIT", 1);
-    const bool split_scope = C == 2 && Cx == 2 && !pointwise;
+    // (a mono input fanned out rides the same form: its one channel staged into both plane sets, VW_BC - cfg1's shape 0.177 -> 0.15 ms
+    //  for 128 x 10 s against the pair-read form, tools/fanout_win_try.py; VND_WIN_SPLIT_FANOUT=0 keeps that)
+    const bool split_scope = C == 2 && (Cx == 2 || (bc && spec_env("VND_WIN_SPLIT_FANOUT", 1) != 0)) && !pointwise;
     //    In the FAST mode (E and P: 128 accumulator registers) the 64-frame split form needs its refill loaded late (VW_LATE: 15
     //    of a wave's 16 accesses per tile at the start of the store phase that consumes them, not a tile ahead) and the per-access
     //    constants kept out of the tile loop's registers: cfg3 +3-4.5 % (0.457 -> 0.437 ms), cfg2 +3.8 % (0.195 -> 0.188 ms,
@@ -510,9 +516,9 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     const bool exact_now = mode == VND_MODE_EXACT;
     if (!picked && win_mode_ok && split_scope && split_env == 1 && vw == 0 &&
         ((exact_now && !t->spec_table.has_seg) || (mode == VND_MODE_FAST && spec_env("VND_WIN_SPLIT_FAST", 1) != 0)))
-        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, 64, attempt == 1, false, &p.cfg, rejected, 0, true, exact_now);
+        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, 64, attempt == 1, bc, &p.cfg, rejected, 0, true, exact_now);
     if (!picked && win_mode_ok && split_scope && split_env == 2)
-        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, false, &p.cfg, rejected, 0, true, exact_now);
+        picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, bc, &p.cfg, rejected, 0, true, exact_now);
     if (!picked && win_mode_ok && win_c && (!bc || vw >= 2))
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, bc, &p.cfg, rejected);
     if (!picked && !spec_pick_config(t->spec_table, (size_t)ctx->lds_limit, rr_hint, dd_hint, &p.cfg, attempt == 1 || C != 2, bc, mode == VND_MODE_EXACT)) { p.why = "halo does not fit the ring"; return p; }
@@ -1564,13 +1570,18 @@ vnd_status vnd_window_kernel_source(int32_t C, const int32_t *tap_offsets, const
                     win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, 1));
     const bool split = !quad && C == 2 && spec_env("VND_WIN_SPLIT", 0) != 0 &&
                        win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, 0, true);
-    if (!quad && !split && !win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g))
+    // (VND_WIN_SOURCE_FANOUT=1: the source of a mono input's fan-out launch through a stereo table - VW_BC)
+    const bool bc = C == 2 && spec_env("VND_WIN_SOURCE_FANOUT", 0) != 0;
+    if (bc && !win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), true, 160 * 1024, &g, 0, split))
+        return fail(VND_ERR_UNSUPPORTED, "this window geometry does not fit the LDS");
+    if (!bc && !quad && !split && !win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g))
         return fail(VND_ERR_UNSUPPORTED, "this window geometry does not fit the LDS");
     SpecConfig cfg;
     cfg.nt = threads; cfg.win = frames_per_lane; cfg.win_g = g.G; cfg.win_lds = (int)g.lds_bytes(); cfg.win_q = g.quad; cfg.win_s = g.split;
     cfg.la = spec_env("VND_SPEC_LA", (split && frames_per_lane >= 64) ? (mode == VND_MODE_EXACT ? 3 : 2) : (frames_per_lane >= 32 ? 4 : 6));      // (as win_pick_config)
     cfg.win_xpose = spec_env("VND_WIN_XPOSE_PAIRS", 1) != 0 ? 1 : 0;
     cfg.exact = mode == VND_MODE_EXACT ? 1 : 0;
+    cfg.bc = bc ? 1 : 0;
     if (lds_bytes_per_tile || fmas_per_tile) {
         size_t lb = 0, fm = 0;
         if (cfg.exact) win_traffic_exact(t, frames_per_lane, &lb, &fm);

@@ -30,7 +30,7 @@ struct WinGeom {
     int R = 0;           // ring entries
     int NB = 0;          // base registers per channel
     int plane = 0;       // bytes between chunk planes
-    int npl = 2;         // input planes sets (1: mono input fanned out)
+    int npl = 2;         // plane sets in LDS: one per output channel (a mono input fills only the first - the second is where channel 1's runs cross in the store phase)
     int quad = 0;        // 1: a workgroup takes a channel QUAD (16 bytes of every frame), a quarter of its lanes per CHANNEL; 2: an OCTET (32 bytes), an eighth
     int split = 0;       // 1: stereo, half the workgroup's waves per CHANNEL
     int nh() const { return split ? nt / 2 : (quad ? nt / (4 * quad) : nt); }   // lanes - and ring entries of a tile - per channel pair (split, quad: per channel)
@@ -43,7 +43,7 @@ inline int win_workgroups_per_cu(const WinGeom &g);
 // Geometry of the window kernel for a table; false when it does not fit (the caller keeps the pair-read kernel).
 inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size_t lds_limit, WinGeom *g, int quad = 0, bool split = false)
 {
-    if (split && (t.C != 2 || bc || quad || nt % 128 != 0)) return false;      // plain stereo, whole waves per channel
+    if (split && (t.C != 2 || quad || nt % 128 != 0)) return false;            // a stereo table, whole waves per channel
     if (!(M == 16 || M == 32 || M == 64) || nt % 64 != 0 || nt < 64 || nt > 1024 || G < 1) return false;
     // the quad / octet form: whole channel quads, whole waves per channel, a lane of a 64-frame access inside one entry
     if (quad && (quad > 2 || t.C % (4 * quad) != 0 || bc || nt % (256 * quad) != 0 || M * quad > 64 || M > 32)) return false;
@@ -52,7 +52,7 @@ inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size
     // tables keep the pair-read form
     if ((int64_t)t.idx.size() * M > 32768) return false;
     if (t.C < 2 || (t.C & 1) || (bc && t.C != 2)) return false;      // whole channel pairs
-    g->M = M; g->nt = nt; g->G = G; g->npl = bc ? 1 : 2; g->C = t.C; g->quad = quad; g->split = split ? 1 : 0;
+    g->M = M; g->nt = nt; g->G = G; g->npl = 2; g->C = t.C; g->quad = quad; g->split = split ? 1 : 0;
     const int nh = g->nh();
     const int qc = M / 4;
     auto lay_out = [&](int de) {
@@ -73,7 +73,7 @@ inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size
         while (units % mod != (res >= 0 ? res : res_rule)) ++units;
         g->plane = units * 16;
         if ((size_t)(qc - 1) * g->plane + (size_t)G * 16 >= 65536) return false;  // ds offset field
-        if ((size_t)qc * g->plane >= 65536 && !bc) return false;                   // channel 1's planes as an immediate
+        if ((size_t)qc * g->plane >= 65536) return false;                          // channel 1's planes as an immediate
         return g->lds_bytes() <= lds_limit;
     };
     const int de = (t.max_index + M - 1) / M;
@@ -336,6 +336,74 @@ inline void win_traffic_exact(const SpecTable &t, int M, size_t *lds_bytes, size
     }
 }
 
+// A mono input fanned out (VW_BC, plain form): both output channels read the SAME plane, and the two channels of a velvet table
+// place their taps almost alike (the same segment grid, jittered) - so ONE read stream over the union of both channels' windows feeds
+// both channels' FMAs: cfg2's table 178 reads per tile and lane instead of 157 + 160, 1.48 B of LDS per FMA instead of 2.64.  Each
+// channel keeps its own E / P chains in ascending offset order: the results are those of a pass per channel, bit for bit.
+inline std::string win_taps_function_merged(const SpecTable &t, const WinGeom &g, int la, int pg = 0)
+{
+    const int M = g.M;
+    std::string s;
+    s += "__device__ __forceinline__ void " + win_taps_name(pg) + "(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
+    spec_append(s, "    v4f q[%d];\n    v2f E0[%d], P0[%d], E1[%d], P1[%d];\n    float O00, OL0, O01, OL1;\n", la + 1, M / 2, M / 2, M / 2, M / 2);
+    struct Rd { int o; std::vector<std::pair<int, WinOp>> ops; };           // (channel, op)
+    std::map<int, Rd> by_o;
+    for (int ch = 0; ch < 2; ++ch)
+        for (const WinRead &r : win_schedule(t, 2 * pg + ch, M)) {
+            Rd &rd = by_o[r.o];
+            rd.o = r.o;
+            for (const WinOp &op : r.ops) rd.ops.push_back({ch, op});
+        }
+    std::vector<Rd> reads;
+    for (auto &kv : by_o) reads.push_back(std::move(kv.second));
+    auto emit_read = [&](size_t k) {
+        const int dE = reads[k].o / M, rr = (reads[k].o % M) / 4, kb = dE / g.G;
+        spec_append(s, "    q[%zu] = VW_RD(b[0][%d], %d);\n", k % (size_t)(la + 1), kb, (dE - kb * g.G) * 16 + rr * g.plane);
+    };
+    std::vector<char> e_used[2] = {std::vector<char>(M / 2, 0), std::vector<char>(M / 2, 0)}, p_used[2] = {std::vector<char>(M / 2, 0), std::vector<char>(M / 2, 0)};
+    bool o0_used[2] = {false, false}, ol_used[2] = {false, false};
+    for (size_t k = 0; k < std::min(reads.size(), (size_t)la); ++k) emit_read(k);
+    for (size_t k = 0; k < reads.size(); ++k) {
+        if (k + la < reads.size()) emit_read(k + la);
+        const std::string qk = "q[" + std::to_string(k % (size_t)(la + 1)) + "]";
+        for (const auto &cop : reads[k].ops) {
+            const int ch = cop.first;
+            const WinOp &op = cop.second;
+            const std::string w = spec_float(op.w), c = std::to_string(ch);
+            if (op.kind <= 1) {
+                const std::string acc = std::string(op.kind == 0 ? "E" : "P") + c + "[" + std::to_string(op.acc) + "]";
+                const std::string x = qk + (op.half ? ".zw" : ".xy");
+                char &used = op.kind == 0 ? e_used[ch][op.acc] : p_used[ch][op.acc];
+                if (used) spec_append(s, "    %s = VW_FMA(%s, %s, %s);\n", acc.c_str(), x.c_str(), w.c_str(), acc.c_str());
+                else spec_append(s, "    %s = VW_MUL(%s, %s);\n", acc.c_str(), x.c_str(), w.c_str());
+                used = 1;
+            } else {
+                const bool is0 = op.kind == 2;
+                const std::string acc = std::string(is0 ? "O0" : "OL") + c;
+                const std::string x = qk + (is0 ? (op.half ? ".w" : ".y") : (op.half ? ".z" : ".x"));
+                bool &used = is0 ? o0_used[ch] : ol_used[ch];
+                if (used) spec_append(s, "    %s = __builtin_fmaf(%s, %s, %s);\n", acc.c_str(), x.c_str(), w.c_str(), acc.c_str());
+                else spec_append(s, "    %s = %s * %s;\n", acc.c_str(), x.c_str(), w.c_str());
+                used = true;
+            }
+        }
+        s += "    VW_SB;\n";
+    }
+    for (int ch = 0; ch < 2; ++ch)
+        for (int j = 0; j < M; ++j) {
+            const std::string c = std::to_string(ch);
+            std::string ev = e_used[ch][j / 2] ? ("E" + c + "[" + std::to_string(j / 2) + "]." + ((j & 1) ? "y" : "x")) : std::string();
+            std::string ov;
+            if (j == 0) { if (o0_used[ch]) ov = "O0" + c; }
+            else if (j == M - 1) { if (ol_used[ch]) ov = "OL" + c; }
+            else if (p_used[ch][(j - 1) / 2]) ov = "P" + c + "[" + std::to_string((j - 1) / 2) + "]." + ((j & 1) ? "x" : "y");
+            const std::string rhs = ev.empty() ? (ov.empty() ? std::string("0.0f") : ov) : (ov.empty() ? ev : ev + " + " + ov);
+            spec_append(s, "    o%d[%d] = %s;\n", ch, j, rhs.c_str());
+        }
+    s += "}\n";
+    return s;
+}
+
 inline std::string win_taps_function_exact(const SpecTable &t, const WinGeom &g, int la, int pg = 0, int only_ch = -1)
 {
     const int M = g.M;
@@ -468,7 +536,7 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
     spec_append(s, "#define VW_NT_STORE_AUX %d\n", spec_env("VND_SPEC_STORE_AUX", 2));
     // the transposition as interleaved frame pairs (one 16-byte read-back per store, planes an odd number of slots apart) or as
     // planar chunks read back in 8-byte halves (VND_WIN_XPOSE_PAIRS=0: then 32-frame runs swizzle their lanes' pair indices)
-    const int xpose = (!c.bc && c.win_xpose) ? 1 : 0;
+    const int xpose = c.win_xpose ? 1 : 0;
     spec_append(s, "#define VW_XPOSE_PAIRS %d\n", xpose);
     spec_append(s, "#define VW_LANE_SWIZZLE %d\n", (g.M == 32 && spec_env("VND_WIN_LANE_SWIZZLE", 1) != 0) ? 1 : 0);
     const char *tuning = getenv("VND_TUNING");
@@ -516,7 +584,8 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
         src += "template <int PG> __device__ void vw_taps_of(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M]);      // (vw_span: not instantiated)\n";
         src += "#define VW_DISPATCH(pg) vw_span_s(a, lds, stream, t_first, ntiles, flags);\n";
     } else {
-        for (int pg = 0; pg < t.C / 2; ++pg) src += c.exact ? win_taps_function_exact(t, g, c.la, pg) : win_taps_function(t, g, c.la, pg);
+        const bool merged = c.bc && !c.exact && spec_env("VND_WIN_FANOUT_MERGED", 1) != 0;      // (one read stream for both channels of a mono input)
+        for (int pg = 0; pg < t.C / 2; ++pg) src += c.exact ? win_taps_function_exact(t, g, c.la, pg) : (merged ? win_taps_function_merged(t, g, c.la, pg) : win_taps_function(t, g, c.la, pg));
         src += win_taps_dispatch(t);
     }
     src += fixed.substr(at + marker.size());
@@ -555,9 +624,19 @@ inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool sm
                     c.rr = 0; c.pp = 0; c.dd = 0;
                     // the store phase: interleaved frame pairs (one 16-byte read-back per store) unless that build spilled
                     // before - it holds both channels' outputs interleaved - then planar chunks in 8-byte halves
-                    c.win_xpose = (bc || split || quad) ? 0 : (spec_env("VND_WIN_XPOSE_PAIRS", 1) != 0 ? 1 : 0);      // (the split form's outputs cross waves as planar runs)
+                    c.win_xpose = (split || quad) ? 0 : (spec_env("VND_WIN_XPOSE_PAIRS", 1) != 0 ? 1 : 0);      // (the split form's outputs cross waves as planar runs)
                     if (rejected && rejected(c)) {                  // a build of this geometry failed or spilled before
-                        if (!c.win_xpose) continue;
+                        if (!c.win_xpose) {
+                            // (the split form with 64-frame runs lives within a few registers of its budget: one read less in flight
+                            //  frees four - a mono input's build spills 12-20 bytes with two reads ahead and none with one)
+                            bool found = false;
+                            if (split && M >= 64 && spec_env("VND_SPEC_LA", -1) < 0)
+                                while (!found && c.la > 1) { c.la -= 1; found = !rejected(c); }
+                            if (!found) continue;
+                            best_waves = waves;
+                            *out = c;
+                            continue;
+                        }
                         // (cfg2's fast kernel: 44 bytes of spill with 4 reads ahead, none with 3 - and 3 to 10 run the same)
                         bool found = false;
                         if (c.la > 3 && spec_env("VND_SPEC_LA", -1) < 0) {
