@@ -22,19 +22,28 @@ from vndecorrelate_amd.taps import function_path_arrays
 
 mine = int(args[0]) if args else 128
 n = int(args[1]) if len(args) > 1 else 48000
-mode = vnd.MODE_FAST
+CH = 2
+mode = vnd.MODE_EXACT if os.environ.get('STAMPS_MODE') == 'exact' else vnd.MODE_FAST
 ctx = _native.default_context()
-arr = function_path_arrays(vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1))
+which = os.environ.get('STAMPS_TABLE', 'cfg2')
+if which == 'cfg5':
+    CH = 8
+    fir = vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=64, num_outs=8, sample_rate_hz=96000, seed=1)
+elif which == 'cfg3':
+    fir = vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=128, num_outs=2, sample_rate_hz=48000, log_distribution_strength=0.0, seed=1)
+else:
+    fir = vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1)
+arr = function_path_arrays(fir)
 table = _native.TapTable.create(ctx, arr.tap_offsets, arr.tap_index, arr.tap_weight)
-buffers = max(2, int(np.ceil(600e6 / (mine * n * 2 * 4 * 2))))
-xs = [torch.empty((mine, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1) for _ in range(buffers)]
+buffers = max(2, int(np.ceil(600e6 / (mine * n * CH * 4 * 2))))
+xs = [torch.empty((mine, n, CH), dtype=torch.float32, device='cuda').uniform_(-1, 1) for _ in range(buffers)]
 ys = [torch.empty_like(xs[0]) for _ in range(buffers)]
-table.prepare(mine, n, 2, mode)
-print(table.describe(mine, n, 2, mode))
+table.prepare(mine, n, CH, mode)
+print(table.describe(mine, n, CH, mode))
 side = torch.cuda.Stream()
 st = side.cuda_stream
 def step(i):
-    table.convolve_device(xs[i % buffers].data_ptr(), ys[i % buffers].data_ptr(), mine, n, 2, mode, st)
+    table.convolve_device(xs[i % buffers].data_ptr(), ys[i % buffers].data_ptr(), mine, n, CH, mode, st)
 # (a hipGraph replay: under VND_TUNING the host side of a launch re-reads its variables and may be slower than a small pass)
 g = torch.cuda.CUDAGraph()
 with torch.cuda.stream(side):
@@ -51,7 +60,7 @@ with torch.cuda.stream(side):
 torch.cuda.synchronize()
 per_pass = e0.elapsed_time(e1) / 200 * 1e3
 print(f'{per_pass:.2f} us per pass (stamped build)')
-s = table.read_stamps(mine, n, 2, mode)
+s = table.read_stamps(mine, n, CH, mode)
 if s.size == 0:
     raise SystemExit('no stamps in this kernel')
 live = s[:, 12] != 0
@@ -74,7 +83,7 @@ t[:, 12:14] = -1
 t0 = entry.min()
 print(f'kernel entry of the first workgroup -> its span starts: {(t[:, 0] - entry).mean() * 0.01:.2f} us (mean over workgroups); last workgroup entered {(entry.max() - t0) * 0.01:.2f} us after the first')
 rel = np.where(t > 0, (t - t0) * 0.01, np.nan)          # us
-names = ['start', 'ring filled'] + [f'tile {k // 4}: {w}' for k in range(12) for w in [('taps done', 'window dead', 'outputs exchanged', 'refill published')[k % 4]]] + ['stores acknowledged']
+names = ['start', 'ring filled'] + [f'tile {k // 4}: {w}' for k in range(12) for w in [('taps done', 'window dead (quads, octets: stores issued)', 'outputs exchanged', 'refill published')[k % 4]]] + ['stores acknowledged']
 print(f'{len(s)} workgroups stamped; last stamp of all {np.nanmax(rel):.2f} us after the first start')
 print(f'{"phase":28s} {"mean":>8s} {"min":>8s} {"max":>8s}   (us after the first workgroup started)')
 for k, name in enumerate(names):

@@ -544,6 +544,7 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
     // workgroup's last unit skips its (useless) refill and the barrier behind it
     spec_append(s, "#define VW_FILL_BATCH %d\n#define VW_RB_BATCH %d\n#define VW_SKIP_FINAL %d\n", spec_env("VND_WIN_FILL_BATCH", 8), spec_env("VND_WIN_RB_BATCH", 1),
                 spec_env("VND_WIN_SKIP_FINAL", 1) != 0 ? 1 : 0);
+    spec_append(s, "#define VW_QC_SKIP_X %d\n", spec_env("VND_WIN_QC_SKIP_X", 1) != 0 ? 1 : 0);
     spec_append(s, "#define VW_STAMP_PHASES %d\n", spec_env("VND_WIN_STAMP_PHASES", 1) != 0 ? 1 : 0);
     spec_append(s, "#define VW_STAMPS %d\n", (tuning && *tuning && *tuning != '0') ? std::min(std::max(spec_env("VND_WIN_STAMPS", 0), 0), 4096) : 0);
     // s_setprio of the store / refill phase (0: none): cfg2 +1.0 % fast, +0.5 % exact at 1, 2 or 3; cfg3 unchanged (tools/win_phase_try.py)
