@@ -441,9 +441,9 @@ def test_fast_decorrelate_stage_through_the_specialised_kernel(env, golden, tmp_
     torch.cuda.synchronize()
     ctx.set_variant(-1)
     source = (tmp_path / 'kernel.hip').read_text()
-    # (a stereo input's fast mode takes the WINDOW form of the per-table kernel - the same switches, prefixed VW_ -,
-    #  a mono input fanned out the pair-read form)
-    px = 'VS' if mono else 'VW'
+    # (the fast mode takes the WINDOW form of the per-table kernel - the same switches, prefixed VW_ - for a stereo input and,
+    #  since round 4, for a mono input fanned out: the plain form, one read stream for both output channels)
+    px = 'VW'
     assert f'#define {px}_EPI 1' in source and f'#define {px}_EXACT 0' in source and f'#define {px}_BC {int(mono)}' in source
     for b in (0, 11, 23):
         sig = x[b].cpu().numpy()

@@ -331,8 +331,9 @@ def test_window_form_with_the_waves_split_over_the_channels(env, golden, monkeyp
 
 def test_stereo_tables_take_the_window_form_by_default_in_both_modes(env, golden):
     """The automatic choice for a stereo table with enough work: the window form, fast and exact, function path and class
-    path; tables of 4k channels the window form on channel quads, of 8k channels on octets; a mono input fanned out and
-    tables of 4k + 2 channels keep the pair-read form."""
+    path; tables of 4k channels the window form on channel quads, of 8k channels on octets; a mono input fanned out the plain form
+    with one read stream for both output channels (fast) or 64-frame split runs (exact: function-path tables); tables of 4k + 2
+    channels keep the pair-read form."""
     d, native, ctx = env
     ctx.set_variant(-1)
     dense, sparse = _table(native, ctx, golden.fir('g48k_k128_u')), _table(native, ctx, golden.fir('g48k_k30'))
@@ -355,7 +356,8 @@ def test_stereo_tables_take_the_window_form_by_default_in_both_modes(env, golden
             assert ('frames_per_lane=64 ' in fast and 'waves=split-by-channel' in fast) or ('frames_per_lane=32 ' in fast and 'split' not in fast), fast
     for mode in (d.MODE_FAST, d.MODE_EXACT):
         text = sparse.describe(128, 480000, 1, mode)
-        assert text.startswith('conv_spec') and 'window' not in text, text
+        assert text.startswith('conv_spec') and 'window' in text, text
+        assert ('frames_per_lane=32 ' in text and 'split' not in text) if mode == d.MODE_FAST else ('frames_per_lane=64 ' in text and 'waves=split-by-channel' in text), text
         text = wide.describe(16, 960000, 8, mode)
         assert text.startswith('conv_spec') and 'window' in text and 'pieces=channel-octets waves=split-by-channel' in text and 'frames_per_lane=32 ' in text, text
         text = four.describe(16, 960000, 4, mode)

@@ -164,7 +164,7 @@ def test_every_channel_pair_of_a_wider_table_gets_its_own_tap_function(native, g
     M, nt = 32, 128
     src, lds_bytes, fmas = native.window_kernel_source(offs, idx, w, 2 if mode == 'fast' else 0, M, nt, with_traffic=True)
     assert '#define VW_C 6' in src and fmas == M * len(idx)
-    assert all(f'if constexpr (PG == {g}) ' in src and f'case {g}: vw_span<{g}>(a, lds, stream, t_first, ntiles, flags); break;' in src for g in range(3))
+    assert all(f'if constexpr (PG == {g}) ' in src and f'case {g}: vw_span<{g}>(a, lds, stream, t_first, ntiles, flags, pace); break;' in src for g in range(3))
     assert 'vw_taps_3(' not in src
     R, G, plane = _macro(src, 'VW_R'), _macro(src, 'VW_G'), _macro(src, 'VW_PLANE')
     need = nt + (int(idx.max()) + M - 1) // M                   # the halo of the farthest tap of ANY pair
@@ -376,7 +376,7 @@ def test_quads_and_octets_with_a_wave_per_channel(native, golden, tmp_path, mode
         for ch in range(2):
             assert ('vw_taps_c%d(' % ch if pg == 0 else 'vw_taps_%dc%d(' % (pg, ch)) in src
     dispatch = src.split('#define VW_DISPATCH')[1].split('\n')[0]
-    assert dispatch.count('vw_span_qc<') == 2 // Q and 'vw_span_qc<0>(a, lds, stream, t_first, ntiles, flags)' in dispatch
+    assert dispatch.count('vw_span_qc<') == 2 // Q and 'vw_span_qc<0>(a, lds, stream, t_first, ntiles, flags, pace)' in dispatch
     f = tmp_path / 'k.hip'
     f.write_text(src)
     out = tmp_path / 'k.s'

@@ -74,6 +74,9 @@ struct vnd_ctx {
     // (hipFuncSetAttribute applies to the current device's copy of the function)
     std::mutex raised_mutex;
     std::map<const void *, size_t> raised;      // kernel -> dynamic LDS bytes it has been allowed
+    // pacing slots of the window kernel (vnd_win_kernel.inc, VWArgs::pace): [2048 CU indices][2] tile counters, made on first use
+    std::mutex pace_mutex;
+    unsigned *pace = nullptr;
 };
 
 typedef std::lock_guard<std::mutex> HostLock;
@@ -648,6 +651,17 @@ static vnd_status launch_spec(vnd_ctx *ctx, const vnd_taps *t, const SpecPlan &p
     a.tiles_total = p.tiles_total; a.tiles_per_span = p.tiles_per_span; a.spans = p.spans; a.nblocks = p.nblocks;
     a.units = p.units;
     a.chunk_tiles = p.chunk_tiles; a.chunk_len0 = p.chunk_len0; a.chunk_len1 = p.chunk_len1; a.chunks_per_stream = p.chunks_per_stream; a.cus_per_xcd = p.cus_per_xcd;
+    a.cus_per_xcd = std::max(1, (ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256) / 8);
+    // pacing: one full round of workgroups, two per CU (their co-residency lasts the whole launch), plain stereo forms
+    if (p.cfg.win && !p.cfg.win_q && p.chunk_tiles == 0 && p.cfg.win_per_cu == 2 && spec_env("VND_WIN_PACE", 1) != 0 &&
+        p.nblocks > (uint32_t)(8 * a.cus_per_xcd) && p.nblocks <= (uint32_t)(2 * 8 * a.cus_per_xcd) && p.units >= p.nblocks) {
+        std::lock_guard<std::mutex> g(ctx->pace_mutex);
+        if (!ctx->pace && hipMalloc((void **)&ctx->pace, 2048 * 2 * sizeof(unsigned)) == hipSuccess) {
+            if (hipMemset(ctx->pace, 0, 2048 * 2 * sizeof(unsigned)) != hipSuccess) { (void)hipFree(ctx->pace); ctx->pace = nullptr; }
+        }
+        (void)hipGetLastError();
+        a.pace = ctx->pace;
+    }
     a.stagger_ticks = p.stagger_ticks; a.chunk_prio = spec_env("VND_WIN_CHUNK_PRIO", 1) != 0 ? 1 : 0;
     if (epi != nullptr && p.cfg.epi) {
         a.epi_ms_encode = epi->ms_encode; a.epi_use_width = epi->use_width; a.epi_w_mid = epi->w_mid; a.epi_w_side = epi->w_side;
@@ -818,6 +832,7 @@ vnd_status vnd_ctx_destroy(vnd_ctx *c)
     if (c->scratch_x) (void)hipFree(c->scratch_x);
     if (c->scratch_y) (void)hipFree(c->scratch_y);
     if (c->work) (void)hipFree(c->work);
+    if (c->pace) (void)hipFree(c->pace);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     for (hipEvent_t ev : c->up_events) (void)hipEventDestroy(ev);

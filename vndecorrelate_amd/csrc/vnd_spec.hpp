@@ -370,6 +370,7 @@ struct SpecArgs {
     int stagger_ticks, chunk_prio, chunk_len1;
     double *epi_blk_sum;          // VW_EPI with 32-frame runs: per-block sums of squares for the block-parallel exact RMS sums
     int epi_nblocks, epi_rows_major;
+    unsigned *pace;               // [2048 CU indices][2] tile counters of co-resident workgroups (window form: pacing)
 };
 
 struct SpecModule {

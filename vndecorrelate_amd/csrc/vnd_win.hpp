@@ -162,7 +162,7 @@ inline std::string win_taps_dispatch(const SpecTable &t)
     for (int pg = 0; pg < t.C / 2; ++pg)
         spec_append(s, "    %sif constexpr (PG == %d) %s(b, o0, o1);\n", pg ? "else " : "", pg, win_taps_name(pg).c_str());
     s += "}\n#define VW_DISPATCH(pg) switch (pg) {";
-    for (int pg = 0; pg < t.C / 2; ++pg) spec_append(s, " case %d: vw_span<%d>(a, lds, stream, t_first, ntiles, flags); break;", pg, pg);
+    for (int pg = 0; pg < t.C / 2; ++pg) spec_append(s, " case %d: vw_span<%d>(a, lds, stream, t_first, ntiles, flags, pace); break;", pg, pg);
     s += " default: break; }\n";
     return s;
 }
@@ -578,12 +578,12 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
             src += "        }\n    }\n";
         }
         src += "}\n#define VW_TAPS_OF_CHANNEL(pc) vw_taps_of_channel<QD>(pc, b, o);\n#define VW_DISPATCH(pg) switch (pg) {";
-        for (int qd = 0; qd < t.C / nch; ++qd) spec_append(src, " case %d: vw_span_qc<%d>(a, lds, stream, t_first, ntiles, flags); break;", qd, qd);
+        for (int qd = 0; qd < t.C / nch; ++qd) spec_append(src, " case %d: vw_span_qc<%d>(a, lds, stream, t_first, ntiles, flags, pace); break;", qd, qd);
         src += " default: break; }\n";
     } else if (g.split) {
         for (int ch = 0; ch < 2; ++ch) src += c.exact ? win_taps_function_exact(t, g, c.la, 0, ch) : win_taps_function(t, g, c.la, 0, ch);
         src += "template <int PG> __device__ void vw_taps_of(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M]);      // (vw_span: not instantiated)\n";
-        src += "#define VW_DISPATCH(pg) vw_span_s(a, lds, stream, t_first, ntiles, flags);\n";
+        src += "#define VW_DISPATCH(pg) vw_span_s(a, lds, stream, t_first, ntiles, flags, pace);\n";
     } else {
         const bool merged = c.bc && !c.exact && spec_env("VND_WIN_FANOUT_MERGED", 1) != 0;      // (one read stream for both channels of a mono input)
         for (int pg = 0; pg < t.C / 2; ++pg) src += c.exact ? win_taps_function_exact(t, g, c.la, pg) : (merged ? win_taps_function_merged(t, g, c.la, pg) : win_taps_function(t, g, c.la, pg));
