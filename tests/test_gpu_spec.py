@@ -70,9 +70,8 @@ def test_forced_small_signals_and_span_seams(env, golden, gname, monkeypatch):
     fir = golden.fir(gname)
     C = fir.shape[1]
     table = _table(native, ctx, fir)
-    # 1e-6 of peak up to 64 taps per channel (the north-star configuration and cfg5); 2e-6 for the
-    # 128-tap tables, where the reference's own two associations differ by 1.2e-6 of peak
-    tol = 2e-6 if 'k128' in gname else TOL_PEAK
+    # 1e-6 of peak: the north star's tolerance, for the 128-tap tables too (2e-6 until round 4)
+    tol = TOL_PEAK
     rng = np.random.default_rng(11)
     lengths = [1, 2, 31, 1023, 1024, 1025, 2047, 2048, 4096, 4097, 5000, 9001, 12346]
     for n in lengths:

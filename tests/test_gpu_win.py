@@ -1,7 +1,7 @@
 """GPU tier: the WINDOW form of the per-table kernel (vnd_win.hpp; VND_MODE_FAST's default for stereo tables) and
 every per-table kernel at the pool shapes bench.py times, against the oracle.
-Bar: <= 1e-6 of the output peak (2e-6 for 128-tap tables, where the reference's own two associations differ by
-1.2e-6); the exact kernels bit for bit."""
+Bar: <= 1e-6 of the output peak - the north star's tolerance, 128-tap tables included (2e-6 until round 4; measured: 7-8e-7
+on the worst stream of the cfg3 pools) -; the exact kernels bit for bit."""
 import numpy as np
 import pytest
 
@@ -50,7 +50,7 @@ def test_window_geometries_seams_and_tails(env, golden, monkeypatch, gname, M, n
     fir = golden.fir(gname)
     table = _table(native, ctx, fir)
     monkeypatch.setenv('VND_SPEC_NT', str(nt))
-    tol = 2e-6 if 'k128' in gname else TOL_PEAK
+    tol = TOL_PEAK
     rng = np.random.default_rng(5)
     T = nt * M
     lengths = [1, 2, 31, M - 1, M, M + 1, T - 1, T, T + 1, 2 * T + 3, 3 * T, 5 * T + 17, 9001, 12346, 40003]
@@ -104,8 +104,8 @@ def test_window_results_do_not_depend_on_the_geometry(env, golden, monkeypatch):
 # ---- the per-table kernels at the pool shapes bench.py times (cfg3 twice, cfg4, cfg5), against the oracle ----
 POOLS = {
     # name: (golden fir, pool, frames, channels, fast tolerance)
-    'cfg3_uniform': ('g48k_k128_u', 24, 2880000, 2, 2e-6),        # 60 s stereo, 128 taps, kappa = 0
-    'cfg3_log_123taps': ('g48k_k128_l', 24, 2880000, 2, 2e-6),    # kappa = 1: the function path keeps 123 of the 128 taps
+    'cfg3_uniform': ('g48k_k128_u', 24, 2880000, 2, 1e-6),        # 60 s stereo, 128 taps, kappa = 0
+    'cfg3_log_123taps': ('g48k_k128_l', 24, 2880000, 2, 1e-6),    # kappa = 1: the function path keeps 123 of the 128 taps
     'cfg4_one_launch': ('g48k_k30', 1024, 48000, 2, 1e-6),        # 1024 streams of 1 s, device resident, ONE launch
     'cfg5_eight_channels': ('g96k_k64_c8', 16, 960000, 8, 1e-6),  # 96 kHz, 8 channels, 64 taps
     # (not bench shapes: the quad form where the quad IS the frame - non-temporal stores - and two octets per frame)
@@ -288,7 +288,7 @@ def test_window_form_with_the_waves_split_over_the_channels(env, golden, monkeyp
     table = _table(native, ctx, fir)
     monkeypatch.setenv('VND_SPEC_NT', str(nt))
     monkeypatch.setenv('VND_WIN_SPLIT', '2')
-    tol = 2e-6 if 'k128' in gname else TOL_PEAK
+    tol = TOL_PEAK
     rng = np.random.default_rng(M + nt)
     T = (nt // 2) * M
     split_seen = 0

@@ -654,7 +654,10 @@ static vnd_status launch_spec(vnd_ctx *ctx, const vnd_taps *t, const SpecPlan &p
     a.cus_per_xcd = std::max(1, (ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256) / 8);
     // pacing: one full round of workgroups, two per CU (their co-residency lasts the whole launch), plain stereo forms
     if (p.cfg.win && !p.cfg.win_q && p.chunk_tiles == 0 && p.cfg.win_per_cu == 2 && spec_env("VND_WIN_PACE", 1) != 0 &&
-        p.nblocks > (uint32_t)(8 * a.cus_per_xcd) && p.nblocks <= (uint32_t)(2 * 8 * a.cus_per_xcd) && p.units >= p.nblocks) {
+        p.nblocks > (uint32_t)(8 * a.cus_per_xcd) && p.nblocks <= (uint32_t)(2 * 8 * a.cus_per_xcd) && p.units >= p.nblocks &&
+        // (long launches only: with a few tiles per workgroup the bias it corrects has no time to build up, and handing the later
+        //  workgroup the priority costs - cfg4's N = 4 shard, 3 tiles each: 42.8 -> 48.8 us; cfg3's 17 tiles: +4.7 %)
+        (int64_t)p.units * p.tiles_per_span >= (int64_t)p.nblocks * spec_env("VND_WIN_PACE_MIN_TILES", 16)) {
         std::lock_guard<std::mutex> g(ctx->pace_mutex);
         if (!ctx->pace && hipMalloc((void **)&ctx->pace, 2048 * 2 * sizeof(unsigned)) == hipSuccess) {
             if (hipMemset(ctx->pace, 0, 2048 * 2 * sizeof(unsigned)) != hipSuccess) { (void)hipFree(ctx->pace); ctx->pace = nullptr; }
