@@ -174,6 +174,40 @@ def test_real_size_pool_matches_the_exact_kernel(env, golden):
     table.close()
 
 
+def test_headline_span_layout_past_four_gib_of_offsets(env, golden):
+    """The bench's headline launch shape - one span of 59 tiles per stream, several units per workgroup - on a pool whose arrays pass
+    4 GiB (1536 cfg2 signals: 5.9 GB each way): stream offsets beyond 32 bits, descriptor bases recomputed per unit.  Every stream fast
+    against exact on the device; the first, a middle and the LAST stream (the highest addresses) of both against the C oracle - exact bit
+    for bit."""
+    import torch
+    d, native, ctx = env
+    ctx.set_variant(-1)
+    fir = golden.fir('g48k_k30')
+    table = _table(native, ctx, fir)
+    pool, n = 1536, 480000                                 # (a multiple of the 512 resident workgroups: one span per stream, as the bench's 2048)
+    assert pool * n * 2 * 4 > 1 << 32
+    for mode in (d.MODE_FAST, d.MODE_EXACT):
+        text = table.describe(pool, n, 2, mode)
+        assert text.startswith('conv_spec') and '_window' in text and '1 spans x 59 tiles per stream' in text, text
+    x = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1)
+    y, ye = torch.empty_like(x), torch.empty_like(x)
+    stream = torch.cuda.current_stream().cuda_stream
+    table.convolve_device(x.data_ptr(), y.data_ptr(), pool, n, 2, mode=d.MODE_FAST, stream=stream)
+    table.convolve_device(x.data_ptr(), ye.data_ptr(), pool, n, 2, mode=d.MODE_EXACT, stream=stream)
+    torch.cuda.synchronize()
+    per_stream = torch.cat([(y[b0:b0 + 96] - ye[b0:b0 + 96]).abs().amax(dim=(1, 2)) for b0 in range(0, pool, 96)])
+    peak = float(ye[::97].abs().max())
+    assert float(per_stream.max()) <= TOL_PEAK * peak, f'stream {int(per_stream.argmax())}: {float(per_stream.max()) / peak:.2e} of peak'
+    offs, idx, w = O.fir_to_taps(fir)
+    for b in (0, 767, pool - 1):
+        want = c_oracle.convolve(x[b].cpu().numpy(), offs, idx, w, threads=8)
+        assert np.array_equal(ye[b].cpu().numpy(), want), f'exact kernel, stream {b}'
+        _check(y[b].cpu().numpy(), want, f'stream {b}')
+    del x, y, ye
+    torch.cuda.empty_cache()
+    table.close()
+
+
 def test_linearity_and_shift_at_full_size(env, golden):
     """Size-independent properties on the specialised path: exact dyadic scaling and shift invariance."""
     import torch

@@ -58,6 +58,7 @@ if 'hbm_read_bytes_per_launch' in derived and 'hbm_write_bytes_per_launch' in de
         'pool': pool, 'bytes_per_launch': int(total), 'bytes_per_stream': total / pool,
         'read_bytes': int(derived['hbm_read_bytes_per_launch']), 'write_bytes': int(derived['hbm_write_bytes_per_launch']),
         'algorithmic_bytes_per_stream': 8 * 480000 * 2, 'launch': launch,
+        'commit': __import__('subprocess').run(['git', 'rev-parse', '--short', 'HEAD'], cwd=str(REPO), capture_output=True, text=True).stdout.strip() or 'unknown',
         'source': f'profiles/{stem}_pmc.json: FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate --pmc passes'}, indent=1) + '\n')
 stats = glob.glob(str(REPO / 'gpurun_out' / f'prof_{tag}' / 'trace' / '**' / '*kernel_stats.csv'), recursive=True)
 if stats:
