@@ -742,13 +742,13 @@ def main():
             for i in range(60):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                table.convolve_device(x[i % 16].data_ptr(), y[i % 16].data_ptr(), 1, n, CHANNELS, m, stream)
+                table.convolve_device(x[i % min(16, args.pool)].data_ptr(), y[i % min(16, args.pool)].data_ptr(), 1, n, CHANNELS, m, stream)
                 torch.cuda.synchronize()
                 lat.append((time.perf_counter() - t0) * 1e6)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for i in range(200):
-                table.convolve_device(x[i % 64].data_ptr(), y[i % 64].data_ptr(), 1, n, CHANNELS, m, stream)
+                table.convolve_device(x[i % min(64, args.pool)].data_ptr(), y[i % min(64, args.pool)].data_ptr(), 1, n, CHANNELS, m, stream)
             e1.record()
             torch.cuda.synchronize()
             single_launch[label] = {'launch_to_sync_us_median': round(sorted(lat[10:])[25], 1), 'back_to_back_us': round(e0.elapsed_time(e1) / 200 * 1e3, 2),

@@ -163,3 +163,30 @@ extern "C" __global__ void spilling_kernel(float *y, const int *idx)
     assert native.code_object_private_bytes(image, 'no_such_kernel') == -1
     assert native.code_object_private_bytes(image[:200], 'clean_kernel') == -1          # a truncated image: no answer, no crash
     assert native.code_object_private_bytes(b'not an object at all' * 10, 'clean_kernel') == -1
+
+
+def test_tuning_variables_exist_only_in_a_tuning_session(tmp_path):
+    """A process started WITHOUT VND_TUNING never looks at the tuning variables (geometry overrides, A/B switches): the generated
+    kernel is the default one whatever the environment says; with VND_TUNING=1 they are read live (csrc/vnd_spec.hpp: spec_env,
+    kTuningNames).  Host switches are not part of this."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, json; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from vndecorrelate_amd import _native\n"
+            "offs = np.array([0, 3, 6], np.int32); idx = np.array([0, 5, 100, 2, 7, 90], np.int32); w = np.ones(6, np.float32)\n"
+            "src = _native.window_kernel_source(offs, idx, w, 2, 32, 256)\n"
+            "import re; print(json.dumps({k: int(re.search(r'#define %%s (\\d+)' %% k, src).group(1)) for k in ('VW_G', 'VW_PRIO')}))\n") % str(REPO)
+    out = {}
+    for tuning in ('', '1'):
+        env = {k: v for k, v in os.environ.items() if not k.startswith('VND_')}
+        env.update({'VND_WIN_G': '4', 'VND_WIN_PRIO': '3'})
+        if tuning:
+            env['VND_TUNING'] = tuning
+        r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tuning] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out[''] == {'VW_G': 8, 'VW_PRIO': 1}, out
+    assert out['1'] == {'VW_G': 4, 'VW_PRIO': 3}, out

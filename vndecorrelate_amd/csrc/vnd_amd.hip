@@ -391,7 +391,7 @@ struct SpecPlan {
     uint32_t nblocks = 0, units = 0;
     // a small launch's CU chunks (window form, stereo): chunk_tiles consecutive tiles per CU, its first-dispatched workgroup takes
     // chunk_len0 of them, the second the rest (0: uniform spans)
-    int chunk_tiles = 0, chunk_len0 = 0, chunk_len1 = 0, chunk_rounds = 0, chunks_per_stream = 0, cus_per_xcd = 0, stagger_ticks = 0;
+    int chunk_tiles = 0, chunk_len0 = 0, chunks_per_stream = 0, cus_per_xcd = 0, stagger_ticks = 0;
     const char *why = "";           // when !use: the reason, for vnd_describe_launch
 };
 
@@ -449,11 +449,11 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     const int rr_hint = (v >= 0 && (v & 31) != 0 && (v & 31) <= 8) ? (v & 31) : 0;
     const int dd_hint = v >= 0 ? ((v >> 26) & 3) : 0;
     // variant bits 5-7: window form off (1), or 16 (2), 32 (3), 64 (4) frames per lane; VND_WIN_M: the default (32; 0 = pair-read kernel)
-    static const int win_env = spec_env("VND_WIN_M", 32);
+    const int win_env = spec_env("VND_WIN_M", 32);
     const int vw = v >= 0 ? ((v >> 5) & 7) : 0;
     const int win_m = vw == 1 ? 0 : (vw == 2 ? 16 : (vw == 3 ? 32 : (vw == 4 ? 64 : win_env)));
     // VND_MODE_EXACT in the window form: tables whose weights let the sign ride in the add (finite) - all in spec scope
-    static const int win_exact_env = spec_env("VND_WIN_EXACT", 1);       // 0: never, 1: where it pays (the table knows), 2: always
+    const int win_exact_env = spec_env("VND_WIN_EXACT", 1);       // 0: never, 1: where it pays (the table knows), 2: always
     const bool win_exact = vw >= 2 || win_exact_env == 2 || (win_exact_env == 1 && t->win_exact_pays);
     // 1536-frame tiles (cfg4's 32-tile streams included: 0.167 vs 0.179 ms) unless a span would be shorter than 12 of them
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -506,7 +506,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     //    frames (rejected builds fall back to the plain form) (tools/win_split_try.py, profiles/r03_split_waves.txt)
     // a mono input fanned out, fast mode: the plain form with ONE read stream for both output channels (win_taps_function_merged:
     // the two channels' taps lie almost alike, their windows' union is little more than one channel's - 1.48 B of LDS per FMA)
-    if (!picked && win_mode_ok && bc && mode == VND_MODE_FAST && vw == 0 && spec_env("VND_WIN_FANOUT_MERGED", 1) != 0)
+    if (!picked && win_mode_ok && bc && mode == VND_MODE_FAST && vw == 0)
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, true, &p.cfg, rejected);
     const int split_env = spec_env("VND_WIN_SPLIT", 1);
     // (a mono input fanned out rides the same form: its one channel staged into both plane sets, VW_BC - cfg1's shape 0.177 -> 0.15 ms
@@ -518,7 +518,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     //    tools/split64_fast_probe.py); a table whose build spills all the same falls back to the plain 32-frame form
     const bool exact_now = mode == VND_MODE_EXACT;
     if (!picked && win_mode_ok && split_scope && split_env == 1 && vw == 0 &&
-        ((exact_now && !t->spec_table.has_seg) || (mode == VND_MODE_FAST && spec_env("VND_WIN_SPLIT_FAST", 1) != 0)))
+        ((exact_now && !t->spec_table.has_seg) || mode == VND_MODE_FAST))
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, 64, attempt == 1, bc, &p.cfg, rejected, 0, true, exact_now);
     if (!picked && win_mode_ok && split_scope && split_env == 2)
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, bc, &p.cfg, rejected, 0, true, exact_now);
@@ -601,14 +601,12 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
             const double c = cost2(a0, w - a0);
             if (c < best - 1e-9) { best = c; best_len0 = a0; }
         }
-        const int len0_env = spec_env("VND_WIN_CHUNK_LEN0", 0), len1_env = spec_env("VND_WIN_CHUNK_LEN1", -1);      // (tuning: force the split; LEN1 >= 0: three workgroups per CU)
+        const int len0_env = spec_env("VND_WIN_CHUNK_LEN0", 0);      // (tuning: force the split)
         if (len0_env > 0 && len0_env < w) { best_len0 = len0_env; best = -1.0; }
         if (w >= 2 && best < uniform - 1e-9 && best_len0 < w && w * (cps - 1) < tiles_total) {
             p.chunk_tiles = (int)w; p.chunk_len0 = (int)best_len0; p.chunks_per_stream = (int)cps; p.cus_per_xcd = cus / 8;
-            p.chunk_len1 = (int)(w - best_len0); p.chunk_rounds = 2;
-            if (len1_env >= 0 && per_cu >= 3 && best_len0 + len1_env < w) { p.chunk_len1 = len1_env; p.chunk_rounds = 3; }
             p.stagger_ticks = std::max(0, spec_env("VND_WIN_STAGGER_TICKS", 300));      // 3 us: about the first workgroup's ring fill - the later one loads while that one computes (tools/ablate/run_r4b.sh, run_r4c.sh)
-            p.units = (uint32_t)(p.chunk_rounds * cus);
+            p.units = (uint32_t)(2 * cus);
             p.nblocks = p.units;
         }
     }
@@ -650,7 +648,7 @@ static vnd_status launch_spec(vnd_ctx *ctx, const vnd_taps *t, const SpecPlan &p
     a.x = x; a.y = y; a.n = n;
     a.tiles_total = p.tiles_total; a.tiles_per_span = p.tiles_per_span; a.spans = p.spans; a.nblocks = p.nblocks;
     a.units = p.units;
-    a.chunk_tiles = p.chunk_tiles; a.chunk_len0 = p.chunk_len0; a.chunk_len1 = p.chunk_len1; a.chunks_per_stream = p.chunks_per_stream; a.cus_per_xcd = p.cus_per_xcd;
+    a.chunk_tiles = p.chunk_tiles; a.chunk_len0 = p.chunk_len0; a.chunks_per_stream = p.chunks_per_stream; a.cus_per_xcd = p.cus_per_xcd;
     a.cus_per_xcd = std::max(1, (ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256) / 8);
     // pacing: one full round of workgroups, two per CU (their co-residency lasts the whole launch), plain stereo forms
     if (p.cfg.win && !p.cfg.win_q && p.chunk_tiles == 0 && p.cfg.win_per_cu == 2 && spec_env("VND_WIN_PACE", 1) != 0 &&
@@ -665,7 +663,7 @@ static vnd_status launch_spec(vnd_ctx *ctx, const vnd_taps *t, const SpecPlan &p
         (void)hipGetLastError();
         a.pace = ctx->pace;
     }
-    a.stagger_ticks = p.stagger_ticks; a.chunk_prio = spec_env("VND_WIN_CHUNK_PRIO", 1) != 0 ? 1 : 0;
+    a.stagger_ticks = p.stagger_ticks; a.chunk_prio = 1;
     if (epi != nullptr && p.cfg.epi) {
         a.epi_ms_encode = epi->ms_encode; a.epi_use_width = epi->use_width; a.epi_w_mid = epi->w_mid; a.epi_w_side = epi->w_side;
         // a wave of the plain 32-frame form owns one 2048-frame block of the sums (kParFrames)
@@ -1339,7 +1337,8 @@ static vnd_status convolve_host(vnd_ctx *ctx, const vnd_taps *t, const float *x,
     // (measured and dropped, same tool: a mapped input read in place with a staged download per group - 15.1 ms for the
     //  1024 streams; a staged upload with every group written in place - 13.7 ms with page-locked, 9.8-10.1 with pageable
     //  input against the staged pipeline's 8.8: a pageable upload is staged by the CPU, beside the SDMA download.)
-    const bool direct = spec_env("VND_HOST_DIRECT", 1) != 0;
+    static int direct_slot = INT32_MIN;
+    const bool direct = host_env_once("VND_HOST_DIRECT", 1, &direct_slot) != 0;
     void *xd = nullptr, *yd = nullptr;
     const bool apart = !overlaps(x, (int64_t)in_elems, y, (int64_t)out_elems);
     const bool x_mapped = direct && apart && host_mapped(x, in_elems * sizeof(float), &xd);
@@ -1650,8 +1649,7 @@ static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64
         if (m && !m->failed) {
             if (sp.cfg.win) {
                 char split[96];
-                if (sp.chunk_tiles > 0 && sp.chunk_rounds == 3) snprintf(split, sizeof split, "a chunk of %d tiles per CU as %d + %d + %d, %d chunks", sp.chunk_tiles, sp.chunk_len0, sp.chunk_len1, sp.chunk_tiles - sp.chunk_len0 - sp.chunk_len1, sp.chunks_per_stream);
-                else if (sp.chunk_tiles > 0) snprintf(split, sizeof split, "a chunk of %d tiles per CU as %d + %d, %d chunks", sp.chunk_tiles, sp.chunk_len0, sp.chunk_len1, sp.chunks_per_stream);
+                if (sp.chunk_tiles > 0) snprintf(split, sizeof split, "a chunk of %d tiles per CU as %d + %d, %d chunks", sp.chunk_tiles, sp.chunk_len0, sp.chunk_tiles - sp.chunk_len0, sp.chunks_per_stream);
                 else snprintf(split, sizeof split, "%d spans x %d tiles", sp.spans, sp.tiles_per_span);
                 snprintf(text, (size_t)len,
                          "conv_spec%s_window (hipRTC, per table) frames_per_lane=%d tile=%d reads_ahead=%d "

@@ -78,28 +78,52 @@ struct SpecTable {
     std::vector<float> seg_gain;
 };
 
-// Smallest ring that holds one tile's window (tile + halo) plus the slot being refilled.
-// Returns false when no supported geometry fits (the caller then uses the generic kernel).
-// Tuning variables (VND_SPEC_NT, VND_SPEC_LA, VND_WIN_G, ...) are consulted on every launch plan.  getenv is not safe
-// against a concurrent setenv/putenv (Python's os.environ) and costs a scan of the environment, so each name is read
-// ONCE per process - unless VND_TUNING was set when the library first looked, which turns every lookup into a live read
-// (the sweep tools and the test suite set it: they change geometry between launches of one process).
-inline int spec_env(const char *name, int fallback)
+// ---- run-time switches ---------------------------------------------------------------------------------------
+// Two kinds.  HOST switches (VND_SPEC, VND_SPEC_EXACT, VND_SPEC_CACHE_DIR, VND_SPEC_DUMP, VND_SPEC_VERBOSE,
+// VND_HOST_DIRECT, VND_HOST_TIME_PIECES / _CHUNKS) are read where they act, always.  TUNING variables - geometry overrides, A/B
+// switches of the sweep tools and the tests, diagnosis builds - exist only in a TUNING SESSION: a process started with VND_TUNING=1
+// reads them live at every launch plan; any other process never looks at them (spec_env returns the default).  The one list of them:
+static const char *const kTuningNames[] = {
+    // geometry of the per-table kernels
+    "VND_SPEC_NT", "VND_SPEC_RR", "VND_SPEC_DD", "VND_SPEC_LA", "VND_SPEC_SHIFT", "VND_SPEC_QUAD_STORES", "VND_WIN_M", "VND_WIN_G", "VND_WIN_QUAD_M",
+    "VND_WIN_SPLIT_LATE", "VND_WIN_SPLIT_SMALL_NT",
+    // which form runs
+    "VND_WIN_EXACT", "VND_WIN_QUAD", "VND_WIN_OCTET", "VND_WIN_WIDE", "VND_WIN_SPLIT", "VND_WIN_SPLIT_FANOUT", "VND_WIN_XPOSE_PAIRS", "VND_WIN_FAR_FIRST",
+    "VND_WIN_SOURCE_FANOUT", "VND_EPI_BLOCK_SUMS", "VND_EPI_WIDE",
+    // one-round launches, pacing, priorities, cache policies
+    "VND_WIN_CHUNKS", "VND_WIN_CHUNK_LEN0", "VND_WIN_STAGGER_TICKS", "VND_WIN_PACE", "VND_WIN_PACE_MIN_TILES", "VND_WIN_PRIO", "VND_SPEC_LOAD_AUX",
+    "VND_SPEC_STORE_AUX", "VND_NT_MIN_MB", "VND_NO_NT", "VND_FORCE_NT",
+    // diagnosis builds
+    "VND_WIN_STAMPS", "VND_WIN_STAMP_PHASES",
+};
+
+inline bool spec_tuning()
 {
-    static const bool live = [] { const char *e = getenv("VND_TUNING"); return e && *e && *e != '0'; }();
-    auto read = [&]() { const char *e = getenv(name); return (e && *e) ? atoi(e) : fallback; };
-    if (live) return read();
-    static std::mutex mu;
-    static std::map<std::string, std::pair<bool, int>> seen;            // name -> (set, value)
-    std::lock_guard<std::mutex> g(mu);
-    auto it = seen.find(name);
-    if (it == seen.end()) {
-        const char *e = getenv(name);
-        it = seen.emplace(name, std::make_pair(e && *e, (e && *e) ? atoi(e) : 0)).first;
-    }
-    return it->second.first ? it->second.second : fallback;
+    static const bool on = [] { const char *e = getenv("VND_TUNING"); return e && *e && *e != '0'; }();
+    return on;
 }
 
+inline int spec_env(const char *name, int fallback)
+{
+    if (!spec_tuning()) return fallback;
+#ifndef NDEBUG
+    bool known = false;
+    for (const char *k : kTuningNames) known |= strcmp(k, name) == 0;
+    if (!known) { fprintf(stderr, "vnd: tuning variable %s is not in kTuningNames\n", name); abort(); }
+#endif
+    const char *e = getenv(name);
+    return (e && *e) ? atoi(e) : fallback;
+}
+
+// a HOST switch: read once per process (getenv is not safe against a concurrent setenv, and a host sets these before it starts)
+inline int host_env_once(const char *name, int fallback, int *slot)
+{
+    if (*slot == INT32_MIN) { const char *e = getenv(name); *slot = (e && *e) ? atoi(e) : fallback; }
+    return *slot;
+}
+
+// Smallest ring that holds one tile's window (tile + halo) plus the slot being refilled.
+// Returns false when no supported geometry fits (the caller then uses the generic kernel).
 inline bool spec_pick_config(const SpecTable &t, size_t lds_limit, int rr_hint, int dd_hint, SpecConfig *out,
                              bool small_tiles = false, bool bc = false, bool shift_wanted = false)
 {
@@ -367,7 +391,7 @@ struct SpecArgs {
     float epi_w_mid, epi_w_side;
     // window form only (VWArgs): a small launch's CU chunks - see vnd_win_kernel.inc
     int chunk_tiles, chunk_len0, chunks_per_stream, cus_per_xcd;
-    int stagger_ticks, chunk_prio, chunk_len1;
+    int stagger_ticks, chunk_prio, reserved0;
     double *epi_blk_sum;          // VW_EPI with 32-frame runs: per-block sums of squares for the block-parallel exact RMS sums
     int epi_nblocks, epi_rows_major;
     unsigned *pace;               // [2048 CU indices][2] tile counters of co-resident workgroups (window form: pacing)

@@ -67,10 +67,9 @@ inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size
         // 2 mod 4 - the rule until late round 3 - 16.2 M, 4 mod 8 56 M, 0 mod 8 137 M.
         // 32-frame runs: with the lanes' pair indices swizzled (VW_LANE_SWIZZLE, the kernel) planes 2 mod 4 slots apart make
         // BOTH the 16-lane writes and the 32-lane read-backs conflict-free
-        const bool swz = qc == 8 && spec_env("VND_WIN_LANE_SWIZZLE", 1) != 0;
+        const bool swz = qc == 8;
         const int mod_rule = swz ? 4 : std::max(2, 16 / qc), res_rule = swz ? 2 : std::max(1, 8 / qc);
-        const int res = spec_env("VND_WIN_PLANE_RES", -1), mod = spec_env("VND_WIN_PLANE_MOD", mod_rule);      // (tuning)
-        while (units % mod != (res >= 0 ? res : res_rule)) ++units;
+        while (units % mod_rule != res_rule) ++units;
         g->plane = units * 16;
         if ((size_t)(qc - 1) * g->plane + (size_t)G * 16 >= 65536) return false;  // ds offset field
         if ((size_t)qc * g->plane >= 65536) return false;                          // channel 1's planes as an immediate
@@ -83,7 +82,7 @@ inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size
     // entries the two runs of lanes meet in the same banks (13 % of all LDS cycles on cfg2 were such conflicts: R = 301).  A few
     // entries of extra halo make the wrap invisible to the banks - taken when they cost no workgroup of residency.
     const int aligned = de + (16 - (nh + de) % 16) % 16;
-    if (aligned != de && spec_env("VND_WIN_ALIGN_RING", 1) != 0) {
+    if (aligned != de) {
         const int before = win_workgroups_per_cu(*g);
         WinGeom plain = *g;
         if (!(lay_out(aligned) && win_workgroups_per_cu(*g) >= before)) *g = plain;
@@ -300,7 +299,7 @@ inline void win_exact_reads(const std::vector<WinExPass> &passes, int M, std::ve
     for (size_t p = 0; p < passes.size(); ++p) {
         const WinExPass &ps = passes[p];
         std::map<int, std::vector<WinExOp>> by_chunk;
-        const bool singles = spec_env("VND_WIN_EXACT_SINGLES", 1) != 0;
+        const bool singles = true;                          // (an odd offset as single adds: the packed form with shuffled pairs only tied with the pair-read kernel)
         for (const WinExTap &tp : ps.taps) {
             if (singles && (tp.idx & 1)) {
                 // an odd offset: output j takes element idx + j.  The aligned input pairs (types 0 / 1) then feed ONE element
@@ -535,7 +534,6 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
                 g.nt, g.M, g.R, g.G, g.NB, g.DE, g.plane, c.la);
     spec_append(s, "#define VW_NT_STORES %d\n#define VW_EPI %d\n#define VW_BC %d\n#define VW_EXACT %d\n#define VW_C %d\n", c.nt_stores, c.epi, c.bc, c.exact, g.C);
     spec_append(s, "#define VW_Q %d\n#define VW_S %d\n", g.quad, g.split);
-    spec_append(s, "#define VW_OPAQUE %d\n", spec_env("VND_WIN_OPAQUE", 1) != 0 ? 1 : 0);      // (plain form: per-access constants kept out of the tile loop's registers)
     // split form: how many of a wave's M/4 refill accesses per tile are loaded late (at the start of the store phase that consumes
     // them) instead of a tile ahead: 64-frame runs keep half of them out of the tap phase's registers
     // (the fast mode's E / P accumulators are twice the exact mode's sums: all but one late there - hipRTC's build of cfg2's table
@@ -546,15 +544,9 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
     // planar chunks read back in 8-byte halves (VND_WIN_XPOSE_PAIRS=0: then 32-frame runs swizzle their lanes' pair indices)
     const int xpose = c.win_xpose ? 1 : 0;
     spec_append(s, "#define VW_XPOSE_PAIRS %d\n", xpose);
-    spec_append(s, "#define VW_LANE_SWIZZLE %d\n", (g.M == 32 && spec_env("VND_WIN_LANE_SWIZZLE", 1) != 0) ? 1 : 0);
-    const char *tuning = getenv("VND_TUNING");
-    // prologue: loads a wave keeps in flight before its first staging write; the store phase's read-backs per batch; the last tile of a
-    // workgroup's last unit skips its (useless) refill and the barrier behind it
-    spec_append(s, "#define VW_FILL_BATCH %d\n#define VW_RB_BATCH %d\n#define VW_SKIP_FINAL %d\n", spec_env("VND_WIN_FILL_BATCH", 8), spec_env("VND_WIN_RB_BATCH", 1),
-                spec_env("VND_WIN_SKIP_FINAL", 1) != 0 ? 1 : 0);
-    spec_append(s, "#define VW_QC_SKIP_X %d\n", spec_env("VND_WIN_QC_SKIP_X", 1) != 0 ? 1 : 0);
+    spec_append(s, "#define VW_LANE_SWIZZLE %d\n", g.M == 32 ? 1 : 0);
     spec_append(s, "#define VW_STAMP_PHASES %d\n", spec_env("VND_WIN_STAMP_PHASES", 1) != 0 ? 1 : 0);
-    spec_append(s, "#define VW_STAMPS %d\n", (tuning && *tuning && *tuning != '0') ? std::min(std::max(spec_env("VND_WIN_STAMPS", 0), 0), 4096) : 0);
+    spec_append(s, "#define VW_STAMPS %d\n", std::min(std::max(spec_env("VND_WIN_STAMPS", 0), 0), 4096));
     // s_setprio of the store / refill phase (0: none): cfg2 +1.0 % fast, +0.5 % exact at 1, 2 or 3; cfg3 unchanged (tools/win_phase_try.py)
     spec_append(s, "#define VW_PRIO %d\n", spec_env("VND_WIN_PRIO", 1));
     spec_append(s, "#define VW_LOAD_AUX %d\n", spec_env("VND_SPEC_LOAD_AUX", 2));
@@ -593,7 +585,7 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
         src += "template <int PG> __device__ void vw_taps_of(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M]);      // (vw_span: not instantiated)\n";
         src += "#define VW_DISPATCH(pg) vw_span_s(a, lds, stream, t_first, ntiles, flags, pace);\n";
     } else {
-        const bool merged = c.bc && !c.exact && spec_env("VND_WIN_FANOUT_MERGED", 1) != 0;      // (one read stream for both channels of a mono input)
+        const bool merged = c.bc && !c.exact;      // (one read stream for both channels of a mono input)
         for (int pg = 0; pg < t.C / 2; ++pg) src += c.exact ? win_taps_function_exact(t, g, c.la, pg) : (merged ? win_taps_function_merged(t, g, c.la, pg) : win_taps_function(t, g, c.la, pg));
         src += win_taps_dispatch(t);
     }
