@@ -102,7 +102,8 @@ def test_host_entry_points_take_the_context_lock():
     """Every *_host entry point of the C ABI serialises on the context (source-level check; the
     behaviour is exercised on the GPU by tests/test_gpu_robustness.py)."""
     import re
-    text = (REPO / 'vndecorrelate_amd' / 'csrc' / 'vnd_amd.hip').read_text()
+    # (the library's one translation unit: vnd_amd.hip and the parts it includes)
+    text = '\n'.join((REPO / 'vndecorrelate_amd' / 'csrc' / f).read_text() for f in ('vnd_amd.hip', 'vnd_host.hpp', 'vnd_stage.hpp', 'vnd_rccl.hpp', 'vnd_hooks.hpp'))
     header = re.sub(r'/\*.*?\*/', '', (REPO / 'include' / 'vnd_amd.h').read_text(), flags=re.S)
     host_fns = sorted(set(re.findall(r'\b(vnd_[a-z0-9_]+_host)\s*\(', header)))
     assert len(host_fns) >= 7

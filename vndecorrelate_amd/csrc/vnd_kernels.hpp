@@ -404,11 +404,6 @@ __device__ __forceinline__ void issue_reads_seq(v2f (&buf)[R], unsigned addr, st
 template <int NT, int R>
 __device__ __forceinline__ void issue_reads(v2f (&buf)[R], unsigned addr)
 {
-#if defined(VND_ABLATE) && VND_ABLATE == 3      // timing-only build: FMAs without the LDS reads
-#pragma unroll
-    for (int j = 0; j < R; ++j) { buf[j] = v2f{1.0f, 2.0f}; asm volatile("" : "+v"(buf[j]) : "v"(addr)); }
-    return;
-#endif
     issue_reads_seq<NT, R>(buf, addr, std::make_integer_sequence<int, R>{});
 }
 
@@ -456,16 +451,6 @@ __device__ __forceinline__ void wait_reads(v2f (&buf)[R])
 template <int R>
 __device__ __forceinline__ void consume(float2 (&acc)[R], const v2f (&buf)[R], float w)
 {
-#if defined(VND_ABLATE) && VND_ABLATE == 2      // timing-only build: LDS reads without the FMAs
-#pragma unroll
-    for (int j = 0; j < R; ++j) asm volatile("" ::"v"(buf[j]));
-    return;
-#endif
-#if defined(VND_ABLATE) && VND_ABLATE == 5      // timing-only build: packed adds in place of the packed FMAs
-#pragma unroll
-    for (int j = 0; j < R; ++j) { acc[j].x += buf[j].x; acc[j].y += buf[j].y; }
-    return;
-#endif
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         acc[j].x = __builtin_fmaf(buf[j].x, w, acc[j].x);
@@ -560,21 +545,6 @@ __device__ __forceinline__ void run_tap_array(const FastTap *__restrict__ tp, in
     }
 }
 
-#ifdef VND_STAMPS
-// Diagnostic build only (tools/ablate): per-workgroup s_memtime stamps of the phases,
-// written to a buffer of their own that nothing else reads.
-__device__ unsigned long long g_stamps[8 * 65536];
-#define VND_STAMP(slot)                                                                   \
-    do {                                                                                  \
-        unsigned long long t_;                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
-        __builtin_amdgcn_sched_barrier(0);                                                \
-        if (threadIdx.x == 0 && blockIdx.x < 65536) g_stamps[blockIdx.x * 8 + (slot)] = t_; \
-    } while (0)
-#else
-#define VND_STAMP(slot) do { } while (0)
-#endif
 
 // The decorrelate epilogue's pointwise steps on one lane's stereo frame pair, in the reference's
 // float32 operation order (bit-identical to NumPy; the file is built with -ffp-contract=off).
@@ -618,7 +588,6 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
     constexpr int PG = BC ? 1 : CG;                          // planes staged
     const int tid = threadIdx.x;
     const int W = a.W;
-    VND_STAMP(0);
     const BlockCoord bc = decode_block(a);
     const int C = a.C, Cx = a.Cx;
     const int c0 = bc.group * CG;
@@ -628,12 +597,8 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
     float *__restrict__ ys = a.y + bc.stream * a.n * C;
     const int64_t bytes_left = ((a.n - t0) * C - c0) * 4;
     float *plane = lds;                                      // [PG][W]
-
-    VND_STAMP(1);
     stage_window<NT, PG>(plane, xs + t0 * Cx + cx0, ((a.n - t0) * Cx - cx0) * 4, Cx, W, tid);
-    VND_STAMP(2);
     __syncthreads();
-    VND_STAMP(3);
 
     float2 accE[CG][R], accO[CG][R];
     float edge[CG];                       // odd-tap part of the tile's last output (frame T-1)
@@ -656,12 +621,8 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
         const int first = __builtin_amdgcn_readfirstlane(a.fast_off[ch]);
         const FastTap *__restrict__ tp = a.taps_fast + first;
         const int n_all = __builtin_amdgcn_readfirstlane(a.fast_off[ch + 1]) - first;
-#if defined(VND_ABLATE) && VND_ABLATE == 1      // timing-only build: staging and stores, no taps
-        const int n_even = 0, n_odd = 0; (void)n_all;
-#else
         const int n_even = __builtin_amdgcn_readfirstlane(a.fast_even[ch]);
         const int n_odd = n_all - n_even;
-#endif
         run_tap_array<NT, R>(tp, n_even, lds_addr(pa), accE[c]);
         run_tap_array<NT, R>(tp + n_even, n_odd, lds_addr(pa), accO[c]);
         // frame T-1 pairs with frame T, which no lane owns: its odd taps, x[T-1+i] = plane[T + (i-1)],
@@ -679,11 +640,7 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
     }
 
     // ---- merge the two accumulator sets: neighbour's accO.x through LDS -----------
-    VND_STAMP(4);
-#if !(defined(VND_ABLATE) && VND_ABLATE == 4)
     __syncthreads();                                   // every wave is done reading the planes
-#endif
-    VND_STAMP(5);
     constexpr int XS = T / 2 + 1;
     // exchange buffer [CG][T/2 + 1]: over the dead window, or (EPI) in each plane's halo part,
     // which keeps the tile's own input x[0 .. T) readable for the epilogue, or (BC) behind the plane
@@ -695,9 +652,7 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
         for (int j = 0; j < R; ++j) xo[c * xs_stride + tid + NT * j] = accO[c][j].x;
         if (tid == NT - 1) xo[c * xs_stride + T / 2] = edge[c];
     }
-#if !(defined(VND_ABLATE) && VND_ABLATE == 4)
     __syncthreads();
-#endif
 
     float *dst = ys + t0 * C + c0;
     const v4i rdst = make_rsrc(dst, bytes_left);
@@ -767,11 +722,6 @@ __global__ __launch_bounds__(NT) void conv_fast_kernel(const KArgs a)
             }
         }
     }
-    VND_STAMP(6);
-#ifdef VND_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // diagnostic only: when the stores have left
-    VND_STAMP(7);
-#endif
 }
 
 // =====================================================================================

@@ -403,6 +403,7 @@ struct SpecModule {
     hipFunction_t fn = nullptr;
     bool failed = false;
     bool pending = false;        // looked for in the disk cache only (a small launch never triggers a build): not there
+    bool building = false;       // a thread is compiling it outside the table's lock (spec_module)
     std::string log;
 };
 

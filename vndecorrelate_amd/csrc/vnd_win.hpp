@@ -665,6 +665,9 @@ inline std::string win_source_for(const SpecTable &t, const SpecConfig &cfg)
 {
     WinGeom g;
     if (!win_geometry(t, cfg.win, cfg.nt, cfg.win_g, cfg.bc != 0, 160 * 1024, &g, cfg.win_q, cfg.win_s != 0)) return "#error window geometry does not fit\n";
+    // the launch passes cfg.win_lds - computed when the plan was made - as the dynamic LDS size: a geometry that comes out different
+    // here (a tuning variable changed between plan and build) must be a rejected build, never a kernel that indexes past its LDS
+    if ((int)g.lds_bytes() != cfg.win_lds) return "#error window geometry changed between the launch plan and the build\n";
     return win_source(t, g, cfg);
 }
 
