@@ -94,7 +94,7 @@ static const char *const kTuningNames[] = {
     "VND_WIN_CHUNKS", "VND_WIN_CHUNK_LEN0", "VND_WIN_STAGGER_TICKS", "VND_WIN_PACE", "VND_WIN_PACE_MIN_TILES", "VND_WIN_PRIO", "VND_SPEC_LOAD_AUX",
     "VND_SPEC_STORE_AUX", "VND_NT_MIN_MB", "VND_NO_NT", "VND_FORCE_NT",
     // diagnosis builds
-    "VND_WIN_STAMPS", "VND_WIN_STAMP_PHASES",
+    "VND_WIN_STAMPS", "VND_WIN_STAMP_PHASES", "VND_WIN_STAMP_WAVE",
 };
 
 inline bool spec_tuning()

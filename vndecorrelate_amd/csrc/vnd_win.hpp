@@ -34,7 +34,13 @@ struct WinGeom {
     int quad = 0;        // 1: a workgroup takes a channel QUAD (16 bytes of every frame), a quarter of its lanes per CHANNEL; 2: an OCTET (32 bytes), an eighth
     int split = 0;       // 1: stereo, half the workgroup's waves per CHANNEL
     int nh() const { return split ? nt / 2 : (quad ? nt / (4 * quad) : nt); }   // lanes - and ring entries of a tile - per channel pair (split, quad: per channel)
-    size_t lds_bytes() const { return (size_t)(quad ? 2 * quad : 1) * (size_t)npl * (size_t)(M / 4) * (size_t)plane; }
+    // octets: the 4-byte staging writes and read-backs of a wave touch, per channel plane, one dword of 32 frames x 2 quads.  The frames
+    // fall into banks 8a + b (a = 0..7 chunk planes an odd number of slots apart, b = 0..3 frames of a chunk): half the banks.  The second
+    // quad's plane sets are shifted by 16 bytes so that it takes the other half (8a + 4 + b) instead of meeting the first in the same ones:
+    // SQ_LDS_BANK_CONFLICT 22.1 M -> 14.1 M cycles per cfg5 launch (tools/ablate/run_r4j.sh) - and the launch takes the same time: the
+    // staging phase is not what the LDS array limits.
+    int quad_pad() const { return quad == 2 ? 16 : 0; }
+    size_t lds_bytes() const { return (size_t)(quad ? 2 * quad : 1) * (size_t)npl * (size_t)(M / 4) * (size_t)plane + (size_t)quad_pad(); }
     int tile() const { return nh() * M; }
 };
 
@@ -533,7 +539,7 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
     spec_append(s, "#define VW_NT %d\n#define VW_M %d\n#define VW_R %d\n#define VW_G %d\n#define VW_NB %d\n#define VW_DE %d\n#define VW_PLANE %d\n#define VW_LA %d\n",
                 g.nt, g.M, g.R, g.G, g.NB, g.DE, g.plane, c.la);
     spec_append(s, "#define VW_NT_STORES %d\n#define VW_EPI %d\n#define VW_BC %d\n#define VW_EXACT %d\n#define VW_C %d\n", c.nt_stores, c.epi, c.bc, c.exact, g.C);
-    spec_append(s, "#define VW_Q %d\n#define VW_S %d\n", g.quad, g.split);
+    spec_append(s, "#define VW_Q %d\n#define VW_S %d\n#define VW_QUADPAD %d\n", g.quad, g.split, g.quad_pad());
     // split form: how many of a wave's M/4 refill accesses per tile are loaded late (at the start of the store phase that consumes
     // them) instead of a tile ahead: 64-frame runs keep half of them out of the tap phase's registers
     // (the fast mode's E / P accumulators are twice the exact mode's sums: all but one late there - hipRTC's build of cfg2's table
@@ -546,6 +552,7 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
     spec_append(s, "#define VW_XPOSE_PAIRS %d\n", xpose);
     spec_append(s, "#define VW_LANE_SWIZZLE %d\n", g.M == 32 ? 1 : 0);
     spec_append(s, "#define VW_STAMP_PHASES %d\n", spec_env("VND_WIN_STAMP_PHASES", 1) != 0 ? 1 : 0);
+    spec_append(s, "#define VW_STAMP_WAVE %d\n", std::max(0, spec_env("VND_WIN_STAMP_WAVE", 0)));      // (whose clock readings the phase stamps are)
     spec_append(s, "#define VW_STAMPS %d\n", std::min(std::max(spec_env("VND_WIN_STAMPS", 0), 0), 4096));
     // s_setprio of the store / refill phase (0: none): cfg2 +1.0 % fast, +0.5 % exact at 1, 2 or 3; cfg3 unchanged (tools/win_phase_try.py)
     spec_append(s, "#define VW_PRIO %d\n", spec_env("VND_WIN_PRIO", 1));
