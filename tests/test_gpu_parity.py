@@ -814,8 +814,10 @@ def test_block_sums_from_the_convolutions_store_phase(vnd):
     xd = torch.from_numpy(x).cuda()
     ws_bytes = _native.decorrelate_workspace_bytes(batch, n, 2)
     out = {}
-    for label, variant, prepare in (('generic', -1, False), ('per-stream', 1 << 19, True), ('from the store phase', -1, True),
-                                    ('block sums off', -1, True)):
+    # (the one-workgroup-per-stream kernel itself comes in two shapes: a workgroup per ARRAY of a stream - x's chains, y's chains -
+    #  when there are fewer streams than two per CU, one per stream otherwise: VND_EPI_SEQ_SPLIT=0)
+    for label, variant, prepare in (('generic', -1, False), ('per-stream', 1 << 19, True), ('per-stream, unsplit', 1 << 19, True),
+                                    ('from the store phase', -1, True), ('block sums off', -1, True)):
         table = _native.TapTable.create(ctx, *[getattr(vn._tap_arrays(), k) for k in ('tap_offsets', 'tap_index', 'tap_weight')], **vn._tap_arrays().kwargs())
         ctx.set_variant(variant)
         if prepare:
@@ -823,6 +825,8 @@ def test_block_sums_from_the_convolutions_store_phase(vnd):
             assert table.describe(batch, n, 2, vnd.MODE_EXACT).startswith('conv_spec_exact_window')
         if label == 'block sums off':
             os.environ['VND_EPI_BLOCK_SUMS'] = '0'
+        if label == 'per-stream, unsplit':
+            os.environ['VND_EPI_SEQ_SPLIT'] = '0'
         try:
             yd = torch.empty_like(xd)
             ws = torch.zeros(ws_bytes // 8 + 1, dtype=torch.float64, device='cuda')
@@ -831,6 +835,7 @@ def test_block_sums_from_the_convolutions_store_phase(vnd):
             torch.cuda.synchronize()
         finally:
             os.environ.pop('VND_EPI_BLOCK_SUMS', None)
+            os.environ.pop('VND_EPI_SEQ_SPLIT', None)
             ctx.set_variant(-1)
         out[label] = (ws[:4 * batch].cpu().numpy().copy(), yd.cpu().numpy())
         table.close()

@@ -40,6 +40,7 @@ struct EArgs {
     int32_t exact_rms;               // sums are the reference's sequential float32 sums (one row per stream)
     float eps;
     int32_t wide;                    // every stream of x and y starts 16-byte aligned (8-byte for a mono x): the sums kernel loads two frames per access
+    int32_t seq_split;               // sequential sums, stereo: TWO workgroups per stream - one for x's chains, one for y's (grid = 2 * batch)
 };
 
 __device__ __forceinline__ double block_sum(double v, double *scratch)
@@ -429,8 +430,13 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
 {
     extern __shared__ __attribute__((aligned(16))) float sq[];      // [2C][BF]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, waves = blockDim.x >> 6;
-    const int C = STEREO ? 2 : a.C, Cx = a.Cx, chains = 2 * C;
-    const int64_t b = blockIdx.x;
+    const int C = STEREO ? 2 : a.C, Cx = a.Cx;
+    // (stereo, seq_split: the x chains and the y chains of a stream are independent recurrences over different arrays - a workgroup
+    //  each doubles the loads in flight when there are fewer streams than two per CU: 256 x 10 s 0.57 -> 0.4x ms)
+    const bool split = STEREO && a.seq_split != 0;
+    const int arr = split ? (int)(blockIdx.x & 1) : 0;               // split: 0 = x's chains, 1 = y's
+    const int chains = split ? C : 2 * C;
+    const int64_t b = split ? blockIdx.x >> 1 : blockIdx.x;
     const int64_t n = a.n;
     const float *__restrict__ xs = a.x + b * a.n * Cx;
     const float *__restrict__ ys = a.y + b * a.n * C;
@@ -447,8 +453,11 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
 #pragma unroll
                     for (int k = 0; k < 4; k += 2) {
                         const int fr = u * (BF / PER) + 4 * tid + k;
-                        const v4f ty = buf_load4(ry, fr * 8, 0, 0);
-                        yr[u][k] = v2f{ty.x, ty.y}; yr[u][k + 1] = v2f{ty.z, ty.w};
+                        if (!split || arr == 1) {
+                            const v4f ty = buf_load4(ry, fr * 8, 0, 0);
+                            yr[u][k] = v2f{ty.x, ty.y}; yr[u][k + 1] = v2f{ty.z, ty.w};
+                        }
+                        if (split && arr == 1) continue;
                         if constexpr (MONO) {
                             const v2f v = buf_load2(rx, fr * 4, 0, 0);
                             xr[u][k] = v2f{v.x, v.x}; xr[u][k + 1] = v2f{v.y, v.y};
@@ -462,7 +471,8 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int fr = u * (BF / PER) + 4 * tid + k;
-                    yr[u][k] = buf_load2(ry, fr * 8, 0, 0);
+                    if (!split || arr == 1) yr[u][k] = buf_load2(ry, fr * 8, 0, 0);
+                    if (split && arr == 1) continue;
                     if constexpr (MONO) {
                         const float v = buf_load1(rx, fr * 4, 0, 0);
                         xr[u][k] = v2f{v, v};
@@ -478,6 +488,12 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
                 float4 *dst = (float4 *)(sq + u * (BF / PER) + 4 * tid);
+                if (split) {                                   // this workgroup's array only: its two chains are rows 0 and 1
+                    const v2f (&vr)[4] = arr ? yr[u] : xr[u];
+                    dst[0 * BF / 4] = make_float4(vr[0].x * vr[0].x, vr[1].x * vr[1].x, vr[2].x * vr[2].x, vr[3].x * vr[3].x);
+                    dst[1 * BF / 4] = make_float4(vr[0].y * vr[0].y, vr[1].y * vr[1].y, vr[2].y * vr[2].y, vr[3].y * vr[3].y);
+                    continue;
+                }
                 dst[0 * BF / 4] = make_float4(xr[u][0].x * xr[u][0].x, xr[u][1].x * xr[u][1].x,
                                               xr[u][2].x * xr[u][2].x, xr[u][3].x * xr[u][3].x);
                 dst[1 * BF / 4] = make_float4(xr[u][0].y * xr[u][0].y, xr[u][1].y * xr[u][1].y,
@@ -512,7 +528,7 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
     }
     int slot = 0;
     for (int ch = wave; ch < chains; ch += waves, ++slot)
-        if (lane == 0) a.partials[b * a.rows * chains + ch] = (double)acc[slot];
+        if (lane == 0) a.partials[b * a.rows * (2 * C) + arr * C + ch] = (double)acc[slot];      // x's chains, then y's
 }
 
 // ---- the same sums, parallel over the stream (stereo tables) -----------------

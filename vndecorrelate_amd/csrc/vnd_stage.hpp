@@ -180,7 +180,10 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
                                                     : epilogue_rms_seq_kernel<false, false, kSeqFramesWide>);
         if (lds > 65536) HIP_TRY(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                       ctx->lds_limit));
-        hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(64 * waves), lds, stream, e);
+        // stereo, fewer streams than two per CU: a workgroup per ARRAY of a stream (x's chains, y's chains) - twice the loads in flight
+        const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+        e.seq_split = (C == 2 && batch < 2 * (int64_t)cus && spec_env("VND_EPI_SEQ_SPLIT", 1) != 0) ? 1 : 0;
+        hipLaunchKernelGGL(k, dim3((unsigned)(e.seq_split ? 2 * batch : batch)), dim3(64 * waves), lds, stream, e);
     }
     if (normalize) {
         hipLaunchKernelGGL(epilogue_reduce_kernel, dim3((unsigned)batch), dim3(kEpiThreads), 0, stream, e);
