@@ -521,7 +521,7 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
         __syncthreads();                                   // every wave is done with the previous block
         stage(f0);
         __syncthreads();
-        if (f0 + BF < n) fetch(f0 + BF);                   // (two blocks in flight measured no faster)
+        if (f0 + BF < n) fetch(f0 + BF);                   // (two blocks in flight: no faster in round 1; with the per-array split of round 4 slower - 256 x 10 s 0.51 -> 0.78 ms)
         int slot = 0;
         for (int ch = wave; ch < chains; ch += waves, ++slot)
             acc[slot] = seq_sum_block<BF>(sq + ch * BF, acc[slot], lane);
