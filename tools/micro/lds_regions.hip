@@ -1,0 +1,77 @@
+// Where in the 160 KB of LDS do a workgroup's waves read?  cfg5's octet kernel streams its window reads at ~8 clocks per ds_read_b128 and
+// CU, pk_fma_rate.hip's two 32 KB workgroups at 4.3.  One workgroup of NW waves, every wave a stream of conflict-free ds_read_b128 (64
+// consecutive 16-byte pieces, base + immediate, 4 in flight, nothing else), the waves' bases laid out by MODE over a region of `span` bytes.
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/micro/lds_regions tools/micro/lds_regions.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(_e), __LINE__); exit(1); } } while (0)
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4f lds_v4f;
+typedef __attribute__((address_space(3))) char lds_char;
+#define RD(base, imm) (*(const volatile lds_v4f *)((base) + (imm)))
+
+template <int NT>
+__global__ __launch_bounds__(NT) void reads_kernel(float *out, int trips, int wave_stride, int lane_stride, int step)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds_generic[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    lds_char *base = (lds_char *)(__attribute__((address_space(3))) float *)lds_generic + (wave_stride >= 0 ? wave * wave_stride : (wave & 1) * 80 * 1024 + (wave >> 1) * -wave_stride) + lane * lane_stride;
+    v4f q[4];
+    v4f acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = RD(base, k * 1024);
+    for (int t = 0; t < trips; ++t) {
+        lds_char *b = base + (t & 7) * step;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const v4f c = q[g % 4];
+            q[g % 4] = RD(b, (g % 8) * 1024);
+            acc += c;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = acc.x;
+}
+
+template <int NT>
+static void run(const char *what, int grid, int lds_bytes, int wave_stride, int lane_stride, int step)
+{
+    float *out;
+    CK(hipMalloc(&out, 4));
+    CK(hipFuncSetAttribute((const void *)reads_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const int trips = 4000;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    reads_kernel<NT><<<grid, NT, lds_bytes>>>(out, trips, wave_stride, lane_stride, step);
+    CK(hipDeviceSynchronize());
+    float best = 1e9f;
+    for (int r = 0; r < 5; ++r) {
+        CK(hipEventRecord(e0));
+        reads_kernel<NT><<<grid, NT, lds_bytes>>>(out, trips, wave_stride, lane_stride, step);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+    }
+    const double reads = (double)grid * (NT / 64) * trips * 16;
+    printf("%-92s %8.4f ms  %6.1f TB/s over the chip = %6.1f B per ns and CU\n", what, best, reads * 1024 / best / 1e9, reads * 1024 / best / 1e6 / 256);
+    CK(hipFree(out));
+}
+
+int main()
+{
+    const int cus = 256;
+    printf("one workgroup per CU unless said; ds_read_b128 streams, 4 in flight per wave, no other work\n");
+    run<256>("4 waves, 32 KB of LDS, waves 1 KB apart (pk_fma_rate's layout)", cus, 32 * 1024, 1024, 16, 0);
+    run<256>("4 waves, 32 KB, TWO workgroups per CU", 2 * cus, 32 * 1024, 1024, 16, 0);
+    run<256>("4 waves, 80 KB each, TWO workgroups per CU (the stereo kernels' residency), waves 16 KB apart", 2 * cus, 80 * 1024, 16 * 1024, 16, 0);
+    run<512>("8 waves, 32 KB, waves 1 KB apart", cus, 32 * 1024, 1024, 16, 0);
+    run<512>("8 waves, 158 KB, waves 1 KB apart (all in the first 16 KB)", cus, 158 * 1024, 1024, 16, 0);
+    run<512>("8 waves, 158 KB, waves 19 KB apart (a channel's planes each: the octet kernel)", cus, 158 * 1024, 19 * 1024, 16, 0);
+    run<512>("8 waves, 158 KB, waves 19 KB apart, the stream walking 8 x 1264 B further every 16 reads", cus, 158 * 1024, 19 * 1024, 16, 1264);
+    run<512>("8 waves, 158 KB, waves 9.5 KB apart (first half of LDS only)", cus, 158 * 1024, 9728, 16, 0);
+    run<512>("8 waves, 158 KB, even waves 16 KB apart in the first half, odd waves 80 KB further", cus, 158 * 1024, -16 * 1024, 16, 0);
+    run<256>("4 waves, 158 KB, waves 38 KB apart", cus, 158 * 1024, 38 * 1024, 16, 0);
+    run<512>("8 waves, 158 KB, waves 19 KB apart, lanes 32 B apart (2-way conflicts)", cus, 158 * 1024, 19 * 1024, 32, 0);
+    return 0;
+}
