@@ -13,12 +13,15 @@ arr = function_path_arrays(vnd.generate_velvet_noise(duration_seconds=0.03, num_
 pool, n = 128, 480000
 st = torch.cuda.current_stream().cuda_stream
 settings = [dict(), dict(VND_WIN_CHUNKS='0'), dict(VND_WIN_CHUNKS='0', VND_WIN_PACE_MIN_TILES='8'), dict(VND_WIN_CHUNK_LEN0='15'), dict(VND_WIN_CHUNK_LEN0='16')]
+if len(sys.argv) > 1:          # settings from the command line: K=V,K=V groups (an empty group "-" is the default)
+    settings = [dict(kv.split('=', 1) for kv in g.split(',') if '=' in kv) for g in sys.argv[1:]]
+names = sorted({k for g in settings for k in g} | {'VND_WIN_CHUNKS', 'VND_WIN_PACE_MIN_TILES', 'VND_WIN_CHUNK_LEN0'})
 for cx in (1, 2):
     x = torch.empty((pool, n, cx), dtype=torch.float32, device='cuda').uniform_(-1, 1)
     y = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda')
     for rep in range(2):
         for env in settings:
-            for k in ('VND_WIN_CHUNKS', 'VND_WIN_PACE_MIN_TILES', 'VND_WIN_CHUNK_LEN0'):
+            for k in names:
                 os.environ.pop(k, None)
             os.environ.update(env)
             table = _native.TapTable.create(ctx, arr.tap_offsets, arr.tap_index, arr.tap_weight)
@@ -33,5 +36,5 @@ for cx in (1, 2):
                 e1.record(); torch.cuda.synchronize()
                 out.append(e0.elapsed_time(e1) / 300)
             d = table.describe(pool, n, cx, 2)
-            print(f'{"mono  " if cx == 1 else "stereo"} {str(env):70s} fast {out[0]:.4f} ms  exact {out[1]:.4f} ms   {d[d.find("workgroups="):][:90]}', flush=True)
+            print(f'{"mono  " if cx == 1 else "stereo"} {str(env):70s} fast {out[0]:.4f} ms  exact {out[1]:.4f} ms   {d[d.find("reads_ahead="):][:60]}', flush=True)
             table.close()
