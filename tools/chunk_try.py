@@ -15,6 +15,8 @@ from oracle import c_oracle
 ctx = _native.default_context()
 arr = function_path_arrays(vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1))
 taps = (arr.tap_offsets, arr.tap_index, arr.tap_weight)
+forced = [a.split('=', 1)[1] for a in sys.argv[1:] if a.startswith('len0=')]          # len0=4: also try a forced split of a CU's chunk (first workgroup's tiles)
+sys.argv = [a for a in sys.argv if not a.startswith('len0=')]
 shapes = [(int(sys.argv[i]), int(sys.argv[i + 1])) for i in range(1, len(sys.argv) - 1, 2)] or [(128, 48000), (64, 96000), (256, 30000), (128, 40000), (32, 200000)]
 side = torch.cuda.Stream()
 
@@ -46,8 +48,9 @@ for mine, n in shapes:
     xs = [torch.empty((mine, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1) for _ in range(buffers)]
     ys = [torch.empty_like(xs[0]) for _ in range(buffers)]
     for env in (dict(VND_WIN_CHUNKS='0'), dict(VND_WIN_CHUNKS='1'), dict(VND_WIN_CHUNKS='1', VND_WIN_STAGGER_TICKS='150'),
-                dict(VND_WIN_CHUNKS='1', VND_WIN_STAGGER_TICKS='300'), dict(VND_WIN_CHUNKS='1', VND_WIN_STAGGER_TICKS='450')):
-        for k in ('VND_WIN_CHUNKS', 'VND_WIN_STAGGER_TICKS'):
+                dict(VND_WIN_CHUNKS='1', VND_WIN_STAGGER_TICKS='300'), dict(VND_WIN_CHUNKS='1', VND_WIN_STAGGER_TICKS='450')) + tuple(
+                dict(VND_WIN_CHUNKS='1', VND_WIN_CHUNK_LEN0=f, VND_WIN_STAGGER_TICKS=t) for f in forced for t in ('300', '600')):
+        for k in ('VND_WIN_CHUNKS', 'VND_WIN_STAGGER_TICKS', 'VND_WIN_CHUNK_LEN0'):
             os.environ.pop(k, None)
         os.environ.update(env)
         table = _native.TapTable.create(ctx, *taps)
