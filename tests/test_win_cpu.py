@@ -51,6 +51,7 @@ static inline v2f vw_pair(v2f a, v2f b) { return v2f{a.y, b.x}; }
 static inline float vw_add1(float a, float b) { return a + b; }
 static inline float vw_sub1(float a, float b) { return a - b; }
 %(defines)s
+#define VW_NBT VW_NB          /* (stereo forms: no tail behind the ring - the quad / octet forms' extra bases are the GPU tests' business) */
 %(function)s
 static unsigned wrap(unsigned a) { const unsigned b = a - (unsigned)VW_R; return a < b ? a : b; }
 extern "C" void run_lane(char *lds, unsigned pl, float *o0, float *o1)
@@ -370,7 +371,15 @@ def test_quads_and_octets_with_a_wave_per_channel(native, golden, tmp_path, mode
     monkeypatch.setenv('VND_WIN_OCTET', '1' if Q == 2 else '0')
     src = native.window_kernel_source(offs, idx, w, mode, M, nt)
     assert _macro(src, 'VW_Q') == Q and _macro(src, 'VW_S') == 0 and _macro(src, 'VW_C') == 8
-    assert _macro(src, 'VW_R') == nt // (4 * Q) + _macro(src, 'VW_DE')
+    # the ring is cut to a multiple of 16 entries (a wave that straddles its end stays in step with the banks); what is cut off - entries
+    # that only the tile's last lanes reach - lives in a TAIL behind the mirror, read through per-lane bases of its own
+    R, tail, DE, NB = (_macro(src, k) for k in ('VW_R', 'VW_TAIL', 'VW_DE', 'VW_NB'))
+    assert R + tail == nt // (4 * Q) + DE and R % 16 == 0 and 0 < tail < 16
+    assert _macro(src, 'VW_PLANE') // 16 >= R + _macro(src, 'VW_G') + tail
+    tail_reads = re.findall(r'VW_RD\(b\[\d\]\[(\d+)\], (\d+)\)', src)
+    used = {int(k) for k, _ in tail_reads if int(k) >= NB}
+    assert used and used <= set(range(NB, NB + tail))                                               # one base per entry offset past the ring
+    assert all(int(imm) % _macro(src, 'VW_PLANE') == 0 for k, imm in tail_reads if int(k) >= NB)    # ... and only the chunk plane as immediate
     assert 2 * Q * 2 * (M // 4) * _macro(src, 'VW_PLANE') <= 160 * 1024
     for pg in range(4):
         for ch in range(2):

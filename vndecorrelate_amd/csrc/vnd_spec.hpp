@@ -86,7 +86,7 @@ struct SpecTable {
 static const char *const kTuningNames[] = {
     // geometry of the per-table kernels
     "VND_SPEC_NT", "VND_SPEC_RR", "VND_SPEC_DD", "VND_SPEC_LA", "VND_SPEC_SHIFT", "VND_SPEC_QUAD_STORES", "VND_WIN_M", "VND_WIN_G", "VND_WIN_QUAD_M",
-    "VND_WIN_SPLIT_LATE", "VND_WIN_SPLIT_SMALL_NT",
+    "VND_WIN_SPLIT_LATE", "VND_WIN_SPLIT_SMALL_NT", "VND_WIN_TAIL",
     // which form runs
     "VND_WIN_EXACT", "VND_WIN_QUAD", "VND_WIN_OCTET", "VND_WIN_WIDE", "VND_WIN_SPLIT", "VND_WIN_SPLIT_FANOUT", "VND_WIN_XPOSE_PAIRS", "VND_WIN_FAR_FIRST",
     "VND_WIN_SOURCE_FANOUT", "VND_EPI_BLOCK_SUMS", "VND_EPI_WIDE", "VND_EPI_SEQ_SPLIT",

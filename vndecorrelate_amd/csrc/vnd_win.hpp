@@ -31,6 +31,7 @@ struct WinGeom {
     int NB = 0;          // base registers per channel
     int plane = 0;       // bytes between chunk planes
     int npl = 2;         // plane sets in LDS: one per output channel (a mono input fills only the first - the second is where channel 1's runs cross in the store phase)
+    int tail = 0;        // quads / octets: entries of the window kept OUTSIDE the ring so that the ring's length R is a multiple of 16 (NH + DE = R + tail)
     int quad = 0;        // 1: a workgroup takes a channel QUAD (16 bytes of every frame), a quarter of its lanes per CHANNEL; 2: an OCTET (32 bytes), an eighth
     int split = 0;       // 1: stereo, half the workgroup's waves per CHANNEL
     int nh() const { return split ? nt / 2 : (quad ? nt / (4 * quad) : nt); }   // lanes - and ring entries of a tile - per channel pair (split, quad: per channel)
@@ -61,11 +62,12 @@ inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size
     g->M = M; g->nt = nt; g->G = G; g->npl = 2; g->C = t.C; g->quad = quad; g->split = split ? 1 : 0;
     const int nh = g->nh();
     const int qc = M / 4;
-    auto lay_out = [&](int de) {
+    auto lay_out = [&](int de, int tail = 0) {
         g->DE = de;
-        g->R = nh + g->DE;
+        g->R = nh + g->DE - tail;
+        g->tail = tail;
         g->NB = g->DE / G + 1;
-        int units = g->R + G;                           // 16-byte slots of one chunk plane: ring + mirror
+        int units = g->R + G + tail;                    // 16-byte slots of one chunk plane: ring + mirror (+ tail)
         // the 8-byte accesses of the staging and of the transposition: 16 lanes at a time write (read) 32 dwords into 32 banks -
         // 8 planes x 2 halves of ONE entry with 32-frame runs (4 planes of two entries with 16, 8 of the 16 planes with 64) - so the
         // planes must lie an ODD multiple of 8/QC slots apart (QC = 8: an odd number of slots; QC = 4: 2 mod 4; QC = 16: odd).
@@ -91,7 +93,18 @@ inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size
     if (aligned != de) {
         const int before = win_workgroups_per_cu(*g);
         WinGeom plain = *g;
-        if (!(lay_out(aligned) && win_workgroups_per_cu(*g) >= before)) *g = plain;
+        if (!(lay_out(aligned) && win_workgroups_per_cu(*g) >= before)) {
+            *g = plain;
+            // quads / octets, where the longer halo does not fit (cfg5: 149 entries of eight channels are 153 of the 160 KB): the ring is
+            // CUT to the multiple of 16 below, and the few entries beyond it - which only the tile's last lanes reach, with their
+            // farthest taps - live in a TAIL behind the mirror, refilled a tile ahead like the ring; the lanes' reads of those entry
+            // offsets go through per-lane bases of their own (ring or tail).  Same LDS, no wave straddles a ring end out of step
+            // with the banks any more: SQ_LDS_BANK_CONFLICT 0.13 -> 0.0x of the LDS cycles on cfg5.
+            const int cut = (nh + de) % 16;
+            if (quad && spec_env("VND_WIN_TAIL", 1) != 0 && cut > 0 && nh + de - cut >= nh + G && cut <= (nt / 64) * (64 / (M * quad))) {
+                if (!(lay_out(de, cut) && win_workgroups_per_cu(*g) >= before)) *g = plain;
+            }
+        }
     }
     return true;
 }
@@ -163,7 +176,7 @@ inline std::string win_taps_channel_name(int pg, int ch)
 // vw_taps_of<PG>(): the pair's function by its number, and VW_DISPATCH: the kernel's span loop instantiated per channel pair
 inline std::string win_taps_dispatch(const SpecTable &t)
 {
-    std::string s = "template <int PG> __device__ __forceinline__ void vw_taps_of(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
+    std::string s = "template <int PG> __device__ __forceinline__ void vw_taps_of(vw_lchar *const (&b)[2][VW_NBT], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
     for (int pg = 0; pg < t.C / 2; ++pg)
         spec_append(s, "    %sif constexpr (PG == %d) %s(b, o0, o1);\n", pg ? "else " : "", pg, win_taps_name(pg).c_str());
     s += "}\n#define VW_DISPATCH(pg) switch (pg) {";
@@ -172,13 +185,25 @@ inline std::string win_taps_dispatch(const SpecTable &t)
     return s;
 }
 
+// the LDS operand of a window read: chunk (o % M) / 4 of the entry o / M past the lane's own - base register + immediate; entry offsets
+// that the tile's last lanes find in the TAIL (WinGeom::tail) have a per-lane base of their own, b[ch][NB + j]
+inline std::string win_rd(const WinGeom &g, int ch, int o)
+{
+    const int dE = o / g.M, rr = (o % g.M) / 4;
+    const int first_tail = g.R - g.nh() + 1;
+    char buf[96];
+    if (g.tail > 0 && dE >= first_tail) snprintf(buf, sizeof buf, "VW_RD(b[%d][%d], %d)", ch, g.NB + (dE - first_tail), rr * g.plane);
+    else { const int kb = dE / g.G; snprintf(buf, sizeof buf, "VW_RD(b[%d][%d], %d)", ch, kb, (dE - kb * g.G) * 16 + rr * g.plane); }
+    return buf;
+}
+
 inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int la, int pg = 0, int only_ch = -1)
 {
     const int M = g.M;
     std::string s;
     // (only_ch: the split form's per-channel function vw_taps_c<ch> - it leaves the other channel's outputs alone)
     const std::string fname = only_ch < 0 ? win_taps_name(pg) : win_taps_channel_name(pg, only_ch);
-    s += "__device__ __forceinline__ void " + fname + "(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
+    s += "__device__ __forceinline__ void " + fname + "(vw_lchar *const (&b)[2][VW_NBT], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
     spec_append(s, "    v4f q[%d];\n    v2f E[%d], P[%d];\n    float O0, OL;\n", la + 1, M / 2, M / 2);
     // one read stream over both channels: the pipeline stays full across the channel boundary
     std::vector<WinRead> reads;
@@ -198,8 +223,7 @@ inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int l
     first_of_ch[2] = reads.size();
     auto emit_read = [&](size_t k) {
         const WinRead &r = reads[k];
-        const int dE = r.o / M, rr = (r.o % M) / 4, kb = dE / g.G;
-        spec_append(s, "    q[%zu] = VW_RD(b[%d][%d], %d);\n", k % (size_t)(la + 1), r.ch, kb, (dE - kb * g.G) * 16 + rr * g.plane);
+        spec_append(s, "    q[%zu] = %s;\n", k % (size_t)(la + 1), win_rd(g, r.ch, r.o).c_str());
     };
     auto emit_merge = [&](int ch, const std::vector<char> &e_used, const std::vector<char> &p_used, bool o0_used, bool ol_used) {
         for (int j = 0; j < M; ++j) {
@@ -356,7 +380,7 @@ inline std::string win_taps_function_merged(const SpecTable &t, const WinGeom &g
 {
     const int M = g.M;
     std::string s;
-    s += "__device__ __forceinline__ void " + win_taps_name(pg) + "(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
+    s += "__device__ __forceinline__ void " + win_taps_name(pg) + "(vw_lchar *const (&b)[2][VW_NBT], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
     spec_append(s, "    v4f q[%d];\n    v2f E0[%d], P0[%d], E1[%d], P1[%d];\n    float O00, OL0, O01, OL1;\n", la + 1, M / 2, M / 2, M / 2, M / 2);
     struct Rd { int o; std::vector<std::pair<int, WinOp>> ops; };           // (channel, op)
     std::map<int, Rd> by_o;
@@ -370,8 +394,7 @@ inline std::string win_taps_function_merged(const SpecTable &t, const WinGeom &g
     for (auto &kv : by_o) reads.push_back(std::move(kv.second));
     if (spec_env("VND_WIN_FAR_FIRST", 1) != 0) std::reverse(reads.begin(), reads.end());      // (small terms first: win_taps_function)
     auto emit_read = [&](size_t k) {
-        const int dE = reads[k].o / M, rr = (reads[k].o % M) / 4, kb = dE / g.G;
-        spec_append(s, "    q[%zu] = VW_RD(b[0][%d], %d);\n", k % (size_t)(la + 1), kb, (dE - kb * g.G) * 16 + rr * g.plane);
+        spec_append(s, "    q[%zu] = %s;\n", k % (size_t)(la + 1), win_rd(g, 0, reads[k].o).c_str());
     };
     std::vector<char> e_used[2] = {std::vector<char>(M / 2, 0), std::vector<char>(M / 2, 0)}, p_used[2] = {std::vector<char>(M / 2, 0), std::vector<char>(M / 2, 0)};
     bool o0_used[2] = {false, false}, ol_used[2] = {false, false};
@@ -423,7 +446,7 @@ inline std::string win_taps_function_exact(const SpecTable &t, const WinGeom &g,
     const size_t ring = (size_t)la + 2;                  // read k lands in q[k % ring]: the previous chunk stays whole while read k + la is issued
     std::string s;
     const std::string fname = only_ch < 0 ? win_taps_name(pg) : win_taps_channel_name(pg, only_ch);
-    s += "__device__ __forceinline__ void " + fname + "(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
+    s += "__device__ __forceinline__ void " + fname + "(vw_lchar *const (&b)[2][VW_NBT], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
     spec_append(s, "    v4f q[%zu];\n    v2f S[%d], A[%d];\n    const v2f Z2 = {0.0f, 0.0f};\n", ring, M / 2, M / 2);
     std::vector<WinExPass> passes;
     std::vector<WinExRead> reads;
@@ -438,9 +461,8 @@ inline std::string win_taps_function_exact(const SpecTable &t, const WinGeom &g,
     }
     pass_first[2] = passes.size();
     auto emit_read = [&](size_t k) {
-        const WinExRead &r = reads[k];
-        const int dE = r.o / M, rr = (r.o % M) / 4, kb = dE / g.G;       // (a lent chunk may lie before the lane's run only if o < 0: never, o >= 0)
-        spec_append(s, "    q[%zu] = VW_RD(b[%d][%d], %d);\n", k % ring, r.ch, kb, (dE - kb * g.G) * 16 + rr * g.plane);
+        const WinExRead &r = reads[k];                                   // (a lent chunk may lie before the lane's run only if o < 0: never, o >= 0)
+        spec_append(s, "    q[%zu] = %s;\n", k % ring, win_rd(g, r.ch, r.o).c_str());
     };
     for (size_t k = 0; k < std::min(reads.size(), (size_t)la); ++k) emit_read(k);
     size_t rk = 0;
@@ -539,7 +561,7 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
     spec_append(s, "#define VW_NT %d\n#define VW_M %d\n#define VW_R %d\n#define VW_G %d\n#define VW_NB %d\n#define VW_DE %d\n#define VW_PLANE %d\n#define VW_LA %d\n",
                 g.nt, g.M, g.R, g.G, g.NB, g.DE, g.plane, c.la);
     spec_append(s, "#define VW_NT_STORES %d\n#define VW_EPI %d\n#define VW_BC %d\n#define VW_EXACT %d\n#define VW_C %d\n", c.nt_stores, c.epi, c.bc, c.exact, g.C);
-    spec_append(s, "#define VW_Q %d\n#define VW_S %d\n#define VW_QUADPAD %d\n", g.quad, g.split, g.quad_pad());
+    spec_append(s, "#define VW_Q %d\n#define VW_S %d\n#define VW_QUADPAD %d\n#define VW_TAIL %d\n", g.quad, g.split, g.quad_pad(), g.tail);
     // split form: how many of a wave's M/4 refill accesses per tile are loaded late (at the start of the store phase that consumes
     // them) instead of a tile ahead: 64-frame runs keep half of them out of the tap phase's registers
     // (the fast mode's E / P accumulators are twice the exact mode's sums: all but one late there - hipRTC's build of cfg2's table
@@ -575,8 +597,8 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
         const int nch = 4 * g.quad;
         for (int pg = 0; pg < t.C / 2; ++pg)
             for (int ch = 0; ch < 2; ++ch) src += c.exact ? win_taps_function_exact(t, g, c.la, pg, ch) : win_taps_function(t, g, c.la, pg, ch);
-        src += "template <int PG> __device__ void vw_taps_of(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M]);      // (vw_span, vw_span_q: not instantiated)\n";
-        src += "template <int QD> __device__ __forceinline__ void vw_taps_of_channel(int pc, vw_lchar *const (&b)[2][VW_NB], float (&o)[VW_M])\n{\n";
+        src += "template <int PG> __device__ void vw_taps_of(vw_lchar *const (&b)[2][VW_NBT], float (&o0)[VW_M], float (&o1)[VW_M]);      // (vw_span, vw_span_q: not instantiated)\n";
+        src += "template <int QD> __device__ __forceinline__ void vw_taps_of_channel(int pc, vw_lchar *const (&b)[2][VW_NBT], float (&o)[VW_M])\n{\n";
         for (int qd = 0; qd < t.C / nch; ++qd) {
             spec_append(src, "    %sif constexpr (QD == %d) {\n        switch (pc) {\n", qd ? "else " : "", qd);
             for (int pc = 0; pc < nch; ++pc)
@@ -589,7 +611,7 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
         src += " default: break; }\n";
     } else if (g.split) {
         for (int ch = 0; ch < 2; ++ch) src += c.exact ? win_taps_function_exact(t, g, c.la, 0, ch) : win_taps_function(t, g, c.la, 0, ch);
-        src += "template <int PG> __device__ void vw_taps_of(vw_lchar *const (&b)[2][VW_NB], float (&o0)[VW_M], float (&o1)[VW_M]);      // (vw_span: not instantiated)\n";
+        src += "template <int PG> __device__ void vw_taps_of(vw_lchar *const (&b)[2][VW_NBT], float (&o0)[VW_M], float (&o1)[VW_M]);      // (vw_span: not instantiated)\n";
         src += "#define VW_DISPATCH(pg) vw_span_s(a, lds, stream, t_first, ntiles, flags, pace);\n";
     } else {
         const bool merged = c.bc && !c.exact;      // (one read stream for both channels of a mono input)
