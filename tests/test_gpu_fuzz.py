@@ -21,7 +21,10 @@ def span_bits(min_span, rounds):
 
 # (channels, span of the offsets, most taps per channel): the shapes are laid out, what fills them is drawn
 CASES = [(2, 700, 40), (8, 700, 24), (3, 64, 20), (2, 2500, 40), (4, 1500, 30), (6, 300, 16), (2, 8, 8), (1, 700, 30),
-         (2, 3000, 60), (4, 8, 6)]
+         (2, 3000, 60), (4, 8, 6),
+         # halos that eight (four) channels cannot round up to a multiple of 16 ring entries inside 160 KB: the ring is cut and its last
+         # entries live in a tail (WinGeom::tail) - random taps at every offset the tile's last lanes find there
+         (8, 2719, 30), (8, 2650, 40), (4, 2719, 24), (16, 2719, 10)]
 
 
 @pytest.mark.parametrize('seed', range(len(CASES)))

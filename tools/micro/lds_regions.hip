@@ -73,5 +73,8 @@ int main()
     run<512>("8 waves, 158 KB, even waves 16 KB apart in the first half, odd waves 80 KB further", cus, 158 * 1024, -16 * 1024, 16, 0);
     run<256>("4 waves, 158 KB, waves 38 KB apart", cus, 158 * 1024, 38 * 1024, 16, 0);
     run<512>("8 waves, 158 KB, waves 19 KB apart, lanes 32 B apart (2-way conflicts)", cus, 158 * 1024, 19 * 1024, 32, 0);
+    // a wave's 1 KB starting at any 16-byte slot (the ring position of its first lane), planes 2528 B apart as in the octet kernel
+    run<512>("8 waves, 158 KB, waves 19 KB + 16 B apart (starts 16 B past a 1 KB boundary, 32 B, ...)", cus, 158 * 1024, 19 * 1024 + 16, 16, 0);
+    run<512>("8 waves, 158 KB, waves 19 KB + 112 B apart", cus, 158 * 1024, 19 * 1024 + 112, 16, 0);
     return 0;
 }
