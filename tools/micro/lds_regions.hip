@@ -34,6 +34,58 @@ __global__ __launch_bounds__(NT) void reads_kernel(float *out, int trips, int wa
     if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = acc.x;
 }
 
+// the generated tap function's shape: NBASE per-lane base registers 128 B apart, immediates = entry * 16 + chunk plane * 2528, descending
+template <int NT>
+__global__ __launch_bounds__(NT) void bases_kernel(float *out, int trips, int wave_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds_generic[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    lds_char *b[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        b[k] = (lds_char *)(__attribute__((address_space(3))) float *)lds_generic + wave * wave_stride + lane * 16 + ((k * 8 * 16 + 64 * 16) % (86 * 16));
+        asm volatile("" : "+v"(b[k]));
+    }
+    v4f q[5];
+    v4f acc = {0, 0, 0, 0};
+    for (int t = 0; t < trips; ++t) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = RD(b[10], (7 - k) * 2528 + 5 * 16);
+#pragma unroll
+        for (int g = 0; g < 80; ++g) {
+            const int n = g + 4, kb = 10 - (n / 8) % 11, r = 7 - n % 8;
+            q[n % 5] = RD(b[kb], r * 2528 + ((n * 3) % 8) * 16);
+            acc += q[g % 5];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = acc.x;
+}
+
+template <int NT>
+static void run_bases(const char *what, int grid, int lds_bytes, int wave_stride)
+{
+    float *out;
+    CK(hipMalloc(&out, 4));
+    CK(hipFuncSetAttribute((const void *)bases_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const int trips = 800;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    bases_kernel<NT><<<grid, NT, lds_bytes>>>(out, trips, wave_stride);
+    CK(hipDeviceSynchronize());
+    float best = 1e9f;
+    for (int r = 0; r < 5; ++r) {
+        CK(hipEventRecord(e0));
+        bases_kernel<NT><<<grid, NT, lds_bytes>>>(out, trips, wave_stride);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+    }
+    const double reads = (double)grid * (NT / 64) * trips * 84;
+    printf("%-92s %8.4f ms  %6.1f TB/s over the chip = %6.1f B per ns and CU\n", what, best, reads * 1024 / best / 1e9, reads * 1024 / best / 1e6 / 256);
+    CK(hipFree(out));
+}
+
 template <int NT>
 static void run(const char *what, int grid, int lds_bytes, int wave_stride, int lane_stride, int step)
 {
@@ -76,5 +128,7 @@ int main()
     // a wave's 1 KB starting at any 16-byte slot (the ring position of its first lane), planes 2528 B apart as in the octet kernel
     run<512>("8 waves, 158 KB, waves 19 KB + 16 B apart (starts 16 B past a 1 KB boundary, 32 B, ...)", cus, 158 * 1024, 19 * 1024 + 16, 16, 0);
     run<512>("8 waves, 158 KB, waves 19 KB + 112 B apart", cus, 158 * 1024, 19 * 1024 + 112, 16, 0);
+    run_bases<512>("8 waves, 158 KB: eleven per-lane bases, immediates over eight chunk planes 2528 B apart (the tap function's reads)", cus, 158 * 1024, 19 * 1024);
+    run_bases<256>("4 waves, the same", cus, 158 * 1024, 38 * 1024);
     return 0;
 }
