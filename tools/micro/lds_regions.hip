@@ -62,6 +62,71 @@ __global__ __launch_bounds__(NT) void bases_kernel(float *out, int trips, int wa
     if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = acc.x;
 }
 
+// ... as STRAIGHT-LINE code, 336 reads per trip (a tile's tap function), the same function for every wave or one per wave (the octet
+// kernel runs eight different ones): is it the instruction stream?
+#define SR_STEP(g, W) q[((g) + 4) % 5] = RD(b[10 - (((g) + W) % 11)], (7 - ((g) + W) % 8) * 2528 + ((((g) + W) * 3) % 8) * 16); acc += q[(g) % 5]; __builtin_amdgcn_sched_barrier(0);
+#define SR_BLOCK(W) SR_STEP(0, W) SR_STEP(1, W) SR_STEP(2, W) SR_STEP(3, W) SR_STEP(4, W)
+#define SR2(x) x x
+#define SR4(x) SR2(x) SR2(x)
+#define SR16(x) SR4(x) SR4(x) SR4(x) SR4(x)
+#define SR64(x) SR16(x) SR16(x) SR16(x) SR16(x)
+template <int W>
+__device__ __forceinline__ void straight_reads(lds_char *const (&b)[11], v4f &acc)
+{
+    v4f q[5];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = RD(b[10], (7 - k) * 2528 + 5 * 16 + W * 16);
+    SR64(SR_BLOCK(W)) SR2(SR_BLOCK(W)) SR_BLOCK(W)          // 67 blocks of 5 reads
+}
+template <int NT, bool PER_WAVE>
+__global__ __launch_bounds__(NT) void straight_kernel(float *out, int trips, int wave_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds_generic[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    lds_char *b[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        b[k] = (lds_char *)(__attribute__((address_space(3))) float *)lds_generic + wave * wave_stride + lane * 16 + ((k * 8 * 16 + 64 * 16) % (86 * 16));
+        asm volatile("" : "+v"(b[k]));
+    }
+    v4f acc = {0, 0, 0, 0};
+    for (int t = 0; t < trips; ++t) {
+        if constexpr (PER_WAVE) {
+            switch (wave) {
+            case 0: straight_reads<0>(b, acc); break; case 1: straight_reads<1>(b, acc); break; case 2: straight_reads<2>(b, acc); break;
+            case 3: straight_reads<3>(b, acc); break; case 4: straight_reads<4>(b, acc); break; case 5: straight_reads<5>(b, acc); break;
+            case 6: straight_reads<6>(b, acc); break; default: straight_reads<7>(b, acc); break;
+            }
+        } else {
+            straight_reads<0>(b, acc);
+        }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = acc.x;
+}
+template <int NT, bool PER_WAVE>
+static void run_straight(const char *what, int grid, int lds_bytes, int wave_stride)
+{
+    float *out;
+    CK(hipMalloc(&out, 4));
+    CK(hipFuncSetAttribute((const void *)straight_kernel<NT, PER_WAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const int trips = 200;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    straight_kernel<NT, PER_WAVE><<<grid, NT, lds_bytes>>>(out, trips, wave_stride);
+    CK(hipDeviceSynchronize());
+    float best = 1e9f;
+    for (int r = 0; r < 5; ++r) {
+        CK(hipEventRecord(e0));
+        straight_kernel<NT, PER_WAVE><<<grid, NT, lds_bytes>>>(out, trips, wave_stride);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+    }
+    const double reads = (double)grid * (NT / 64) * trips * 335;
+    printf("%-92s %8.4f ms  %6.1f TB/s over the chip = %6.1f B per ns and CU\n", what, best, reads * 1024 / best / 1e9, reads * 1024 / best / 1e6 / 256);
+    CK(hipFree(out));
+}
+
 template <int NT>
 static void run_bases(const char *what, int grid, int lds_bytes, int wave_stride)
 {
@@ -130,5 +195,7 @@ int main()
     run<512>("8 waves, 158 KB, waves 19 KB + 112 B apart", cus, 158 * 1024, 19 * 1024 + 112, 16, 0);
     run_bases<512>("8 waves, 158 KB: eleven per-lane bases, immediates over eight chunk planes 2528 B apart (the tap function's reads)", cus, 158 * 1024, 19 * 1024);
     run_bases<256>("4 waves, the same", cus, 158 * 1024, 38 * 1024);
+    run_straight<512, false>("8 waves, 158 KB: the same reads as 336 straight-line instructions per trip, one function for all waves", cus, 158 * 1024, 19 * 1024);
+    run_straight<512, true>("8 waves, 158 KB: ... a function of its own per wave (8 x 336 reads of code)", cus, 158 * 1024, 19 * 1024);
     return 0;
 }
