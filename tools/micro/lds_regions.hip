@@ -36,14 +36,16 @@ __global__ __launch_bounds__(NT) void reads_kernel(float *out, int trips, int wa
 
 // the generated tap function's shape: NBASE per-lane base registers 128 B apart, immediates = entry * 16 + chunk plane * 2528, descending
 template <int NT>
-__global__ __launch_bounds__(NT) void bases_kernel(float *out, int trips, int wave_stride)
+__global__ __launch_bounds__(NT) void bases_kernel(float *out, int trips, int wave_stride, int ring = 0, int start = 0)
 {
     extern __shared__ __attribute__((aligned(16))) float lds_generic[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     lds_char *b[11];
 #pragma unroll
     for (int k = 0; k < 11; ++k) {
-        b[k] = (lds_char *)(__attribute__((address_space(3))) float *)lds_generic + wave * wave_stride + lane * 16 + ((k * 8 * 16 + 64 * 16) % (86 * 16));
+        // ring > 0: the lanes' entries wrap as in the product - base k holds entry (start + lane + 8 k) mod ring
+        const int ent = ring > 0 ? (start + lane + 8 * k) % ring : lane + ((k * 8 + 64) % 86);
+        b[k] = (lds_char *)(__attribute__((address_space(3))) float *)lds_generic + wave * wave_stride + ent * 16;
         asm volatile("" : "+v"(b[k]));
     }
     v4f q[5];
@@ -78,9 +80,12 @@ __device__ __forceinline__ void straight_reads(lds_char *const (&b)[11], v4f &ac
     for (int k = 0; k < 4; ++k) q[k] = RD(b[10], (7 - k) * 2528 + 5 * 16 + W * 16);
     SR64(SR_BLOCK(W)) SR2(SR_BLOCK(W)) SR_BLOCK(W)          // 67 blocks of 5 reads
 }
-template <int NT, bool PER_WAVE>
+template <int NT, bool PER_WAVE, int NPAD = 0>
 __global__ __launch_bounds__(NT) void straight_kernel(float *out, int trips, int wave_stride)
 {
+    float pad[NPAD + 1];                                  // (NPAD registers held live through the loop: the product's lanes carry ~220)
+#pragma unroll
+    for (int i = 0; i < NPAD; ++i) pad[i] = (float)(threadIdx.x + i);
     extern __shared__ __attribute__((aligned(16))) float lds_generic[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     lds_char *b[11];
@@ -91,6 +96,8 @@ __global__ __launch_bounds__(NT) void straight_kernel(float *out, int trips, int
     }
     v4f acc = {0, 0, 0, 0};
     for (int t = 0; t < trips; ++t) {
+#pragma unroll
+        for (int i = 0; i < NPAD; ++i) asm volatile("" : "+v"(pad[i]));
         if constexpr (PER_WAVE) {
             switch (wave) {
             case 0: straight_reads<0>(b, acc); break; case 1: straight_reads<1>(b, acc); break; case 2: straight_reads<2>(b, acc); break;
@@ -101,23 +108,26 @@ __global__ __launch_bounds__(NT) void straight_kernel(float *out, int trips, int
             straight_reads<0>(b, acc);
         }
     }
-    if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = acc.x;
+    float ps = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NPAD; ++i) ps += pad[i];
+    if (acc.x + acc.y + acc.z + acc.w + ps == 123.456f) out[0] = acc.x;
 }
-template <int NT, bool PER_WAVE>
+template <int NT, bool PER_WAVE, int NPAD = 0>
 static void run_straight(const char *what, int grid, int lds_bytes, int wave_stride)
 {
     float *out;
     CK(hipMalloc(&out, 4));
-    CK(hipFuncSetAttribute((const void *)straight_kernel<NT, PER_WAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void *)straight_kernel<NT, PER_WAVE, NPAD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int trips = 200;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    straight_kernel<NT, PER_WAVE><<<grid, NT, lds_bytes>>>(out, trips, wave_stride);
+    straight_kernel<NT, PER_WAVE, NPAD><<<grid, NT, lds_bytes>>>(out, trips, wave_stride);
     CK(hipDeviceSynchronize());
     float best = 1e9f;
     for (int r = 0; r < 5; ++r) {
         CK(hipEventRecord(e0));
-        straight_kernel<NT, PER_WAVE><<<grid, NT, lds_bytes>>>(out, trips, wave_stride);
+        straight_kernel<NT, PER_WAVE, NPAD><<<grid, NT, lds_bytes>>>(out, trips, wave_stride);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         best = ms < best ? ms : best;
@@ -128,7 +138,7 @@ static void run_straight(const char *what, int grid, int lds_bytes, int wave_str
 }
 
 template <int NT>
-static void run_bases(const char *what, int grid, int lds_bytes, int wave_stride)
+static void run_bases(const char *what, int grid, int lds_bytes, int wave_stride, int ring = 0, int start = 0)
 {
     float *out;
     CK(hipMalloc(&out, 4));
@@ -136,12 +146,12 @@ static void run_bases(const char *what, int grid, int lds_bytes, int wave_stride
     const int trips = 800;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    bases_kernel<NT><<<grid, NT, lds_bytes>>>(out, trips, wave_stride);
+    bases_kernel<NT><<<grid, NT, lds_bytes>>>(out, trips, wave_stride, ring, start);
     CK(hipDeviceSynchronize());
     float best = 1e9f;
     for (int r = 0; r < 5; ++r) {
         CK(hipEventRecord(e0));
-        bases_kernel<NT><<<grid, NT, lds_bytes>>>(out, trips, wave_stride);
+        bases_kernel<NT><<<grid, NT, lds_bytes>>>(out, trips, wave_stride, ring, start);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         best = ms < best ? ms : best;
@@ -195,7 +205,12 @@ int main()
     run<512>("8 waves, 158 KB, waves 19 KB + 112 B apart", cus, 158 * 1024, 19 * 1024 + 112, 16, 0);
     run_bases<512>("8 waves, 158 KB: eleven per-lane bases, immediates over eight chunk planes 2528 B apart (the tap function's reads)", cus, 158 * 1024, 19 * 1024);
     run_bases<256>("4 waves, the same", cus, 158 * 1024, 38 * 1024);
+    run_bases<512>("8 waves: ... the lanes' entries wrapping in a ring of 144 (a multiple of 16), tile starting at entry 0", cus, 158 * 1024, 19 * 1024, 144, 0);
+    run_bases<512>("8 waves: ... ring of 144, tile starting at entry 48 (some bases straddle the ring's end)", cus, 158 * 1024, 19 * 1024, 144, 48);
+    run_bases<512>("8 waves: ... ring of 144, tile starting at entry 112", cus, 158 * 1024, 19 * 1024, 144, 112);
+    run_bases<512>("8 waves: ... ring of 149 (not a multiple of 16), tile starting at entry 43", cus, 158 * 1024, 19 * 1024, 149, 43);
     run_straight<512, false>("8 waves, 158 KB: the same reads as 336 straight-line instructions per trip, one function for all waves", cus, 158 * 1024, 19 * 1024);
     run_straight<512, true>("8 waves, 158 KB: ... a function of its own per wave (8 x 336 reads of code)", cus, 158 * 1024, 19 * 1024);
+    run_straight<512, true, 190>("8 waves, 158 KB: ... and 190 more registers held live per lane (the product's lanes carry ~220)", cus, 158 * 1024, 19 * 1024);
     return 0;
 }
