@@ -33,6 +33,16 @@ The JSON line also carries
                 per pass, rotating buffers) beside a plain device copy of the same shard;
   end_to_end    the synchronous host API (H2D + kernel + D2H) on pageable and pinned NumPy buffers,
                 N=1 only - PCIe-inclusive, never part of `value`.
+
+What is printed where.  stdout carries ONE short JSON line (a few KB): the contract's keys, `roofline`,
+`cpu_baseline`, and in `config` one short numeric key per claim of README's table (`exact_frac`, `cfg3_frac`,
+`cfg5_frac`, `proj_speedup`, ... - `COMPACT_KEYS` below says what each one is).  Everything else - launch
+descriptions, notes, per-leg records - goes to `bench_detail.json` beside this file (and to `gpurun_out/` when
+that directory exists) and, as one JSON document, to stderr BEFORE the line.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N ranks: the parent -
+which never imports torch or touches a GPU - runs `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+as a CHILD process, relays rank 0's line and exits with the child's code.
 """
 from __future__ import annotations
 
@@ -72,10 +82,92 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=10.0, help='budget of the CPU baseline leg')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-exact', action='store_true', help='skip the extra exact-mode timing')
-    ap.add_argument('--no-secondary', action='store_true', help='skip cfg3/cfg5/cfg4, cfg4_strong and end_to_end')
+    ap.add_argument('--no-secondary', action='store_true', help='skip cfg3/cfg5/cfg4, the next rows and end_to_end')
+    ap.add_argument('--no-strong', action='store_true', help='skip the cfg4 strong-scaling leg')
+    ap.add_argument('--no-power', action='store_true', help='do not sample board power / shader clock')
+    ap.add_argument('--detail', default=None, help='where the detail document goes (default: bench_detail.json beside bench.py)')
     ap.add_argument('--variant', type=int, default=-1, help='kernel variant override (tuning)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo for rehearsals)')
     return ap.parse_args()
+
+
+def launch_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a CHILD process tree and relay rank 0's
+    line.  This process has not imported torch and makes no GPU call, before or after (the ranks are children, not
+    an exec of this process): `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py <the same arguments>`."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), str(pathlib.Path(__file__).resolve()), *argv]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL between processes needs it on this driver
+    print('bench.py: starting', args.gpus, 'ranks:', ' '.join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for text in proc.stdout:                              # rank 0's JSON line goes to stdout as it is; anything else a rank printed, to stderr
+        out = sys.stdout if text.lstrip().startswith('{"metric"') else sys.stderr
+        out.write(text)
+        out.flush()
+    return proc.wait()
+
+
+class PowerSampler:
+    """Board power (W) and shader clock (MHz) of ONE card from its hwmon files, read by a thread every few
+    milliseconds while the main thread launches kernels.  `window(t0, t1)` gives the median of the samples taken between
+    two `time.perf_counter()` stamps.  The card is found by PCI address; a box that does not show the files reports null."""
+
+    def __init__(self, torch, device_index, period_s=0.004):
+        import glob
+        import threading
+        self.samples, self.stop_flag, self.thread, self.files = [], False, None, None
+        self.cap_W = self.card = None
+        self.period = period_s
+        try:
+            p = torch.cuda.get_device_properties(device_index)
+            want = f'{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0'
+            for card in glob.glob('/sys/class/drm/card*/device'):
+                if os.path.realpath(card).endswith(want):
+                    hw = glob.glob(card + '/hwmon/hwmon*')
+                    if hw:
+                        power = next((hw[0] + '/' + f for f in ('power1_input', 'power1_average') if os.path.exists(hw[0] + '/' + f)), None)
+                        clock = hw[0] + '/freq1_input' if os.path.exists(hw[0] + '/freq1_input') else None
+                        cap = hw[0] + '/power1_cap'
+                        self.cap_W = int(open(cap).read()) / 1e6 if os.path.exists(cap) else None
+                        if power:
+                            self.files = (power, clock)
+                            self.card = card.split('/')[-2]
+        except Exception:
+            self.files = None
+        if self.files:
+            self.thread = threading.Thread(target=self._run, daemon=True)
+            self.thread.start()
+
+    def _run(self):
+        power, clock = self.files
+        while not self.stop_flag:
+            try:
+                w = int(open(power).read()) / 1e6
+                mhz = int(open(clock).read()) / 1e6 if clock else None
+                self.samples.append((time.perf_counter(), w, mhz))
+            except Exception:
+                pass
+            time.sleep(self.period)
+
+    def window(self, t0, t1):
+        rows = [(w, m) for t, w, m in self.samples if t0 <= t <= t1]
+        if not rows:
+            return None
+        ws = sorted(w for w, _ in rows)
+        ms = sorted(m for _, m in rows if m is not None)
+        return {'power_W': round(ws[len(ws) // 2], 1), 'sclk_MHz': round(ms[len(ms) // 2]) if ms else None, 'samples': len(rows)}
+
+    def close(self):
+        self.stop_flag = True
+        if self.thread:
+            self.thread.join(timeout=1.0)
 
 
 def cpu_baseline(budget_s: float) -> dict:
@@ -116,6 +208,7 @@ def cpu_baseline(budget_s: float) -> dict:
             'sample': f'{reps} x one cfg2 signal ({x.shape[0]}x{x.shape[1]} f32, {TAPS} taps), '
                       f'NumPy restatement of convolve_velvet_noise, mean {mean * 1e3:.1f} ms, '
                       f'min {best * 1e3:.1f} ms, host cores available {os.cpu_count()}',
+            'sample_short': f'{reps} x one cfg2 signal, NumPy restatement of convolve_velvet_noise, mean {mean * 1e3:.1f} ms, 1 thread',
             'best_value': round(x.size / best / 1e6, 3)}
 
 
@@ -377,7 +470,7 @@ def next_rows(torch, vnd, _native) -> dict:
         rec['what'] = ('vnd_decorrelate_f32_dev (MS encode + RMS normalise) over a resident pool of 10 s stereo signals, one call.  exact: convolution '
                        'with the pointwise steps in its store phase (8 B/sample) + NumPy-order sums (x and y read once: 8) + scale pass (8) = 24 B/sample; '
                        'pools below 256 streams take the block-parallel sums, whose per-block predictions the convolution leaves on its way; '
-                       'fast_fused: per-tile float64 partial sums in the store phase + scale pass = 16 B/sample')
+                       'fast_fused: the store phase leaves per-block sums of squares (a lane\'s 32 squares in float32, the wave and everything after in float64) + scale pass = 16 B/sample')
         out['f1_pool'] = rec
     except Exception as exc:
         out['f1_pool'] = {'error': repr(exc)}
@@ -560,8 +653,114 @@ def cfg4_strong(torch, dist, vnd, _native, ctx, table_image, mode, world, rank, 
             'launch_rank0': table.describe(mine, n, CHANNELS, mode)}
 
 
+def dig(record, *path, default=None):
+    """record[path[0]][path[1]]... or `default` when a leg is missing or failed."""
+    for key in path:
+        if not isinstance(record, dict) or key not in record:
+            return default
+        record = record[key]
+    return record
+
+
+# what the short keys of `config` are (the detail document carries the full records they come from)
+COMPACT_KEYS = {
+    'parity': 'headline: worst of the checked streams of the timed output vs the C oracle, fraction of the output peak',
+    'exact_ms / exact_frac': 'VND_MODE_EXACT (bit-identical, the API default) on the headline pool: kernel ms, fraction of 8 TB/s',
+    'class_exact_frac': 'the class path\'s table (VelvetNoise.convolve) in exact mode on the same pool',
+    'cfgK_ms / cfgK_frac / cfgK_exact_frac': 'BASELINE configs[K-1] on one GPU: kernel ms and fraction of 8 TB/s by 8 B per sample, fast and exact',
+    'cfg3_fp32_frac': 'cfg3 against the FP32 vector peak (157.3 TFLOP/s): its binding limit',
+    'cfg3k1_frac': 'cfg3 with kappa 1 (123 distinct taps per channel)',
+    'f1_P_exact_frac / f1_P_fast_frac': 'the whole decorrelate stage over a pool of P 10 s stereo signals, by its own 24 / 16 B per sample',
+    'f1_c8_frac': 'VelvetNoise.decorrelate of 8-channel 96 kHz signals (LR mode, RMS normaliser), fused fast stage, by 16 B per sample',
+    'm2s_frac / m2s_exact_frac': 'mono in, stereo out, 12 B per frame',
+    'scan_ms / chain_ms': 'f3 grid scan of 400 candidates, f4 resident chain: host to host',
+    'e2e_cfg2_ms / e2e_cfg4_ms': 'host API, pageable buffers, PCIe inclusive: one cfg2 signal, the cfg4 batch',
+    'proj_N1_us / proj_N8_us / proj_copy_N8_us / proj_speedup': 'one-GPU projection of the cfg4 strong cut: a rank\'s pass at N = 1 and N = 8, a copy of the N = 8 shard, N1 / N8',
+    'worst_parity_over_pools': 'fast mode: the worst stream of every timed secondary pool against the exact kernel, of the pool\'s peak',
+    'single_us': 'one cfg2 signal per launch, device resident: launch to synchronise, median (fast mode)',
+    'cfg4_strong': 'this run\'s ranks on the 1024 x 1 s batch: max-over-ranks ms per pass, whole-job Msamples/s',
+}
+
+
+def compact(d: dict) -> dict:
+    """The stdout line: the contract's keys plus one short numeric key per claim, all under `config`, `roofline` and
+    `cpu_baseline` (which the driver's record keeps whole), no string above 120 characters."""
+    r4 = lambda v: None if v is None else round(float(v), 4)
+    cfg, roof, sec, nxt = d['config'], d['roofline'], d.get('secondary') or {}, d.get('next_rows') or {}
+    c = {'workload': f"cfg2: 48 kHz stereo f32, 10 s, 30 taps / 30 ms, seed 1; pool of {cfg['pool_signals_per_gpu']} signals per GPU, one launch per step",
+         'pool': cfg['pool_signals_per_gpu'], 'frames': cfg['frames'], 'channels': cfg['channels'], 'mode': cfg['arithmetic'],
+         'parity': float(f"{cfg['parity_vs_oracle_of_peak']:.3g}"), 'timed_ms': d.get('timed_ms'), 'world_size': cfg['world_size'], 'backend': cfg['backend'],
+         'ranks_seen': cfg['ranks_seen_by_all_reduce'],
+         'exact_ms': dig(d, 'exact_mode', 'kernel_ms'), 'exact_frac': dig(d, 'exact_mode', 'frac_of_8TBs'),
+         'class_exact_frac': dig(d, 'exact_mode', 'class_path_table', 'frac_of_8TBs')}
+    worst = None
+    for name, short in (('cfg3', 'cfg3'), ('cfg3_kappa1', 'cfg3k1'), ('cfg5', 'cfg5'), ('cfg4', 'cfg4')):
+        rec = sec.get(name) or {}
+        if 'error' in rec:
+            c[short + '_error'] = rec['error'][:100]
+            continue
+        if not rec:
+            continue
+        if short != 'cfg3k1':
+            c[short + '_ms'] = rec.get('kernel_ms')
+        c[short + '_frac'] = rec.get('frac_of_8TBs')
+        if short == 'cfg3':
+            c['cfg3_fp32_frac'] = rec.get('frac_of_fp32_vector_peak')
+        if 'exact_mode' in rec:
+            c[short + '_exact_frac'] = dig(rec, 'exact_mode', 'frac_of_8TBs')
+        if rec.get('parity_max_over_pool') is not None:
+            worst = max(worst or 0.0, rec['parity_max_over_pool'])
+    if worst is not None:
+        c['worst_parity_over_pools'] = float(f'{worst:.3g}')
+    for pool in (256, 128):
+        for label, short in (('exact', 'exact'), ('fast_fused', 'fast')):
+            v = dig(nxt, 'f1_pool', f'pool{pool}_{label}', 'frac_of_8TBs')
+            if v is not None:
+                c[f'f1_{pool}_{short}_frac'] = v
+    for key, path in (('f1_c8_frac', ('f1_c8', 'fast_fused', 'frac_of_8TBs')), ('f1_c8_exact_frac', ('f1_c8', 'exact', 'frac_of_8TBs')),
+                      ('m2s_frac', ('mono_to_stereo_fast', 'frac_of_8TBs')), ('m2s_exact_frac', ('mono_to_stereo_fast', 'exact_mode', 'frac_of_8TBs')),
+                      ('scan_ms', ('f3_grid_scan', 'ms_host_to_host')), ('chain_ms', ('f4_resident_chain', 'ms_host_to_host'))):
+        v = dig(nxt, *path)
+        if v is not None:
+            c[key] = v
+    for key, path in (('e2e_cfg2_ms', ('cfg2_one_signal', 'pageable', 'ms_per_call')), ('e2e_cfg4_ms', ('cfg4_batch', 'pageable', 'ms_per_call'))):
+        v = dig(d, 'end_to_end', *path)
+        if v is not None:
+            c[key] = v
+    proj = dig(d, 'cfg4_strong', 'projection')
+    if proj:
+        c.update({'proj_N1_us': dig(proj, 'N=1', 'us_per_pass'), 'proj_N8_us': dig(proj, 'N=8', 'us_per_pass'),
+                  'proj_copy_N8_us': dig(proj, 'N=8', 'device_copy_us'), 'proj_speedup': dig(proj, 'N=8', 'speedup_vs_N1')})
+    v = dig(cfg, 'single_launch_us', 'fast', 'launch_to_sync_us_median')
+    if v is not None:
+        c['single_us'] = v
+    if d.get('cfg4_strong'):
+        st = d['cfg4_strong']
+        c['cfg4_strong'] = {k: st.get(k) for k in ('ranks', 'streams_on_rank0', 'ms_per_pass_max_over_ranks', 'Msamples_s')}
+    c['detail'] = 'bench_detail.json; stderr'
+    line = {k: d[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                              'dtype', 'data')}
+    line['config'] = c
+    pw = roof.get('power') or {}
+    line['roofline'] = {'bound': roof['bound'], 'achieved': roof['achieved'], 'peak': roof['peak'], 'unit': roof['unit'], 'frac': roof['frac'],
+                        'traffic': roof['traffic'], 'kernel_ms': roof['kernel_ms'], 'copy_GBs': roof['streaming_copy_GBs'],
+                        'frac_of_copy': roof['frac_of_streaming_copy'],
+                        'power_W': dig(pw, 'convolution', 'power_W'), 'sclk_MHz': dig(pw, 'convolution', 'sclk_MHz'),
+                        'sclk_timed_MHz': dig(pw, 'convolution_timed_steps', 'sclk_MHz'),
+                        'copy_power_W': dig(pw, 'copy_kernel', 'power_W'), 'copy_sclk_MHz': dig(pw, 'copy_kernel', 'sclk_MHz'), 'cap_W': pw.get('cap_W')}
+    if d.get('cpu_baseline'):
+        cb = d['cpu_baseline']
+        cr = cb.get('c_restatement_Msamples_s') or {}
+        line['cpu_baseline'] = {'value': cb['value'], 'unit': cb['unit'], 'cores': cb['cores'], 'kind': cb['kind'], 'sample': cb['sample_short'],
+                                'c_port_1_thread': cr.get('threads_1'), 'c_port_all_threads': next((v for k, v in cr.items() if k != 'threads_1'), None),
+                                'host_cores': os.cpu_count()}
+    return line
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))          # before torch is imported: this process never touches a GPU
     import torch
     import torch.distributed as dist
 
@@ -569,9 +768,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch multi-GPU runs with: python -m torch.distributed.run '
-                             '--nproc-per-node N bench.py --gpus N ...')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: start the ranks with plain `python bench.py --gpus N` '
+                         '(it launches them itself) or with torchrun --nproc-per-node N')
     if 'VND_BENCH_FORCE_DEVICE' in os.environ:                 # rehearsing N ranks on a 1-GPU box
         local_rank = int(os.environ['VND_BENCH_FORCE_DEVICE'])
     os.environ['VND_DEVICE'] = str(local_rank)
@@ -582,6 +780,14 @@ def main():
             dist.init_process_group('nccl', device_id=device)  # nccl == RCCL on ROCm
         else:
             dist.init_process_group(args.backend)
+    # what the process group itself says: a sum of ones over the ranks (RCCL when the backend is nccl)
+    ranks_seen = 1
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.int64, device=device if args.backend == 'nccl' else 'cpu')
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        assert ranks_seen == dist.get_world_size() == world, (ranks_seen, dist.get_world_size(), world)
+    power = PowerSampler(torch, local_rank) if (rank == 0 and not args.no_power) else None
 
     import vndecorrelate_amd.decorrelation as vnd
     from vndecorrelate_amd import _native
@@ -642,8 +848,11 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        return time.perf_counter() - t0, ev0.elapsed_time(ev1) / steps
+        t1 = time.perf_counter()
+        stamps.append((t_w, t0, t1))
+        return t1 - t0, ev0.elapsed_time(ev1) / steps
 
+    stamps = []
     elapsed, kernel_ms = timed(mode, args.steps, args.warmup)
     timed_ms = elapsed * 1e3
     checked = sorted({0, args.pool // 2, args.pool - 1})      # first, middle, last stream (the last: past 4 GiB of offsets)
@@ -714,6 +923,7 @@ def main():
     # the device's own streaming ceiling on the same pool: a plain device copy (4 B read + 4 B
     # written per sample, the kernel's algorithmic traffic), the honest companion of the 8 TB/s figure
     copy_gbs = stream_copy_gbs = None
+    power_info = None
     if rank == 0:
         for _ in range(3):
             y.copy_(x)
@@ -730,6 +940,28 @@ def main():
         ctx.time_copy(x.data_ptr(), y.data_ptr(), x.numel(), 3, stream_ptr)
         stream_copy_ms = ctx.time_copy(x.data_ptr(), y.data_ptr(), x.numel(), 20, stream_ptr)
         stream_copy_gbs = ALGO_BYTES_PER_SAMPLE * samples_per_step / (stream_copy_ms * 1e-3) / 1e9
+        # board power and shader clock (the convolution sits on the board's power cap, the copy does not).  The hwmon power
+        # figure is a running average that takes a few hundred ms to settle, so beside the readings taken DURING the timed steps each
+        # kernel gets 1 s of back-to-back launches after them and reports the median of that run's second half
+        if power is not None and power.files:
+            t_w, t0, t1 = stamps[0]
+
+            def sustained(fn, seconds=1.0):
+                s0, k = time.perf_counter(), 0
+                while time.perf_counter() - s0 < seconds:
+                    fn(); k += 1
+                    if k % 8 == 0:
+                        torch.cuda.synchronize()
+                torch.cuda.synchronize()
+                s1 = time.perf_counter()
+                return power.window(s0 + (s1 - s0) / 2, s1)
+            power_info = {'convolution_timed_steps': power.window(t0, t1),
+                          'convolution': sustained(lambda: run(mode)),
+                          'copy_kernel': sustained(lambda: ctx.time_copy(x.data_ptr(), y.data_ptr(), x.numel(), 4, stream_ptr)),
+                          'cap_W': power.cap_W, 'card': power.card,
+                          'how': f'hwmon power1_input / freq1_input of the card, a reading every {power.period * 1e3:.0f} ms from a thread; medians over the second '
+                                 'half of 1 s of back-to-back launches of each kernel after the timed region (the power figure is a slow average), and over '
+                                 'the timed steps themselves'}
 
     launch_text = table.describe(args.pool, n, CHANNELS, mode)
     # what a one-file caller sees (the reference's own use, tests/test_example.py:19-49): ONE device-resident cfg2 signal per launch -
@@ -758,7 +990,7 @@ def main():
     torch.cuda.empty_cache()
 
     strong = None
-    if not args.no_secondary:
+    if not args.no_strong:
         strong = cfg4_strong(torch, dist, vnd, _native, ctx, image, mode, world, rank, device, args.backend,
                              taps=(arrays.tap_offsets, arrays.tap_index, arrays.tap_weight) if rank == 0 else None)
 
@@ -784,7 +1016,7 @@ def main():
                 traffic_source = ('profiles/hbm_traffic.json was taken on another launch (' + str(rec.get('launch'))[:120] + ' ...): no traffic figure '
                                   'for this one - re-run tools/profile.sh')
                 print('bench.py: profiles/hbm_traffic.json does not describe this launch; roofline.traffic is null', file=sys.stderr)
-        line = {
+        detail = {
             'metric': 'Msamples/sec decorrelated (stereo, 30 taps) + achieved HBM GB/s vs roofline',
             'value': round(value, 1), 'unit': 'Msamples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'warmup_actual': warmups[0], 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
@@ -798,6 +1030,7 @@ def main():
                        'arithmetic': args.mode, 'parity_vs_oracle_of_peak': (0.0 if mode == vnd.MODE_EXACT else parity),
                        'parity_streams_checked': checked,
                        'launch': launch_text, 'exact_mode': 'top-level key `exact_mode`', 'single_launch_us': single_launch,
+                       'world_size': world, 'backend': (args.backend if world > 1 else None), 'ranks_seen_by_all_reduce': ranks_seen,
                        'sharding': 'independent streams per rank; RCCL broadcast of the tap table only'},
             # VND_MODE_EXACT - the drop-in API's DEFAULT arithmetic, bit-identical to the reference - on the same pool, function path
             # (convolve_velvet_noise) and class path (VelvetNoise.convolve): not part of `value`
@@ -815,20 +1048,37 @@ def main():
 
                          'limit': 'board power cap (1400 W; the shader clock falls to ~1.9 GHz under this kernel: '
                                   'profiles/r03_cfg2_power.txt), DESIGN.md 3.5',
+                         'power': power_info,
                          'algorithmic_bytes_per_launch': ALGO_BYTES_PER_SAMPLE * samples_per_step},
         }
+        if power is not None:
+            power.close()
         if strong is not None:
-            line['cfg4_strong'] = strong
+            detail['cfg4_strong'] = strong
         if world == 1 and not args.no_secondary:
-            line['secondary'] = secondary_configs(torch, vnd, _native, ctx, mode)
+            detail['secondary'] = secondary_configs(torch, vnd, _native, ctx, mode)
             try:
-                line['end_to_end'] = end_to_end(torch, vnd, mode)
+                detail['end_to_end'] = end_to_end(torch, vnd, mode)
             except Exception as exc:                    # as above: never at the headline's expense
-                line['end_to_end'] = {'error': repr(exc)}
-            line['next_rows'] = next_rows(torch, vnd, _native)
+                detail['end_to_end'] = {'error': repr(exc)}
+            detail['next_rows'] = next_rows(torch, vnd, _native)
         if world == 1 and not args.no_cpu:
-            line['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
-        print(json.dumps(line), flush=True)
+            detail['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
+        # the long record: a side file (and gpurun_out/, which travels back from a GPU box) and stderr; the short line: stdout, last
+        text = json.dumps(detail, indent=1)
+        targets = [pathlib.Path(args.detail)] if args.detail else [REPO / 'bench_detail.json']
+        if (REPO / 'gpurun_out').is_dir():
+            targets.append(REPO / 'gpurun_out' / 'bench_detail.json')
+        for target in targets:
+            try:
+                target.write_text(text)
+            except OSError as exc:
+                print(f'bench.py: could not write {target}: {exc}', file=sys.stderr)
+        print(json.dumps(detail), file=sys.stderr, flush=True)
+        line = compact(detail)
+        text = json.dumps(line, separators=(',', ':'))
+        assert len(text) < 4096, f'the bench line grew to {len(text)} bytes: the driver keeps a tail'
+        print(text, flush=True)
     if world > 1:
         dist.destroy_process_group()
 

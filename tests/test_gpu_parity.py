@@ -82,7 +82,12 @@ def test_promoting_path_more_types(vnd, golden):
         want = O.convolve_velvet_noise(x, fir)
         got = vnd.convolve_velvet_noise(x, fir)
         assert got.dtype == np.float32 and np.array_equal(got, want), (x.dtype, fir.dtype)
+        # outside exact mode the operands are cast to float32 FIRST (the float32 kernels): the north star's 1e-6 of peak is asserted
+        # against the function-path oracle on those float32 operands; against the promoting oracle the cast's own rounding (2^-24
+        # relative per operand, ~30 terms) comes on top - a separate, explained bar of 2e-6
         fast = vnd.convolve_velvet_noise(x, fir, mode=vnd.MODE_FAST)
+        want32 = O.convolve_velvet_noise(x.astype(np.float32), fir.astype(np.float32))
+        assert np.max(np.abs(fast.astype(np.float64) - want32)) <= 1e-6 * np.max(np.abs(want32)), (x.dtype, fir.dtype)
         assert np.max(np.abs(fast.astype(np.float64) - want)) <= 2e-6 * np.max(np.abs(want)), (x.dtype, fir.dtype)
     xb = rng.uniform(-1, 1, (3, 4001, 2))
     yb = vnd.convolve_velvet_noise_batched(xb, fir32)

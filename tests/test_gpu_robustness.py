@@ -131,3 +131,54 @@ def test_huge_tap_index_takes_the_gather_kernel(vnd):
     want[:, 1] = -x[:, 1]
     assert np.array_equal(got, want)
     table.close()
+
+
+def test_first_paced_launch_of_a_fresh_context_inside_a_graph_capture(vnd):
+    """A `*_dev` call only enqueues on the caller's stream (include/vnd_amd.h): the FIRST paced launch of a fresh context -
+    cfg3's bench pool, two workgroups per CU pacing each other through the context's tile counters - must be legal inside a
+    stream capture (the counters are allocated and zeroed by vnd_ctx_create, not by the launch, and never through the null
+    stream), and the graph's replay must write what a plain launch writes."""
+    import torch
+    from oracle import c_oracle
+    from vndecorrelate_amd import _native
+    from vndecorrelate_amd.taps import function_path_arrays
+    arr = function_path_arrays(vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=128, num_outs=2, sample_rate_hz=48000,
+                                                         log_distribution_strength=0.0, seed=1))
+    batch, n = 24, 2880000
+    ctx = _native.Context(0)
+    table = _native.TapTable.create(ctx, arr.tap_offsets, arr.tap_index, arr.tap_weight)
+    try:
+        table.prepare(batch, n, 2, vnd.MODE_FAST)                  # the hipRTC build is host work: before the capture
+        assert table.describe(batch, n, 2, vnd.MODE_FAST).startswith('conv_spec_window')
+        x = torch.empty((batch, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1)
+        y = torch.zeros_like(x)
+        side = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            table.convolve_device(x.data_ptr(), y.data_ptr(), batch, n, 2, vnd.MODE_FAST, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        y.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        plain = torch.empty_like(y)
+        table.convolve_device(x.data_ptr(), plain.data_ptr(), batch, n, 2, vnd.MODE_FAST, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(y, plain)
+        want = c_oracle.convolve(x[batch - 1].cpu().numpy(), arr.tap_offsets, arr.tap_index, arr.tap_weight, threads=8)
+        assert np.max(np.abs(y[batch - 1].cpu().numpy() - want)) <= 1e-6 * np.max(np.abs(want))
+    finally:
+        table.close()
+        ctx.close()
+
+
+def test_an_unregistered_tuning_name_is_an_error_code_not_an_abort(vnd):
+    """Under VND_TUNING=1 (the test tier sets it) every tuning variable the library reads must be in its registry; a name
+    that is not used to abort() the host process in debug builds - it is VND_ERR_INVALID now, and after this module's
+    launches through every kernel family no such name has been recorded."""
+    from vndecorrelate_amd import _native
+    from vndecorrelate_amd.taps import function_path_arrays
+    arr = function_path_arrays(vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1))
+    table = _native.TapTable.create(_native.default_context(), arr.tap_offsets, arr.tap_index, arr.tap_weight)
+    text = table.describe(64, 480000, 2, vnd.MODE_FAST)                 # plans a launch: reads the geometry variables
+    assert text.startswith('conv_spec'), text
+    table.close()

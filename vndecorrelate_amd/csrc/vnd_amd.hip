@@ -59,6 +59,18 @@ vnd_status vnd_ctx_create(int32_t device, vnd_ctx **out)
         delete c;
         return fail(VND_ERR_HIP, "hipStreamCreate failed");
     }
+    // the window kernel's pacing slots (16 KB): here, so that no launch allocates, touches the null stream or breaks a capture.
+    // Zeroed on the context's own stream and waited for; a failure only switches pacing off.
+    if (hipMalloc((void **)&c->pace, 2048 * 2 * sizeof(unsigned)) == hipSuccess) {
+        if (hipMemsetAsync(c->pace, 0, 2048 * 2 * sizeof(unsigned), c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) {
+            (void)hipFree(c->pace);
+            c->pace = nullptr;
+        }
+    } else {
+        c->pace = nullptr;
+    }
+    (void)hipGetLastError();
     *out = c;
     return VND_OK;
 }
@@ -314,6 +326,7 @@ static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64
     // the pointers only decide alignment: describe the launch of 256-byte-aligned buffers (hipMalloc's)
     for (int attempt = 0; attempt < 8; ++attempt) {
         const SpecPlan sp = make_spec_plan(ctx, t, nullptr, nullptr, batch, n, C, Cx, mode, nullptr);
+        if (vnd_status ts = tuning_status(); ts != VND_OK) return ts;
         if (!sp.use) break;
         DeviceScope on(ctx->device);
         SpecModule *m = spec_module(ctx, t, sp.cfg, !sp.eager);
@@ -379,6 +392,7 @@ vnd_status vnd_prepare_launch(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, in
     DeviceScope on(ctx->device);
     for (int attempt = 0; attempt < 8; ++attempt) {               // (a window geometry that does not build is skipped: plan again)
         const SpecPlan sp = make_spec_plan(ctx, t, nullptr, nullptr, batch, n, t->C, in_channels, mode, nullptr);
+        if (vnd_status ts = tuning_status(); ts != VND_OK) return ts;
         if (!sp.use) return VND_OK;
         SpecModule *m = spec_module(ctx, t, sp.cfg, false);
         if (m && !m->failed) return VND_OK;

@@ -150,12 +150,14 @@ static vnd_status host_time_pipeline(vnd_ctx *ctx, const vnd_taps *t, const floa
 static bool host_mapped(const void *p, size_t bytes, void **dev)
 {
     if (!p || bytes == 0) return false;
-    // every probe must be page-locked host memory whose device address continues the first one's: a range whose two ENDS are
-    // registered but whose middle is not (two hipHostRegister calls with a gap) must not reach a kernel as one device pointer.
-    // Probes every 2 MiB (at most 64 of them, evenly spread) and at the last byte.
-    const size_t step = std::max<size_t>((size_t)2 << 20, (bytes + 63) / 64);
+    // The range is walked REGISTRATION BY REGISTRATION: every probe must be page-locked host memory whose device address continues
+    // the first one's, and the next probe is the first byte past the extent (hipMemGetAddressRange) of the registration the last
+    // one fell in - so a hole of any size between two hipHostRegister ranges is stepped ON, not over, and such a range never
+    // reaches a kernel as one device pointer.  Where the runtime does not report an extent for this kind of memory the walk
+    // falls back to fixed 2 MiB steps (plus the last byte) and declines ranges that would need more than 4096 of them.
     void *base = nullptr;
-    for (size_t off = 0;; off = std::min(off + step, bytes - 1)) {
+    size_t probes = 0;
+    for (size_t off = 0;;) {
         hipPointerAttribute_t at{};
         const bool ok = hipPointerGetAttributes(&at, (const char *)p + off) == hipSuccess;
         (void)hipGetLastError();                                  // (an ordinary pageable pointer reports an error: not ours)
@@ -163,6 +165,18 @@ static bool host_mapped(const void *p, size_t bytes, void **dev)
         if (off == 0) base = at.devicePointer;
         else if ((const char *)at.devicePointer - (const char *)base != (ptrdiff_t)off) return false;
         if (off == bytes - 1) break;
+        size_t next = off + ((size_t)2 << 20);
+        hipDeviceptr_t ext_base = nullptr;
+        size_t ext_bytes = 0;
+        if (hipMemGetAddressRange(&ext_base, &ext_bytes, (hipDeviceptr_t)at.devicePointer) == hipSuccess && ext_bytes > 0 &&
+            (const char *)ext_base <= (const char *)at.devicePointer &&
+            (const char *)at.devicePointer < (const char *)ext_base + ext_bytes) {
+            next = off + (size_t)((const char *)ext_base + ext_bytes - (const char *)at.devicePointer);   // first byte past this registration
+        } else {
+            (void)hipGetLastError();
+            if (++probes > 4096) return false;
+        }
+        off = std::min(next, bytes - 1);
     }
     *dev = base;
     return true;

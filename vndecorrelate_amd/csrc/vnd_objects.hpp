@@ -75,8 +75,8 @@ struct vnd_ctx {
     // (hipFuncSetAttribute applies to the current device's copy of the function)
     std::mutex raised_mutex;
     std::map<const void *, size_t> raised;      // kernel -> dynamic LDS bytes it has been allowed
-    // pacing slots of the window kernel (vnd_win_kernel.inc, VWArgs::pace): [2048 CU indices][2] tile counters, made on first use
-    std::mutex pace_mutex;
+    // pacing slots of the window kernel (vnd_win_kernel.inc, VWArgs::pace): [2048 CU indices][2] tile counters, allocated and zeroed
+    // by vnd_ctx_create - never in a launch path (a *_dev call may sit inside a stream capture); read-only here afterwards
     unsigned *pace = nullptr;
 };
 

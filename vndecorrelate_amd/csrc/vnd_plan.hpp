@@ -256,6 +256,15 @@ static Plan make_plan(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int6
     return p;
 }
 
+// VND_TUNING=1 sessions: a tuning variable the library read that is not in kTuningNames (vnd_spec.hpp) is a bug in the library;
+// the entry point that planned the launch reports it as VND_ERR_INVALID - it never ends the host process
+static vnd_status tuning_status()
+{
+    const char *name = spec_unregistered_name().load();
+    if (name == nullptr) return VND_OK;
+    return fail(VND_ERR_INVALID, "tuning variable %s is read by the library but not registered in kTuningNames", name);
+}
+
 static vnd_status check_shape(const vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64_t n,
                               int32_t C, int32_t mode, int32_t Cx = 0)
 {
@@ -520,6 +529,20 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
 // kernel takes over (the reason stays readable through vnd_describe_launch)
 // cache_only: a launch too small to be worth a 1.5-5 s build takes the per-table kernel only when its code object is
 // already there - in this table's map or in the disk cache (looked up once) - and the generic kernel otherwise
+// spec_compile builds strings and vectors: an exception in it (std::bad_alloc) must neither cross the C ABI nor leave the entry
+// `building` for ever (every later launch of that geometry would wait on spec_built) - the entry is published as failed instead
+static void spec_compile_guarded(const SpecTable &table, const SpecConfig &cfg, int device, int lds_limit, SpecModule *m, bool cache_only)
+{
+    try {
+        spec_compile(table, cfg, device, lds_limit, m, cache_only);
+    } catch (const std::exception &e) {
+        m->failed = true; m->pending = false;
+        try { m->log = std::string("exception while building: ") + e.what(); } catch (...) {}
+    } catch (...) {
+        m->failed = true; m->pending = false;
+    }
+}
+
 static SpecModule *spec_module(vnd_ctx *ctx, const vnd_taps *t_, const SpecConfig &cfg, bool cache_only = false)
 {
     // The table's mutex guards the MAP, not the 1.5-5 s of hipRTC: the thread that finds no entry inserts one marked `building`,
@@ -536,7 +559,7 @@ static SpecModule *spec_module(vnd_ctx *ctx, const vnd_taps *t_, const SpecConfi
             SpecModule *m = fresh.get();
             t->spec_modules.emplace(cfg, std::move(fresh));
             g.unlock();
-            spec_compile(t->spec_table, cfg, ctx->device, ctx->lds_limit, m, cache_only);
+            spec_compile_guarded(t->spec_table, cfg, ctx->device, ctx->lds_limit, m, cache_only);
             g.lock();
             m->building = false;
             t->spec_built.notify_all();
@@ -551,7 +574,7 @@ static SpecModule *spec_module(vnd_ctx *ctx, const vnd_taps *t_, const SpecConfi
         if (m->pending && !cache_only) {                                  // looked for in the disk cache only, before: build it now
             m->building = true;
             g.unlock();
-            spec_compile(t->spec_table, cfg, ctx->device, ctx->lds_limit, m, false);
+            spec_compile_guarded(t->spec_table, cfg, ctx->device, ctx->lds_limit, m, false);
             g.lock();
             m->building = false;
             t->spec_built.notify_all();
@@ -579,12 +602,7 @@ static vnd_status launch_spec(vnd_ctx *ctx, const vnd_taps *t, const SpecPlan &p
         // (long launches only: with a few tiles per workgroup the bias it corrects has no time to build up, and handing the later
         //  workgroup the priority costs - cfg4's N = 4 shard, 3 tiles each: 42.8 -> 48.8 us; cfg3's 17 tiles: +4.7 %)
         (int64_t)p.units * p.tiles_per_span >= (int64_t)p.nblocks * spec_env("VND_WIN_PACE_MIN_TILES", 16)) {
-        std::lock_guard<std::mutex> g(ctx->pace_mutex);
-        if (!ctx->pace && hipMalloc((void **)&ctx->pace, 2048 * 2 * sizeof(unsigned)) == hipSuccess) {
-            if (hipMemset(ctx->pace, 0, 2048 * 2 * sizeof(unsigned)) != hipSuccess) { (void)hipFree(ctx->pace); ctx->pace = nullptr; }
-        }
-        (void)hipGetLastError();
-        a.pace = ctx->pace;
+        a.pace = ctx->pace;                                  // made and zeroed by vnd_ctx_create: a *_dev launch only enqueues (null: no pacing)
     }
     a.stagger_ticks = p.stagger_ticks; a.chunk_prio = 1;
     if (epi != nullptr && p.cfg.epi) {
@@ -618,6 +636,7 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
     if (Cx == 0) Cx = C;
     for (int attempt = 0; attempt < 8; ++attempt) {
         const SpecPlan sp = make_spec_plan(ctx, t, x, y, batch, n, C, Cx, mode, epi);
+        if (vnd_status ts = tuning_status(); ts != VND_OK) return ts;
         if (!sp.use) break;
         bool launched = false, built = true;
         vnd_status st = launch_spec(ctx, t, sp, x, y, n, stream, &launched, epi, &built);

@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstring>
 #include <cstdio>
@@ -103,14 +104,20 @@ inline bool spec_tuning()
     return on;
 }
 
+// a name the library asked for that is not in the list: a library bug, reported - never by ending the host process - as
+// VND_ERR_INVALID by the entry point that planned the launch (tuning_status() in vnd_plan.hpp), with the name in vnd_last_error
+inline std::atomic<const char *> &spec_unregistered_name()
+{
+    static std::atomic<const char *> name{nullptr};
+    return name;
+}
+
 inline int spec_env(const char *name, int fallback)
 {
     if (!spec_tuning()) return fallback;
-#ifndef NDEBUG
     bool known = false;
     for (const char *k : kTuningNames) known |= strcmp(k, name) == 0;
-    if (!known) { fprintf(stderr, "vnd: tuning variable %s is not in kTuningNames\n", name); abort(); }
-#endif
+    if (!known) { spec_unregistered_name().store(name); return fallback; }
     const char *e = getenv(name);
     return (e && *e) ? atoi(e) : fallback;
 }

@@ -375,7 +375,8 @@ inline void win_traffic_exact(const SpecTable &t, int M, size_t *lds_bytes, size
 // A mono input fanned out (VW_BC, plain form): both output channels read the SAME plane, and the two channels of a velvet table
 // place their taps almost alike (the same segment grid, jittered) - so ONE read stream over the union of both channels' windows feeds
 // both channels' FMAs: cfg2's table 178 reads per tile and lane instead of 157 + 160, 1.48 B of LDS per FMA instead of 2.64.  Each
-// channel keeps its own E / P chains in ascending offset order: the results are those of a pass per channel, bit for bit.
+// channel keeps its own E / P chains in the read order of win_taps_function - FAR end of the window first by default (small terms first,
+// VND_WIN_FAR_FIRST), ascending offsets when that is switched off: the results are those of a pass per channel, bit for bit.
 inline std::string win_taps_function_merged(const SpecTable &t, const WinGeom &g, int la, int pg = 0)
 {
     const int M = g.M;
