@@ -257,3 +257,68 @@ def test_bench_runs_with_two_ranks(tmp_path, how):
     assert 'cpu_baseline' not in line and 'cfg3_frac' not in config   # N = 1 only
     full = json.loads(detail.read_text())
     assert full['cfg4_strong']['parity_vs_oracle_of_peak'] <= 1e-6 and 'secondary' not in full
+
+
+def test_one_process_device_lists_through_the_drop_in_calls():
+    """`convolve_velvet_noise_batched(x, fir, devices=...)` and `VelvetNoise.decorrelate_batched(x, devices=...)`: the batch cut
+    over the listed devices from THIS process (multi.DevicePool - one context and one host thread per device, blocks written
+    straight into one result).  With one visible device the list is [0] and the result must be the unsharded call's, bit for
+    bit, in both modes; with more, 'all' spreads a ragged batch over every device (table replicated over a single-process RCCL
+    communicator) and must still equal it."""
+    import vndecorrelate_amd.decorrelation as vnd
+    from vndecorrelate_amd import _native, multi
+    n_dev = _native.device_count()
+    fir = vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1)
+    x = np.random.default_rng(41).uniform(-1, 1, (11, 30000, 2)).astype(np.float32)
+    try:
+        for mode in (vnd.MODE_EXACT, vnd.MODE_FAST):
+            want = vnd.convolve_velvet_noise_batched(x, fir, mode=mode)
+            for devices in ([0], 'all'):
+                got = vnd.convolve_velvet_noise_batched(x, fir, mode=mode, devices=devices)
+                assert got.dtype == np.float32 and np.array_equal(got, want), (mode, devices)
+        pool = multi.pool_for('all')
+        assert [c for _, c in pool.last_blocks] == [11 // n_dev + (1 if d < 11 % n_dev else 0) for d in range(n_dev)]
+        assert pool.last_transport == ('rccl' if n_dev > 1 else 'upload (one device)')
+        vn = vnd.VelvetNoise(sample_rate_hz=48000, seed=1)
+        want = vn.decorrelate_batched(x)
+        assert np.array_equal(want[3], vn.decorrelate(x[3]))
+        for devices in ([0], 'all'):
+            assert np.array_equal(vn.decorrelate_batched(x, devices=devices), want), devices
+        mono = np.ascontiguousarray(x[:, :, :1])
+        assert np.array_equal(vn.decorrelate_batched(mono, devices='all'), vn.decorrelate_batched(mono))
+        with pytest.raises(ValueError):
+            vnd.convolve_velvet_noise_batched(x, fir, devices=[n_dev])
+        if n_dev > 1:                                               # the plain-upload transport gives the same tables
+            up = multi.DevicePool(list(range(n_dev)), table_transport='upload')
+            out = np.empty_like(x)
+            from vndecorrelate_amd.taps import function_path_arrays
+            up.map_streams(function_path_arrays(fir), x, out, 'convolve', vnd.MODE_EXACT)
+            assert np.array_equal(out, vnd.convolve_velvet_noise_batched(x, fir)) and up.last_transport == 'upload'
+            up.close()
+    finally:
+        multi.close_pools()
+
+
+def test_single_process_rccl_communicator_carries_the_table():
+    """The pool's table transport with more than one device - ncclCommInitAll in this process, one vnd_taps_broadcast_rccl
+    per device - on as many devices as the box has (a one-device communicator on a one-GPU box: the root keeps its table,
+    every RCCL call on the path still runs)."""
+    import vndecorrelate_amd.decorrelation as vnd
+    from vndecorrelate_amd import _native, multi
+    from vndecorrelate_amd.taps import function_path_arrays
+    from concurrent.futures import ThreadPoolExecutor
+    n_dev = _native.device_count()
+    arr = function_path_arrays(vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1))
+    try:
+        rccl = multi._Rccl()
+    except RuntimeError:
+        pytest.skip('librccl.so not found')
+    comms = rccl.init_all(list(range(n_dev)))
+    try:
+        ctxs = [_native.context_for(d) for d in range(n_dev)]
+        first = _native.TapTable.create(ctxs[0], arr.tap_offsets, arr.tap_index, arr.tap_weight)
+        with ThreadPoolExecutor(n_dev) as ex:
+            tables = list(ex.map(lambda r: _native.TapTable.broadcast_rccl(ctxs[r], first if r == 0 else None, 0, r, comms[r]), range(n_dev)))
+        assert tables[0] is first and all(t.to_bytes() == arr.to_bytes() for t in tables)
+    finally:
+        rccl.destroy(comms)

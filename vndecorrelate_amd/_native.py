@@ -422,7 +422,7 @@ class TapTable:
     # A signal with fewer channels than the table is fanned out: output channel c reads
     # input channel c % in_channels (vnd_*_fanout_*; mono -> stereo, or one signal through
     # a bank of filters).  The result always has the table's channel count.
-    def _host_shapes(self, x: np.ndarray, what: str):
+    def _host_shapes(self, x: np.ndarray, what: str, out: Optional[np.ndarray] = None):
         if x.dtype != np.float32 or not x.flags.c_contiguous:
             raise ValueError(f'{what} wants a C-contiguous float32 array')
         if x.ndim == 2:
@@ -431,12 +431,18 @@ class TapTable:
             batch, n, c = x.shape
         else:
             raise ValueError(f'expected (n, C) or (batch, n, C), got {x.shape}')
-        y = pinned_pool.empty(x.shape[:-1] + (self.num_channels,), np.float32)
+        shape = x.shape[:-1] + (self.num_channels,)
+        if out is None:
+            y = pinned_pool.empty(shape, np.float32)
+        else:                                   # the caller's block of a larger result (multi.DevicePool): written in place
+            if out.dtype != np.float32 or not out.flags.c_contiguous or out.shape != shape:
+                raise ValueError(f'{what}: out must be a C-contiguous float32 array of shape {shape}')
+            y = out
         return batch, n, c, y
 
-    def convolve_host(self, x: np.ndarray, mode: int = MODE_EXACT) -> np.ndarray:
-        """x: C-contiguous float32 ``(n, C)`` or ``(batch, n, C)``; returns a new array."""
-        batch, n, c, y = self._host_shapes(x, 'convolve_host')
+    def convolve_host(self, x: np.ndarray, mode: int = MODE_EXACT, *, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """x: C-contiguous float32 ``(n, C)`` or ``(batch, n, C)``; returns a new array (or ``out``, filled)."""
+        batch, n, c, y = self._host_shapes(x, 'convolve_host', out)
         if c == self.num_channels:
             _check(self._lib.vnd_convolve_f32_host(self.ctx.handle, self.handle,
                                                    _ptr(x, ctypes.c_float), _ptr(y, ctypes.c_float),
@@ -448,15 +454,14 @@ class TapTable:
         return y
 
     def decorrelate_host(self, x: np.ndarray, mode: int = MODE_EXACT, *, ms_encode: bool, width,
-                         normalize, eps: float = 1e-10) -> np.ndarray:
+                         normalize, eps: float = 1e-10, out: Optional[np.ndarray] = None) -> np.ndarray:
         """Convolution + decorrelate epilogue on the device; x as in ``convolve_host``.
         ``normalize``: False/True or one of the ``NORMALIZE_*`` values."""
-        batch, n, c, y = self._host_shapes(x, 'decorrelate_host')
+        batch, n, c, y = self._host_shapes(x, 'decorrelate_host', out)
         if batch > MAX_STREAMS_PER_CALL:
             for first in range(0, batch, MAX_STREAMS_PER_CALL):
-                y[first:first + MAX_STREAMS_PER_CALL] = self.decorrelate_host(
-                    x[first:first + MAX_STREAMS_PER_CALL], mode, ms_encode=ms_encode, width=width,
-                    normalize=normalize, eps=eps)
+                self.decorrelate_host(x[first:first + MAX_STREAMS_PER_CALL], mode, ms_encode=ms_encode, width=width,
+                                      normalize=normalize, eps=eps, out=y[first:first + MAX_STREAMS_PER_CALL])
             return y
         tail = (int(mode), int(bool(ms_encode)), int(width is not None), float(width or 0.0),
                 int(normalize), float(eps))
@@ -671,14 +676,21 @@ _default_ctx: dict = {}
 _default_ctx_lock = threading.Lock()
 
 
+def context_for(device: int) -> Context:
+    """The process-wide context of ``device`` (one per device, made on first use; ``multi.DevicePool`` runs one
+    host thread per device through these)."""
+    dev = int(device)
+    with _default_ctx_lock:
+        ctx = _default_ctx.get(dev)
+        if ctx is None:
+            ctx = _default_ctx[dev] = Context(dev)
+    return ctx
+
+
 def default_context() -> Context:
     """Process-wide context on ``VND_DEVICE`` / ``LOCAL_RANK`` / device 0."""
     dev = int(os.environ.get('VND_DEVICE', os.environ.get('LOCAL_RANK', '0')))
     n = device_count()
     if n > 0:
         dev %= n
-    with _default_ctx_lock:
-        ctx = _default_ctx.get(dev)
-        if ctx is None:
-            ctx = _default_ctx[dev] = Context(dev)
-    return ctx
+    return context_for(dev)

@@ -304,9 +304,14 @@ def convolve_velvet_noise(input_signal: NDArray, velvet_noise_filters: NDArray, 
 
 
 def convolve_velvet_noise_batched(input_signals: NDArray, velvet_noise_filters: NDArray, *,
-                                  mode: Optional[int] = None) -> NDArray:
+                                  mode: Optional[int] = None, devices=None) -> NDArray:
     """Many independent streams with one shared filter bank: ``(B, n, C)`` in and
-    out, one kernel launch.  Equals stacking :func:`convolve_velvet_noise` over B."""
+    out, one kernel launch.  Equals stacking :func:`convolve_velvet_noise` over B.
+
+    ``devices``: ``None`` - the process's default device; ``'all'`` or a list of device indices - the
+    batch is cut into contiguous blocks of streams, one per device, run side by side from this one
+    process (``multi.DevicePool``: the table is built once and replicated - over RCCL with more than one
+    device -, no collective on the data path); the result is the same array either way."""
     if input_signals.ndim != 3:
         raise ValueError(f'expected (batch, n, C), got shape {input_signals.shape}')
     fir = np.asarray(velvet_noise_filters)
@@ -324,6 +329,11 @@ def convolve_velvet_noise_batched(input_signals: NDArray, velvet_noise_filters: 
     x = np.ascontiguousarray(input_signals, dtype=np.float32)
     if x.size == 0:
         return np.zeros(x.shape, dtype=np.float32)
+    if devices is not None:
+        from . import multi
+        arrays = function_path_arrays(fir, num_channels)
+        out = _native.pinned_pool.empty(x.shape[:-1] + (arrays.num_channels,), np.float32)
+        return multi.pool_for(devices).map_streams(arrays, x, out, 'convolve', mode)
     table = _fir_tables.get(_fir_key(fir, num_channels),
                             lambda: function_path_arrays(fir, num_channels))
     return table.convolve_host(x, mode)
@@ -624,32 +634,42 @@ class VelvetNoise(Decorrelator):
         return (x.ndim in (2, 3) and x.shape[-1] == self.num_outs and x.shape[-2] > 0
                 and (self.normalizer is None or self.normalizer is rms_normalize))
 
-    def _decorrelate_on_device(self, x: NDArray) -> NDArray:
+    def _decorrelate_on_device(self, x: NDArray, devices=None) -> NDArray:
         stereo_steps = self.mode == LayoutMode.MS or self.width is not None
         if stereo_steps and self.num_outs != 2:
             raise ValueError('Input shape invalid: Expected shape (num samples, 2), '
                              f'but got shape {x.shape[:-1] + (self.num_outs,)}.')
-        table = self._device_table()
-        return table.decorrelate_host(np.ascontiguousarray(x, dtype=np.float32), _default_mode,
-                                      ms_encode=self.mode == LayoutMode.MS, width=self.width,
-                                      normalize=_normalize_flag(self.normalizer is not None))
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        stage = dict(ms_encode=self.mode == LayoutMode.MS, width=self.width,
+                     normalize=_normalize_flag(self.normalizer is not None))
+        if devices is not None and x.ndim == 3:
+            from . import multi
+            out = _native.pinned_pool.empty(x.shape[:-1] + (self.num_outs,), np.float32)
+            return multi.pool_for(devices).map_streams(self._tap_arrays(), x, out, 'decorrelate', _default_mode, **stage)
+        return self._device_table().decorrelate_host(x, _default_mode, **stage)
 
-    def decorrelate_batched(self, input_signals: NDArray) -> NDArray:
+    def decorrelate_batched(self, input_signals: NDArray, *, devices=None) -> NDArray:
         """``(B, n, num_outs)`` independent signals through the whole stage in one
-        device pass (convolution + epilogue on the GPU); float32 result, same shape."""
+        device pass (convolution + epilogue on the GPU); float32 result, same shape.
+        ``devices='all'`` or a list of device indices: contiguous blocks of the batch on several GPUs
+        from this one process (see :func:`convolve_velvet_noise_batched`); the stage's reductions are per
+        stream, so nothing crosses devices."""
         x = to_float32(np.asarray(input_signals))
         if x.ndim != 3:
             raise ValueError(f'expected (batch, n, channels), got shape {x.shape}')
+        if devices is not None:
+            from . import multi
+            multi.resolve_devices(devices)              # a bad list is an error whatever path the batch takes
         if _device_epilogue is None and not _use_device_epilogue(self.num_outs, self.normalizer is not None,
                                                                   x.shape[1], True):
             return np.stack([self.decorrelate(sig[:, 0] if x.shape[-1] == 1 else sig) for sig in x]) \
                 if len(x) else np.zeros(x.shape[:-1] + (self.num_outs,), np.float32)
         if x.shape[-1] == 1 and self.num_outs == 2 and x.shape[1] > 0 and \
                 (self.normalizer is None or self.normalizer is rms_normalize):
-            return self._decorrelate_on_device(x)           # mono signals, fanned out on the device
+            return self._decorrelate_on_device(x, devices if len(x) else None)      # mono signals, fanned out on the device
         if not self._device_epilogue_applies(x):
             return np.stack([self.decorrelate(sig) for sig in x]) if len(x) else np.zeros(x.shape, np.float32)
-        return self._decorrelate_on_device(x)
+        return self._decorrelate_on_device(x, devices if len(x) else None)
 
 
 def decorrelate_bank(input_signal: NDArray, decorrelators: Sequence[VelvetNoise]) -> List[NDArray]:
