@@ -474,6 +474,58 @@ def next_rows(torch, vnd, _native) -> dict:
         out['f1_pool'] = rec
     except Exception as exc:
         out['f1_pool'] = {'error': repr(exc)}
+    # f1 on cfg5's shape: VelvetNoise(num_outs=8, mode='LR', filtered_channels=0..7).decorrelate - how BASELINE's 8-channel config maps onto
+    # the class API (decorrelation.py:417-442 with :433-440 reduced to the per-channel RMS normaliser) - over a resident pool
+    try:
+        from oracle import vnd_oracle as O
+        fs8, n8, pool8 = 96000, 960000, 16
+        kw8 = dict(sample_rate_hz=fs8, num_outs=8, num_impulses=64, filtered_channels=tuple(range(8)), mode='LR', seed=1)
+        vn8 = vnd.VelvetNoise(**kw8)
+        table = vn8._device_table()
+        st = torch.cuda.current_stream().cuda_stream
+        x = torch.empty((pool8, n8, 8), dtype=torch.float32, device='cuda').uniform_(-1, 1)
+        y = torch.empty_like(x)
+        ws_bytes = _native.decorrelate_workspace_bytes(pool8, n8, 8)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device='cuda')
+        rec = {}
+        for label, mode, bytes_per_sample in (('fast_fused', vnd.MODE_FAST, 16), ('exact', vnd.MODE_EXACT, 24)):
+            table.prepare(pool8, n8, 8, mode)
+
+            def run():
+                table.decorrelate_device(x.data_ptr(), y.data_ptr(), pool8, n8, 8, mode=mode, ms_encode=False, width=None,
+                                         normalize=1, workspace_ptr=ws.data_ptr(), workspace_bytes=ws_bytes, stream=st)
+            for _ in range(5):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            reps = 20
+            e0.record()
+            for _ in range(reps):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            b = pool8 - 1
+            want = O.decorrelate(x[b].cpu().numpy(), **kw8)
+            got = y[b].cpu().numpy()
+            if mode == vnd.MODE_EXACT:
+                assert np.array_equal(got, want), 'f1_c8: exact stage differs from the oracle'
+                worst = 0.0
+            else:
+                worst = float(np.max(np.abs(got.astype(np.float64) - want)) / np.max(np.abs(want)))
+                assert worst <= 5e-4, f'f1_c8: fused fast stage off by {worst:.2e} of peak'
+            moved = bytes_per_sample * pool8 * n8 * 8
+            rec[label] = {'ms_per_call': round(ms, 4), 'bytes_per_sample_moved': bytes_per_sample, 'achieved_GBs': round(moved / (ms * 1e-3) / 1e9, 1),
+                          'frac_of_8TBs': round(moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'Msamples_s': round(pool8 * n8 * 8 / (ms * 1e-3) / 1e6, 1),
+                          'parity_vs_oracle_stage_of_peak': worst, 'launch': table.describe(pool8, n8, 8, mode)[:200]}
+        rec['what'] = ('vnd_decorrelate_f32_dev of 16 x 10 s 96 kHz 8-channel signals (LR mode: the per-channel RMS normaliser alone), class-path table of 64 '
+                       'taps per channel; fractions by the bytes the stage must move: 16 B per sample fused (convolution 8 + scale pass 8), 24 exact (+ 8: the '
+                       'reference-order sums read x and y)')
+        out['f1_c8'] = rec
+        del x, y, ws
+        torch.cuda.empty_cache()
+    except Exception as exc:
+        out['f1_c8'] = {'error': repr(exc)}
     # fan-out: mono in, stereo out (decorrelation.py:431-432) on the cfg2 shape, device resident, throughput mode
     try:
         from vndecorrelate_amd.taps import function_path_arrays

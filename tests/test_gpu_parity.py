@@ -849,3 +849,50 @@ def test_block_sums_from_the_convolutions_store_phase(vnd):
         assert np.array_equal(y, out['per-stream'][1]), label
     for b in (0, 1, 3):
         assert np.array_equal(out['from the store phase'][1][b], O.decorrelate(x[b], sample_rate_hz=48000, seed=1)), b
+
+
+def test_eight_channel_decorrelate_fast_stage_through_the_octet_kernels_sums(vnd, golden):
+    """cfg5 through the class API (VelvetNoise(num_outs=8, mode='LR', filtered_channels=0..7).decorrelate, decorrelation.py:417-442):
+    in the fast mode the per-channel RMS normaliser's sums of squares leave the octet kernel's store phase and one pass scales.
+    Against the golden reference output (dec_c8_lr) and, on a pool at the bench's shape, against the oracle's whole stage; the bar is
+    the fused stage's 5e-4 of peak (the reference's RMS is a SEQUENTIAL float32 sum, the device's a float64 one - the exact mode
+    keeps the sequential order and is bit-identical: asserted beside it); the scales themselves against float64 sums to 1e-6."""
+    import torch
+    from vndecorrelate_amd import _native
+    from conftest import make_input
+    meta = golden.manifest['cls_decorrelate']['dec_c8_lr']
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in golden.manifest['class_taps'][meta['class']]['kwargs'].items()}
+    vn = vnd.VelvetNoise(**kw)
+    x = make_input(meta['input'])
+    golden.expect('dec_c8_lr', vn.decorrelate(x), exact=True)                      # exact mode: the reference's bits
+    ctx = _native.default_context()
+    table = vn._device_table()
+    ctx.set_variant(1 << 23)                                                       # specialise however little work there is
+    vnd.set_default_mode(vnd.MODE_FAST)
+    try:
+        assert 'pieces=channel-octets' in table.describe(1, len(x), 8, vnd.MODE_FAST)
+        golden.expect('dec_c8_lr', vn.decorrelate(x), exact=False, rtol_peak=5e-4)
+    finally:
+        vnd.set_default_mode(vnd.MODE_EXACT)
+        ctx.set_variant(-1)
+    # a pool at the bench's shape, ragged in time (the last tile is partial), device resident
+    pool, n = 6, 960000 - 1234
+    xs = torch.empty((pool, n, 8), dtype=torch.float32, device='cuda').uniform_(-1, 1)
+    ys = torch.empty_like(xs)
+    ws_bytes = _native.decorrelate_workspace_bytes(pool, n, 8)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    assert 'pieces=channel-octets' in table.describe(pool, n, 8, vnd.MODE_FAST)
+    table.decorrelate_device(xs.data_ptr(), ys.data_ptr(), pool, n, 8, mode=vnd.MODE_FAST, ms_encode=False, width=None, normalize=1,
+                             workspace_ptr=ws.data_ptr(), workspace_bytes=ws_bytes, stream=st)
+    conv = torch.empty_like(xs)
+    table.convolve_device(xs.data_ptr(), conv.data_ptr(), pool, n, 8, vnd.MODE_FAST, st)
+    torch.cuda.synchronize()
+    # the scale the stage applied, per (stream, channel), against float64 sums of squares of what it scaled
+    want_scale = torch.sqrt((xs.double() ** 2).mean(dim=1)) / torch.sqrt((conv.double() ** 2).mean(dim=1) + 1e-10)
+    got_scale = (ys.double() * conv.double()).sum(dim=1) / (conv.double() ** 2).sum(dim=1)
+    assert float(((got_scale - want_scale).abs() / want_scale).max()) <= 1e-6
+    for b in (0, pool - 1):
+        want = O.decorrelate(xs[b].cpu().numpy(), **kw)
+        err = float(np.max(np.abs(ys[b].cpu().numpy().astype(np.float64) - want)) / np.max(np.abs(want)))
+        assert err <= 5e-4, (b, err)

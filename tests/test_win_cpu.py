@@ -402,3 +402,38 @@ def test_quads_and_octets_with_a_wave_per_channel(native, golden, tmp_path, mode
     monkeypatch.setenv('VND_WIN_QUAD', '0')
     pairs = native.window_kernel_source(offs, idx, w, mode, M, 256)
     assert _macro(pairs, 'VW_Q') == 0 and _macro(pairs, 'VW_R') == 256 + _macro(pairs, 'VW_DE')
+
+
+@pytest.mark.parametrize('Q', [2, 1])
+def test_quads_and_octets_leave_the_normalisers_sums_in_the_store_phase(native, golden, tmp_path, Q, monkeypatch):
+    """VelvetNoise.decorrelate on 4k channels (LR mode: the per-channel RMS normaliser alone, decorrelation.py:433-440) in the fast
+    mode: the quad / octet kernel built with VW_EPI adds up the squares of a lane's input run (still in its ring entry) and of its
+    outputs (in registers) before the store phase overwrites the entry - 8 more 16-byte LDS reads per lane and tile, two float64
+    butterflies per wave, one row of 2 C sums per (tile, channel wave).  Cross-compiled: still no spill, the same stores, the
+    same barriers, and the float64 adds are there."""
+    offs, idx, w = _table(golden.fir('g96k_k64_c8'))
+    M, nt = 32, 256 * Q
+    monkeypatch.setenv('VND_WIN_OCTET', '1' if Q == 2 else '0')
+    plain = native.window_kernel_source(offs, idx, w, 2, M, nt)
+    monkeypatch.setenv('VND_WIN_SOURCE_EPI', '1')
+    src = native.window_kernel_source(offs, idx, w, 2, M, nt)
+    assert _macro(plain, 'VW_EPI') == 0 and _macro(src, 'VW_EPI') == 1 and _macro(src, 'VW_Q') == Q
+    asm = {}
+    for tag, text in (('plain', plain), ('epi', src)):
+        f = tmp_path / f'{tag}.hip'
+        f.write_text(text)
+        out = tmp_path / f'{tag}.s'
+        r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only',
+                            '-include', 'hip/hip_runtime.h', '-S', str(f), '-o', str(out)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        asm[tag] = out.read_text()
+        assert re.search(r'ScratchSize: 0\b', asm[tag]), f'{tag}: the quad / octet kernel must not spill'
+    ops = {tag: re.findall(r'^\s+([a-z0-9_]+)', text, re.M) for tag, text in asm.items()}
+    spans = 2 // Q
+    assert ops['epi'].count('s_barrier') == ops['plain'].count('s_barrier') == spans * 3
+    assert ops['epi'].count('buffer_store_dwordx4') == ops['plain'].count('buffer_store_dwordx4')
+    assert ops['plain'].count('v_add_f64') == 0 and ops['epi'].count('v_add_f64') >= spans * 12          # 2 sums x 6 butterfly steps
+    assert ops['epi'].count('ds_bpermute_b32') == spans * 24
+    assert ops['epi'].count('ds_read_b128') - ops['plain'].count('ds_read_b128') == spans * (M // 4)   # the lane's own input run
+    # the exact mode has no such build: its sums follow NumPy's order (epilogue_rms_seq_kernel)
+    assert _macro(native.window_kernel_source(offs, idx, w, 0, M, nt), 'VW_EPI') == 0

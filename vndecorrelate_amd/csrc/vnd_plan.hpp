@@ -317,6 +317,11 @@ struct EpiFuse {                 // non-null => launch the fused-epilogue instan
     int nblocks = 0;
     int rows_major = 0;          // 1: [stream][block][x0 x1 y0 y1] - rows for epilogue_reduce_kernel (the fused fast stage's sums)
     int *path = nullptr;         // out: 0 a generic kernel ran, 1 the per-table kernel and it left the block sums, 2 the per-table kernel without them
+    // 4k-channel tables (quad / octet form): the store phase leaves one row of 2 C sums of squares per (tile, wave of a channel) in
+    // blk_sum (rows_major); *rows = rows per stream it writes.  spec_only: launch nothing if the per-table kernel does not take it
+    // (*path stays 0: the caller goes on with its unfused passes)
+    int *rows = nullptr;
+    bool spec_only = false;
 };
 
 // variant word, specialised kernel: bit 25 forces the generic kernel; bits 26-27 prefetch depth
@@ -332,7 +337,11 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     // a fused epilogue is within scope when it is the pointwise steps alone (no sums, no moments sink) on a stereo output:
     // they ride in the per-table kernels' store phase (VS_EPI)
     // (... with the normaliser's sums too where the caller offers room for per-block sums: the window form's store phase leaves them)
-    const bool pointwise = epi != nullptr && (!epi->normalize || epi->blk_sum != nullptr) && epi->sink == nullptr && C == 2;
+    const bool pointwise2 = epi != nullptr && (!epi->normalize || epi->blk_sum != nullptr) && epi->sink == nullptr && C == 2;
+    // ... and on 4k channels the normaliser's sums alone (LR mode: no pointwise step exists there), in the quad / octet form's store phase
+    const bool sums_q = epi != nullptr && epi->sink == nullptr && C % 4 == 0 && Cx == C && !epi->ms_encode && !epi->use_width &&
+                        epi->normalize && epi->blk_sum != nullptr && epi->rows_major && epi->rows != nullptr && mode == VND_MODE_FAST;
+    const bool pointwise = pointwise2 || sums_q;
     // fan-out: a mono input through a stereo table is in scope (one LDS plane, VS_BC); wider fan-outs are not
     const bool bc = Cx == 1 && C == 2;
     if ((epi != nullptr && !pointwise) || (Cx != C && !bc)) { p.why = "fused epilogue or fan-out launch"; return p; }
@@ -380,7 +389,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     // signals of 4k channels: the window form on channel QUADS / OCTETS (VW_Q, vw_span_qc: a workgroup moves 16 / 32 bytes of every
     // frame, a wave per channel) - VND_WIN_QUAD=0 keeps the pair-read kernel (or, with VND_WIN_WIDE=1 / variant bits 5-7, the
     // window form on channel pairs)
-    const bool win_quad = C % 4 == 0 && Cx == C && !pointwise && spec_env("VND_WIN_QUAD", 1) != 0;
+    const bool win_quad = C % 4 == 0 && Cx == C && (!pointwise || sums_q) && spec_env("VND_WIN_QUAD", 1) != 0;
     // (a geometry whose build failed or spilled is remembered in the table's module map: skipped, the next best taken)
     const bool nt_big = batch * n * C * (int64_t)sizeof(float) >= ((int64_t)spec_env("VND_NT_MIN_MB", 64) << 20);
     auto nt_stores_of = [&](const SpecConfig &c) {
@@ -431,6 +440,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, bc, &p.cfg, rejected, 0, true, exact_now);
     if (!picked && win_mode_ok && win_c && (!bc || vw >= 2))
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, bc, &p.cfg, rejected);
+    if (sums_q && !(picked && p.cfg.win_q)) { p.why = "the sums of a 4k-channel table ride in the quad / octet form only"; return p; }
     if (!picked && !spec_pick_config(t->spec_table, (size_t)ctx->lds_limit, rr_hint, dd_hint, &p.cfg, attempt == 1 || C != 2, bc, mode == VND_MODE_EXACT)) { p.why = "halo does not fit the ring"; return p; }
     const int64_t T = p.cfg.tile();
     const int64_t tiles_total = (n + T - 1) / T;
@@ -611,6 +621,12 @@ static vnd_status launch_spec(vnd_ctx *ctx, const vnd_taps *t, const SpecPlan &p
         if (epi->blk_sum != nullptr && p.cfg.win == 32 && !p.cfg.win_s && !p.cfg.win_q && p.cfg.tile() % kParFrames == 0) {
             a.epi_blk_sum = epi->blk_sum; a.epi_nblocks = epi->nblocks; a.epi_rows_major = epi->rows_major;
         }
+        // quads / octets: a row per (tile, wave of a channel) - the plan's tiles x the waves a channel has
+        if (epi->blk_sum != nullptr && p.cfg.win_q && epi->rows_major && epi->rows != nullptr) {
+            a.epi_blk_sum = epi->blk_sum; a.epi_rows_major = 1;
+            a.epi_nblocks = p.tiles_total * std::max(1, p.cfg.nt / 64 / (4 * p.cfg.win_q));
+            *epi->rows = a.epi_nblocks;
+        }
     }
     void *params[] = {&a};
     hipError_t e = hipModuleLaunchKernel(m->fn, p.nblocks, 1, 1, p.cfg.nt, 1, 1, (unsigned)p.cfg.lds_bytes(), stream, params,
@@ -643,6 +659,7 @@ static vnd_status launch(vnd_ctx *ctx, const vnd_taps *t, const float *x, float 
         if (st != VND_OK || launched) return st;
         if (!sp.cfg.win || built) break;                          // (a failed window build: plan again, that geometry is skipped now)
     }
+    if (epi != nullptr && epi->spec_only) return VND_OK;          // (*epi->path is 0: nothing was launched)
     const Plan p = make_plan(ctx, t, batch, n, C, mode, Cx);
     KArgs a{};
     a.x = x; a.y = y; a.taps = t->d_taps; a.taps_fast = t->d_taps_fast; a.taps_ord = t->d_taps_ord; a.fast_off = t->d_fast_off; a.fast_even = t->d_fast_even; a.tap_off = t->d_tap_off;

@@ -94,7 +94,23 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
     }
     const bool want_blk = par_ok && (batch < 256 || par_forced) && spec_env("VND_EPI_BLOCK_SUMS", 1) != 0;
     bool sums_pending = false;                             // the sequential sums still have to run
-    if (fused) {
+    // 4k channels, fast mode, the normaliser alone (LR mode - cfg5 through the class API, decorrelation.py:433-440): the quad / octet
+    // kernel's store phase leaves the sums of squares on its way (x still in the ring, y in registers), one streaming pass scales:
+    // 16 bytes per sample instead of 24.  Where that kernel does not take the launch nothing has run and the passes below do.
+    bool q_done = false;
+    if (mode == VND_MODE_FAST && normalize && !want_seq && !ms_encode && !use_width && C % 4 == 0 && Cx == C &&
+        ctx->variant_nofuse == 0 && spec_env("VND_EPI_BLOCK_SUMS", 1) != 0) {
+        int rows_q = 0;
+        EpiFuse f{(double *)workspace, 0, 0, e.normalize, e.w_mid, e.w_side};
+        f.path = &conv_path; f.blk_sum = (double *)workspace; f.rows_major = 1; f.rows = &rows_q; f.spec_only = true;
+        st = launch(ctx, t, x, y, batch, n, C, mode, stream, &f, Cx);
+        if (st != VND_OK) return st;
+        if (conv_path == 1 && rows_q > 0 && rows_q <= epi_rows_max(n)) { e.rows = rows_q; q_done = true; }
+        else if (conv_path != 0) return fail(VND_ERR_HIP, "the quad / octet kernel ran without its sums");
+    }
+    if (q_done) {
+        // (nothing more before the reduce and scale passes)
+    } else if (fused) {
         // with reference-order sums the fused kernel only applies the pointwise steps
         EpiFuse f{(double *)workspace, e.ms_encode, e.use_width, want_seq ? 0 : e.normalize, e.w_mid, e.w_side};
         f.path = &conv_path;
