@@ -1119,7 +1119,7 @@ def main():
         # the long record: a side file (and gpurun_out/, which travels back from a GPU box) and stderr; the short line: stdout, last
         text = json.dumps(detail, indent=1)
         targets = [pathlib.Path(args.detail)] if args.detail else [REPO / 'bench_detail.json']
-        if (REPO / 'gpurun_out').is_dir():
+        if not args.detail and (REPO / 'gpurun_out').is_dir():
             targets.append(REPO / 'gpurun_out' / 'bench_detail.json')
         for target in targets:
             try:

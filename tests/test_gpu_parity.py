@@ -896,3 +896,40 @@ def test_eight_channel_decorrelate_fast_stage_through_the_octet_kernels_sums(vnd
         want = O.decorrelate(xs[b].cpu().numpy(), **kw)
         err = float(np.max(np.abs(ys[b].cpu().numpy().astype(np.float64) - want)) / np.max(np.abs(want)))
         assert err <= 5e-4, (b, err)
+
+
+@pytest.mark.parametrize('channels', [4, 6, 8])
+def test_exact_rms_sums_of_wider_signals_block_parallel_equal_the_per_stream_kernel(vnd, channels):
+    """The reference-order (NumPy: sequential float32) sums of squares of the exact stage on signals of more than two channels run
+    block-parallel, channel pair by channel pair (round 5; before, one workgroup per stream: 8.7 ms for cfg5's pool of 16).  Same
+    bits as the per-stream kernel (variant bit 19 keeps it) on every stream of a ragged pool, and as the oracle's whole stage -
+    np.mean(np.square(.)) itself - on two of them; signals with exact float32 ties (16-bit audio) and a silent channel included."""
+    import torch
+    from vndecorrelate_amd import _native
+    kw = dict(sample_rate_hz=48000, num_outs=channels, num_impulses=30, filtered_channels=tuple(range(channels)), mode='LR', seed=3)
+    vn = vnd.VelvetNoise(**kw)
+    table = vn._device_table()
+    ctx = _native.default_context()
+    pool, n = 5, 200000 + 77
+    rng = np.random.default_rng(channels)
+    host = rng.uniform(-1, 1, (pool, n, channels)).astype(np.float32)
+    host[1] = (np.round(host[1] * 20000) / 32768.0).astype(np.float32)           # 16-bit audio: squares that tie in float32
+    host[2, :, channels - 1] = 0.0                                                # a silent channel: rms 0, scale 0 / sqrt(eps)
+    xs = torch.from_numpy(host).cuda()
+    ws_bytes = _native.decorrelate_workspace_bytes(pool, n, channels)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for name, variant in (('block_parallel', -1), ('per_stream', 1 << 19)):
+        ctx.set_variant(variant)
+        try:
+            y = torch.empty_like(xs)
+            table.decorrelate_device(xs.data_ptr(), y.data_ptr(), pool, n, channels, mode=vnd.MODE_EXACT, ms_encode=False, width=None,
+                                     normalize=1, workspace_ptr=ws.data_ptr(), workspace_bytes=ws_bytes, stream=st)
+            torch.cuda.synchronize()
+            out[name] = y.cpu().numpy()
+        finally:
+            ctx.set_variant(-1)
+    assert np.array_equal(out['block_parallel'], out['per_stream'])
+    for b in (1, 2):
+        assert np.array_equal(out['block_parallel'][b], O.decorrelate(host[b], **kw)), b

@@ -583,7 +583,21 @@ struct RArgs {
     int32_t prefixed;                // blk_sum already holds EXCLUSIVE prefix sums (rms_par_prefix_kernel ran)
     int32_t wide;                    // every stream of x and y starts 16-byte aligned: the staging loads are whole 16-byte accesses
     double *__restrict__ partials;   // [batch][4]: the sums, as the sequential kernel writes them
+    // signals of more than two channels: a "stream" of these kernels is a CHANNEL PAIR of a stream - index b = stream * pairs + pair
+    // everywhere (blk_sum, rec, grp, first: [batch * pairs][4][...]); the loaders read the pair's 8 bytes of every C-channel frame
+    // and the stitch kernel writes the sums where the sequential kernel would: partials[stream][x_0 .. x_C-1, y_0 .. y_C-1]
+    int32_t C;                       // channels per frame (2: stereo, the original form)
+    int32_t pairs;                   // C / 2
 };
+
+// the pair's first sample of frame f0 of its stream, and the bytes from there to the stream's end
+__device__ __forceinline__ const float *par_pair_base(const RArgs &a, const float *arr, int64_t b, int64_t f0, int ch, int64_t *bytes)
+{
+    const int64_t stream = b / a.pairs;
+    const int pair = (int)(b - stream * a.pairs);
+    *bytes = (a.n - f0) * (int64_t)a.C * 4 - (2 * pair + ch) * 4;
+    return arr + (stream * a.n + f0) * a.C + 2 * pair + ch;
+}
 
 // squares of block `blk` of stream b into sq[4][2048] (chains: x ch0, x ch1, y ch0, y ch1); frames
 // past the end of the stream read 0 and add +0, exact
@@ -591,6 +605,26 @@ template <bool MONO>
 __device__ __forceinline__ void par_stage(const RArgs &a, int64_t b, int blk, float *sq, int tid)
 {
     const int64_t f0 = (int64_t)blk * kParFrames;
+    if (!MONO && a.C > 2) {
+        // a channel pair of a wider signal: 8 bytes of every frame, frames C * 4 bytes apart
+        int64_t xb, yb;
+        const float *xs = par_pair_base(a, a.x, b, f0, 0, &xb), *ys = par_pair_base(a, a.y, b, f0, 0, &yb);
+        const v4i rx = make_rsrc(xs, xb), ry = make_rsrc(ys, yb);
+        const int fb = a.C * 4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int fr = 4 * tid + 1024 * u;
+            v2f xf[4], yf[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { xf[k] = buf_load2(rx, (fr + k) * fb, 0, 0); yf[k] = buf_load2(ry, (fr + k) * fb, 0, 0); }
+            float4 *dst = (float4 *)(sq + fr);
+            dst[0 * kParFrames / 4] = make_float4(xf[0].x * xf[0].x, xf[1].x * xf[1].x, xf[2].x * xf[2].x, xf[3].x * xf[3].x);
+            dst[1 * kParFrames / 4] = make_float4(xf[0].y * xf[0].y, xf[1].y * xf[1].y, xf[2].y * xf[2].y, xf[3].y * xf[3].y);
+            dst[2 * kParFrames / 4] = make_float4(yf[0].x * yf[0].x, yf[1].x * yf[1].x, yf[2].x * yf[2].x, yf[3].x * yf[3].x);
+            dst[3 * kParFrames / 4] = make_float4(yf[0].y * yf[0].y, yf[1].y * yf[1].y, yf[2].y * yf[2].y, yf[3].y * yf[3].y);
+        }
+        return;
+    }
     const float *xs = a.x + (b * a.n + f0) * (MONO ? 1 : 2);
     const float *ys = a.y + (b * a.n + f0) * 2;
     const v4i rx = make_rsrc(xs, (a.n - f0) * (MONO ? 4 : 8));
@@ -804,10 +838,12 @@ __device__ __forceinline__ float4 par_fetch4(const RArgs &a, int64_t b, int chai
         return make_float4(buf_load1(rs, (fr + 0) * 4, 0, 0), buf_load1(rs, (fr + 1) * 4, 0, 0),
                            buf_load1(rs, (fr + 2) * 4, 0, 0), buf_load1(rs, (fr + 3) * 4, 0, 0));
     }
-    const float *src = (from_x ? a.x : a.y) + (b * a.n + f0) * 2 + ch;
-    const v4i rs = make_rsrc(src, ((a.n - f0) * 2 - ch) * 4);
-    return make_float4(buf_load1(rs, (fr + 0) * 8, 0, 0), buf_load1(rs, (fr + 1) * 8, 0, 0),
-                       buf_load1(rs, (fr + 2) * 8, 0, 0), buf_load1(rs, (fr + 3) * 8, 0, 0));
+    int64_t bytes;
+    const float *src = par_pair_base(a, from_x ? a.x : a.y, b, f0, ch, &bytes);       // (stereo: C = 2, one pair - the stream itself)
+    const v4i rs = make_rsrc(src, bytes);
+    const int fb = a.C * 4;
+    return make_float4(buf_load1(rs, (fr + 0) * fb, 0, 0), buf_load1(rs, (fr + 1) * fb, 0, 0),
+                       buf_load1(rs, (fr + 2) * fb, 0, 0), buf_load1(rs, (fr + 3) * fb, 0, 0));
 }
 
 // squares of `count` frames of one chain, starting at frame f0 of stream b, into dst (4 per lane and round)
@@ -825,12 +861,14 @@ __device__ __forceinline__ void par_load_squares(const RArgs &a, int64_t b, int 
             *(float4 *)(dst + fr) = make_float4(s0 * s0, s1 * s1, s2 * s2, s3 * s3);
         }
     } else {
-        const float *src = (from_x ? a.x : a.y) + (b * a.n + f0) * 2 + ch;
-        const v4i rs = make_rsrc(src, ((a.n - f0) * 2 - ch) * 4);
+        int64_t bytes;
+        const float *src = par_pair_base(a, from_x ? a.x : a.y, b, f0, ch, &bytes);
+        const v4i rs = make_rsrc(src, bytes);
+        const int fb = a.C * 4;
         for (int u = 0; u < count; u += 256) {
             const int fr = u + 4 * lane;
-            const float s0 = buf_load1(rs, (fr + 0) * 8, 0, 0), s1 = buf_load1(rs, (fr + 1) * 8, 0, 0);
-            const float s2 = buf_load1(rs, (fr + 2) * 8, 0, 0), s3 = buf_load1(rs, (fr + 3) * 8, 0, 0);
+            const float s0 = buf_load1(rs, (fr + 0) * fb, 0, 0), s1 = buf_load1(rs, (fr + 1) * fb, 0, 0);
+            const float s2 = buf_load1(rs, (fr + 2) * fb, 0, 0), s3 = buf_load1(rs, (fr + 3) * fb, 0, 0);
             *(float4 *)(dst + fr) = make_float4(s0 * s0, s1 * s1, s2 * s2, s3 * s3);
         }
     }
@@ -983,7 +1021,12 @@ __global__ __launch_bounds__(64) void rms_par_stitch_kernel(const RArgs a)
             }
         }
     }
-    if (lane == 0) a.partials[b * 4 + chain] = (double)acc;
+    if (lane == 0) {
+        // where the sequential kernel leaves a stream's sums: x's C chains, then y's (stereo: b * 4 + chain)
+        const int64_t stream = b / a.pairs;
+        const int pair = (int)(b - stream * a.pairs);
+        a.partials[stream * 2 * a.C + (chain >= 2 ? a.C : 0) + 2 * pair + (chain & 1)] = (double)acc;
+    }
 }
 
 // ---- NumPy's sum of squares of a SINGLE-channel float32 signal, bit for bit ------------------------

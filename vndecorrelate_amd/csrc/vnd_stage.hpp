@@ -17,8 +17,9 @@ vnd_status vnd_decorrelate_workspace_bytes(int64_t batch, int64_t n, int32_t C, 
 {
     if (!bytes || batch < 0 || n < 0 || C <= 0) return fail(VND_ERR_INVALID, "bad workspace query");
     *bytes = batch * epi_rows_max(n) * 2 * C * (int64_t)sizeof(double) + batch * C * (int64_t)sizeof(float) + 16;
-    // the parallel exact sums of a stereo table: per stream and chain, a float64 sum and a record per block
-    if (C == 2) *bytes += 32 + batch * 4 * (par_blocks(n) * (int64_t)(sizeof(double) + sizeof(ParRec) + sizeof(ParGrp)) + (int64_t)sizeof(float));
+    // the parallel exact sums (stereo tables, and channel pair by channel pair for wider ones): per stream, pair and chain, a float64
+    // sum and a record per block
+    if (C % 2 == 0) *bytes += 32 + batch * (C / 2) * 4 * (par_blocks(n) * (int64_t)(sizeof(double) + sizeof(ParRec) + sizeof(ParGrp)) + (int64_t)sizeof(float));
     // the pairwise sums of a single-channel table: one float per (stream, array, 8192-sample chunk)
     if (C == 1) *bytes += 32 + batch * 2 * pw_chunks(n) * (int64_t)sizeof(float);
     return VND_OK;
@@ -76,23 +77,27 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
     //   65 .. 255: it still fills less than every CU once (128: 0.80 / 0.82, and 0.66 once the block sums come from the convolution);
     //   256 and more: it fills the chip by itself and reads the data once instead of twice (1024: 4.36 / 6.76).
     // variant bit 19 keeps the per-stream kernel, bit 17 forces the block-parallel form (A/B runs).
-    const bool par_ok = want_seq && C == 2 && par_blocks(n) <= kParMaxBlocks && !(ctx->variant >= 0 && ((ctx->variant >> 19) & 1));
+    // Wider signals (round 5): the same kernels channel pair by channel pair - a "stream" of theirs is one pair of a stream (RArgs::pairs),
+    // 8 bytes of every frame.  The per-stream kernel takes 16 workgroups for cfg5's pool of 16 signals (8.7 ms for the stage); the
+    // block-parallel form 16 x 4 pairs x 469 blocks.
+    const int pairs = C / 2;
+    const bool par_ok = want_seq && C % 2 == 0 && (C == 2 || Cx == C) && par_blocks(n) <= kParMaxBlocks && !(ctx->variant >= 0 && ((ctx->variant >> 19) & 1));
     const bool par_forced = ctx->variant >= 0 && ((ctx->variant >> 17) & 1);
     RArgs r{};
     int conv_path = 0;                                     // EpiFuse::path of the convolution launch
     if (par_ok) {
-        r.x = x; r.y = y; r.n = n; r.Cx = Cx; r.nblocks = (int32_t)par_blocks(n);
+        r.x = x; r.y = y; r.n = n; r.Cx = Cx; r.nblocks = (int32_t)par_blocks(n); r.C = C; r.pairs = pairs;
         char *extra = (char *)((float *)((double *)workspace + batch * epi_rows_max(n) * 2 * C) + batch * C);
         extra += (16 - ((uintptr_t)extra & 15)) & 15;
         r.blk_sum = (double *)extra;
-        r.rec = (ParRec *)(r.blk_sum + batch * 4 * (int64_t)r.nblocks);
-        r.grp = (ParGrp *)(r.rec + batch * 4 * (int64_t)r.nblocks);
-        r.first = (float *)(r.grp + batch * 4 * (int64_t)r.nblocks);
+        r.rec = (ParRec *)(r.blk_sum + batch * pairs * 4 * (int64_t)r.nblocks);
+        r.grp = (ParGrp *)(r.rec + batch * pairs * 4 * (int64_t)r.nblocks);
+        r.first = (float *)(r.grp + batch * pairs * 4 * (int64_t)r.nblocks);
         r.partials = (double *)workspace;
         r.prefixed = r.nblocks > kParPrefixBlocks ? 1 : 0;
         r.wide = e.wide;
     }
-    const bool want_blk = par_ok && (batch < 256 || par_forced) && spec_env("VND_EPI_BLOCK_SUMS", 1) != 0;
+    const bool want_blk = par_ok && C == 2 && (batch < 256 || par_forced) && spec_env("VND_EPI_BLOCK_SUMS", 1) != 0;
     bool sums_pending = false;                             // the sequential sums still have to run
     // 4k channels, fast mode, the normaliser alone (LR mode - cfg5 through the class API, decorrelation.py:433-440): the quad / octet
     // kernel's store phase leaves the sums of squares on its way (x still in the ring, y in registers), one streaming pass scales:
@@ -155,13 +160,14 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
         sums_pending = seq;
     }
     const bool blk_done = conv_path == 1 && want_blk;
-    const bool par_sums = sums_pending && par_ok && (batch <= 64 || par_forced || blk_done);
+    // (wider signals: the per-stream kernel fills the chip from 256 streams on, as for stereo; below that the pairs' blocks do)
+    const bool par_sums = sums_pending && par_ok && (batch <= 64 || par_forced || blk_done || (C > 2 && batch < 256));
     if (par_sums) {
         e.rows = 1;
         e.exact_rms = 1;
         e.normalize = 1;
-        const dim3 pgrid((unsigned)r.nblocks, (unsigned)batch), tgrid((unsigned)r.nblocks, (unsigned)batch);     // tally: blocks 1.., plus block 0's chain
-        const dim3 sgrid((unsigned)(batch * 4));
+        const dim3 pgrid((unsigned)r.nblocks, (unsigned)(batch * pairs)), tgrid((unsigned)r.nblocks, (unsigned)(batch * pairs));     // tally: blocks 1.., plus block 0's chain
+        const dim3 sgrid((unsigned)(batch * pairs * 4));
         if (Cx == 1) {
             if (!blk_done) hipLaunchKernelGGL(rms_par_sum_kernel<true>, pgrid, dim3(kParThreads), 0, stream, r);
             if (r.prefixed) hipLaunchKernelGGL(rms_par_prefix_kernel, dim3((unsigned)(batch * 4)), dim3(kParThreads), 0, stream, r);
@@ -169,7 +175,7 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
             hipLaunchKernelGGL(rms_par_stitch_kernel<true>, sgrid, dim3(64), 0, stream, r);
         } else {
             if (!blk_done) hipLaunchKernelGGL(rms_par_sum_kernel<false>, pgrid, dim3(kParThreads), 0, stream, r);
-            if (r.prefixed) hipLaunchKernelGGL(rms_par_prefix_kernel, dim3((unsigned)(batch * 4)), dim3(kParThreads), 0, stream, r);
+            if (r.prefixed) hipLaunchKernelGGL(rms_par_prefix_kernel, dim3((unsigned)(batch * pairs * 4)), dim3(kParThreads), 0, stream, r);
             hipLaunchKernelGGL(rms_par_tally_kernel<false>, tgrid, dim3(kParThreads), 0, stream, r);
             hipLaunchKernelGGL(rms_par_stitch_kernel<false>, sgrid, dim3(64), 0, stream, r);
         }
