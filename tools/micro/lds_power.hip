@@ -92,13 +92,19 @@ __global__ __launch_bounds__(512) void fma_kernel(float *out, int trips, unsigne
 #pragma unroll
     for (int j = 0; j < 32; ++j) acc[j] = 0.0f;
     const float w = 0.37f;
-    for (int t = 0; t < trips; ++t) {
+    for (int t = 0; t < trips; t += 8) {
+        // (eight passes per loop trip: a 16-instruction loop body spends half its time in the branch - first version of this probe)
+#pragma unroll
+        for (int rep = 0; rep < 8; ++rep) {
 #pragma unroll
         for (int j = 0; j < 32; j += 2) {
             if constexpr (KIND == 0) {
                 v2f a = {acc[j], acc[j + 1]};
                 a = __builtin_elementwise_fma(v2f{x[j], x[j + 1]}, v2f{w, w}, a);
                 acc[j] = a.x; acc[j + 1] = a.y;
+            } else if constexpr (KIND == 3) {
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[j]) : "v"(x[j]), "v"(w));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[j + 1]) : "v"(x[j + 1]), "v"(w));
             } else if constexpr (KIND == 1) {
                 asm volatile("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(acc[j]) : "v"(x[j]), "v"(w));
                 asm volatile("v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(acc[j + 1]) : "v"(x[j + 1]), "v"(w));
@@ -112,6 +118,7 @@ __global__ __launch_bounds__(512) void fma_kernel(float *out, int trips, unsigne
         }
 #pragma unroll
         for (int j = 0; j < 32; ++j) asm volatile("" : "+v"(acc[j]), "+v"(x[j]));
+        }
     }
     float sum = 0.0f;
 #pragma unroll
@@ -257,8 +264,12 @@ int main(int argc, char **argv)
     run<4>(smp, have, "8 waves: reads + 4 v_pk_fma_f32 per read, random", 3, seconds);
     run<4, 256>(smp, have, "4 waves (a half-wave per channel, 64-frame runs): + 4 per read, random", 3, seconds);
     run<3, 256>(smp, have, "4 waves: reads + 3 v_pk_fma_f32 per read, random", 3, seconds);
+    printf("-- cfg3's tap phase: 4096 packed FMAs per 374 window reads, lane and tile = 11 per read (FMA rate = B/ns/CU / 1024 x 11 x 128 x 2 flop x 256 CUs)\n");
+    run<11>(smp, have, "8 waves: reads + 11 v_pk_fma_f32 per read, zeros", 0, seconds);
+    run<11>(smp, have, "8 waves: reads + 11 v_pk_fma_f32 per read, random", 3, seconds);
     printf("-- windows from the neighbouring lanes' registers: FMA streams on held registers, no LDS, 8 waves per CU, random operands\n");
     run_fma<0>(smp, have, "v_pk_fma_f32 (what the tap phase issues today)", seconds);
+    run_fma<3>(smp, have, "v_fmac_f32 (one FMA per lane and instruction)", seconds);
     run_fma<1>(smp, have, "v_fmac_f32 with a DPP row_shr:1 operand (one FMA per lane and instruction)", seconds);
     run_fma<2>(smp, have, "v_mov_b32 row_shr:1 x 2 + v_pk_fma_f32 (a shifted pair)", seconds);
     return 0;

@@ -8,7 +8,7 @@ tag=${1:-run}; shift || true
 out=gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-args=(--steps 20 --warmup 5 --no-cpu --no-exact --no-secondary "$@")
+args=(--steps 20 --warmup 5 --no-cpu --no-exact --no-secondary --no-strong --no-power "$@")
 run() {  # name, rocprof options...
   local name=$1; shift
   rocprofv3 "$@" -d "$out/$name" -o p --output-format csv -- python3 bench.py "${args[@]}" > "$out/$name.log" 2>&1
@@ -17,7 +17,7 @@ run() {  # name, rocprof options...
 # (the trace pass times 100 launches, so that the csv's plain average - which includes the cold warm-up launches -
 #  is the steady-state figure to within ~1 %)
 args_pmc=("${args[@]}")
-args=(--steps 100 --warmup 5 --no-cpu --no-exact --no-secondary "$@")
+args=(--steps 100 --warmup 5 --no-cpu --no-exact --no-secondary --no-strong --no-power "$@")
 run trace --kernel-trace --stats
 args=("${args_pmc[@]}")
 run sq1 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU

@@ -23,8 +23,10 @@ c = counters
 # the bench line of the traced pass tells the pool size and the launch geometry
 bench_line = {}
 for line in (REPO / 'gpurun_out' / f'prof_{tag}' / 'trace.log').read_text().splitlines():
-    if line.startswith('{"metric"'):
-        bench_line = json.loads(line)
+    if line.startswith('{"metric"'):          # stderr carries the full record before stdout's short line: the one with the launch text
+        cand = json.loads(line)
+        if 'launch' in cand.get('config', {}) or not bench_line:
+            bench_line = cand
 pool = bench_line.get('config', {}).get('pool_signals_per_gpu', 128)
 launch = bench_line.get('config', {}).get('launch', '')
 out['bench_line_of_traced_pass'] = {k: bench_line.get(k) for k in ('value', 'ms_per_step', 'steps', 'warmup_actual')}
