@@ -212,7 +212,7 @@ def cpu_baseline(budget_s: float) -> dict:
             'best_value': round(x.size / best / 1e6, 3)}
 
 
-def device_rate(torch, table, shape, mode, *, min_ms=30.0, buffers=1, taps=None, exact_pool=False):
+def device_rate(torch, table, shape, mode, *, min_ms=30.0, buffers=1, taps=None, exact_pool=False, power=None):
     """Kernel milliseconds per launch of `table` over a resident (batch, n, C) pool (HIP events on the
     launch stream, >= min_ms timed after a clock-settling warm-up).  `buffers` > 1 rotates distinct
     pools so that small shapes still stream from HBM, not from the 256 MiB Infinity Cache."""
@@ -246,7 +246,18 @@ def device_rate(torch, table, shape, mode, *, min_ms=30.0, buffers=1, taps=None,
         iters *= 2
     per = ms / iters
     bytes_per_launch = ALGO_BYTES_PER_SAMPLE * batch * n * c
-    rec = {'kernel_ms': round(per, 4), 'achieved_GBs': round(bytes_per_launch / (per * 1e-3) / 1e9, 1),
+    board = None
+    if power is not None and power.files:
+        # 0.6 s more of the same launches, not timed: the board's power figure is a slow average (medians of the last 0.3 s)
+        s0, k = time.perf_counter(), 0
+        while time.perf_counter() - s0 < 0.6:
+            launch(k); k += 1
+            if k % 8 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        s1 = time.perf_counter()
+        board = power.window(s0 + (s1 - s0) / 2, s1)
+    rec = {'kernel_ms': round(per, 4), 'board': board, 'achieved_GBs': round(bytes_per_launch / (per * 1e-3) / 1e9, 1),
            'frac_of_8TBs': round(bytes_per_launch / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
            'Msamples_s': round(batch * n * c / (per * 1e-3) / 1e6, 1), 'launches_timed': iters,
            'launch': table.describe(batch, n, c, mode)}
@@ -287,7 +298,7 @@ def oracle_parity(x_dev, y_dev, taps, mode, exact_mode=0):
     return float(np.max(np.abs(got.astype(np.float64) - want)) / np.max(np.abs(want)))
 
 
-def secondary_configs(torch, vnd, _native, ctx, mode) -> dict:
+def secondary_configs(torch, vnd, _native, ctx, mode, power=None) -> dict:
     """The other BASELINE configs on one GPU (rates only; their parity is tests/test_gpu_*.py)."""
     from vndecorrelate_amd.taps import function_path_arrays
     out = {}
@@ -321,7 +332,7 @@ def secondary_configs(torch, vnd, _native, ctx, mode) -> dict:
     for name, kw, shape, buffers, what, limit in specs:
         try:
             t, taps = table_of(**kw)
-            r = device_rate(torch, t, shape, mode, buffers=buffers, taps=taps, exact_pool=True)
+            r = device_rate(torch, t, shape, mode, buffers=buffers, taps=taps, exact_pool=True, power=power if name in ('cfg3', 'cfg5') else None)
             assert r['parity_vs_oracle_of_peak'] <= 1e-6, f"{name}: timed output off by {r['parity_vs_oracle_of_peak']:.2e} of peak"
             r.update({'workload': what, 'binding_limit': limit})
             if mode != vnd.MODE_EXACT and name != 'cfg3_kappa1':
@@ -758,6 +769,8 @@ def compact(d: dict) -> dict:
         c[short + '_frac'] = rec.get('frac_of_8TBs')
         if short == 'cfg3':
             c['cfg3_fp32_frac'] = rec.get('frac_of_fp32_vector_peak')
+        if rec.get('board'):
+            c[short + '_W'], c[short + '_MHz'] = rec['board']['power_W'], rec['board']['sclk_MHz']
         if 'exact_mode' in rec:
             c[short + '_exact_frac'] = dig(rec, 'exact_mode', 'frac_of_8TBs')
         if rec.get('parity_max_over_pool') is not None:
@@ -1103,17 +1116,17 @@ def main():
                          'power': power_info,
                          'algorithmic_bytes_per_launch': ALGO_BYTES_PER_SAMPLE * samples_per_step},
         }
-        if power is not None:
-            power.close()
         if strong is not None:
             detail['cfg4_strong'] = strong
         if world == 1 and not args.no_secondary:
-            detail['secondary'] = secondary_configs(torch, vnd, _native, ctx, mode)
+            detail['secondary'] = secondary_configs(torch, vnd, _native, ctx, mode, power)
             try:
                 detail['end_to_end'] = end_to_end(torch, vnd, mode)
             except Exception as exc:                    # as above: never at the headline's expense
                 detail['end_to_end'] = {'error': repr(exc)}
             detail['next_rows'] = next_rows(torch, vnd, _native)
+        if power is not None:
+            power.close()
         if world == 1 and not args.no_cpu:
             detail['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
         # the long record: a side file (and gpurun_out/, which travels back from a GPU box) and stderr; the short line: stdout, last
