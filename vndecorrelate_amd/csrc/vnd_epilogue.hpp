@@ -664,6 +664,21 @@ __device__ __forceinline__ void par_stage(const RArgs &a, int64_t b, int blk, fl
     }
 }
 
+// Which (block, stream-or-pair) a workgroup of the sum / tally kernels takes.  Stereo: blockIdx.x = block, blockIdx.y = stream.  Wider
+// signals: the P channel pairs of a block read the SAME cache lines (8 bytes each of every C-channel frame), so they must meet in one L2:
+// blockIdx.y = stream, and blockIdx.x runs XCD by XCD (blocks b, b + 8, ... share an L2; MI355X_MICROARCH.md) with the pair fastest -
+// the P workgroups of a block are neighbours in their XCD's queue, and the lines come from HBM once, not P times.  grid.x =
+// ceil(nblocks / 8) * 8 * P; returns false for the padding.
+__device__ __forceinline__ bool par_unit(const RArgs &a, int *blk, int64_t *b)
+{
+    if (a.pairs <= 1) { *blk = (int)blockIdx.x; *b = blockIdx.y; return true; }
+    const unsigned id = blockIdx.x, xcd = id & 7u, j = id >> 3;
+    const unsigned pair = j % (unsigned)a.pairs;
+    *blk = (int)((j / (unsigned)a.pairs) * 8u + xcd);
+    *b = (int64_t)blockIdx.y * a.pairs + pair;
+    return *blk < a.nblocks;
+}
+
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
 #pragma unroll
@@ -676,8 +691,9 @@ __global__ __launch_bounds__(kParThreads) void rms_par_sum_kernel(const RArgs a)
 {
     __shared__ __attribute__((aligned(16))) float sq[4 * kParFrames];
     const int tid = threadIdx.x, lane = tid & 63, chain = tid >> 6;
-    const int blk = blockIdx.x;
-    const int64_t b = blockIdx.y;
+    int blk;
+    int64_t b;
+    if (!par_unit(a, &blk, &b)) return;
     par_stage<MONO>(a, b, blk, sq, tid);
     __syncthreads();
     const float *row = sq + chain * kParFrames;
@@ -741,8 +757,10 @@ __global__ __launch_bounds__(kParThreads) void rms_par_tally_kernel(const RArgs 
 {
     __shared__ __attribute__((aligned(16))) float sq[4 * kParFrames];
     const int tid = threadIdx.x, lane = tid & 63, chain = tid >> 6;
-    const int64_t b = blockIdx.y;
-    if ((int)blockIdx.x == a.nblocks - 1) {
+    int unit;
+    int64_t b;
+    if (!par_unit(a, &unit, &b)) return;
+    if (unit == a.nblocks - 1) {
         // the extra workgroup: the chains' START - block 0 by the recurrence itself, from +0 (its first groups
         // are all ties and binade crossings) - runs beside the tallies of the other blocks instead of holding
         // up the block sums that they wait for
@@ -752,7 +770,7 @@ __global__ __launch_bounds__(kParThreads) void rms_par_tally_kernel(const RArgs 
         if (lane == 0) a.first[b * 4 + chain] = acc;
         return;
     }
-    const int blk = blockIdx.x + 1;
+    const int blk = unit + 1;
     par_stage<MONO>(a, b, blk, sq, tid);
     // where the running sum stands when this block starts, to within float64 rounding: only its
     // binade matters, and a wrong guess merely sends the block down the sequential path

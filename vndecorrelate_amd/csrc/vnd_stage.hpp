@@ -166,7 +166,9 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
         e.rows = 1;
         e.exact_rms = 1;
         e.normalize = 1;
-        const dim3 pgrid((unsigned)r.nblocks, (unsigned)(batch * pairs)), tgrid((unsigned)r.nblocks, (unsigned)(batch * pairs));     // tally: blocks 1.., plus block 0's chain
+        // (wider signals: the pairs of a block side by side in one XCD's queue - par_unit)
+        const unsigned gx = pairs == 1 ? (unsigned)r.nblocks : (unsigned)(((r.nblocks + 7) / 8) * 8 * pairs);
+        const dim3 pgrid(gx, (unsigned)batch), tgrid(gx, (unsigned)batch);     // tally: blocks 1.., plus block 0's chain
         const dim3 sgrid((unsigned)(batch * pairs * 4));
         if (Cx == 1) {
             if (!blk_done) hipLaunchKernelGGL(rms_par_sum_kernel<true>, pgrid, dim3(kParThreads), 0, stream, r);
