@@ -898,8 +898,9 @@ def test_eight_channel_decorrelate_fast_stage_through_the_octet_kernels_sums(vnd
         assert err <= 5e-4, (b, err)
 
 
+@pytest.mark.parametrize('frames', [200000 + 77, 200000 + 78])      # odd: streams only 8-byte aligned (a pair per workgroup); even: 16-byte accesses (a quad per workgroup where C % 4 == 0)
 @pytest.mark.parametrize('channels', [4, 6, 8])
-def test_exact_rms_sums_of_wider_signals_block_parallel_equal_the_per_stream_kernel(vnd, channels):
+def test_exact_rms_sums_of_wider_signals_block_parallel_equal_the_per_stream_kernel(vnd, channels, frames):
     """The reference-order (NumPy: sequential float32) sums of squares of the exact stage on signals of more than two channels run
     block-parallel, channel pair by channel pair (round 5; before, one workgroup per stream: 8.7 ms for cfg5's pool of 16).  Same
     bits as the per-stream kernel (variant bit 19 keeps it) on every stream of a ragged pool, and as the oracle's whole stage -
@@ -910,7 +911,7 @@ def test_exact_rms_sums_of_wider_signals_block_parallel_equal_the_per_stream_ker
     vn = vnd.VelvetNoise(**kw)
     table = vn._device_table()
     ctx = _native.default_context()
-    pool, n = 5, 200000 + 77
+    pool, n = 5, frames
     rng = np.random.default_rng(channels)
     host = rng.uniform(-1, 1, (pool, n, channels)).astype(np.float32)
     host[1] = (np.round(host[1] * 20000) / 32768.0).astype(np.float32)           # 16-bit audio: squares that tie in float32

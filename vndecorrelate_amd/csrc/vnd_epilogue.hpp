@@ -669,14 +669,40 @@ __device__ __forceinline__ void par_stage(const RArgs &a, int64_t b, int blk, fl
 // blockIdx.y = stream, and blockIdx.x runs XCD by XCD (blocks b, b + 8, ... share an L2; MI355X_MICROARCH.md) with the pair fastest -
 // the P workgroups of a block are neighbours in their XCD's queue, and the lines come from HBM once, not P times.  grid.x =
 // ceil(nblocks / 8) * 8 * P; returns false for the padding.
+// PW: channel pairs per workgroup (2: a channel QUAD - 16 bytes of every frame per access, par_stage_quad; *b = its first pair).
+template <int PW = 1>
 __device__ __forceinline__ bool par_unit(const RArgs &a, int *blk, int64_t *b)
 {
     if (a.pairs <= 1) { *blk = (int)blockIdx.x; *b = blockIdx.y; return true; }
+    const unsigned per_block = (unsigned)a.pairs / PW;
     const unsigned id = blockIdx.x, xcd = id & 7u, j = id >> 3;
-    const unsigned pair = j % (unsigned)a.pairs;
-    *blk = (int)((j / (unsigned)a.pairs) * 8u + xcd);
-    *b = (int64_t)blockIdx.y * a.pairs + pair;
+    const unsigned unit = j % per_block;
+    *blk = (int)((j / per_block) * 8u + xcd);
+    *b = (int64_t)blockIdx.y * a.pairs + unit * PW;
     return *blk < a.nblocks;
+}
+
+// a channel QUAD of a wider signal (pairs b0 and b0 + 1 of its stream): whole 16-byte accesses, 512 threads x 4 frames, squares into
+// sq[8][2048]: rows 0-3 the first pair's chains (x ch0, x ch1, y ch0, y ch1), rows 4-7 the second pair's
+__device__ __forceinline__ void par_stage_quad(const RArgs &a, int64_t b0, int blk, float *sq, int tid)
+{
+    const int64_t f0 = (int64_t)blk * kParFrames;
+    int64_t xb, yb;
+    const float *xs = par_pair_base(a, a.x, b0, f0, 0, &xb), *ys = par_pair_base(a, a.y, b0, f0, 0, &yb);
+    const v4i rx = make_rsrc(xs, xb), ry = make_rsrc(ys, yb);
+    const int fb = a.C * 4, fr = 4 * tid;
+    v4f xq[4], yq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { xq[k] = buf_load4(rx, (fr + k) * fb, 0, 0); yq[k] = buf_load4(ry, (fr + k) * fb, 0, 0); }
+    float4 *dst = (float4 *)(sq + fr);
+    dst[0 * kParFrames / 4] = make_float4(xq[0].x * xq[0].x, xq[1].x * xq[1].x, xq[2].x * xq[2].x, xq[3].x * xq[3].x);
+    dst[1 * kParFrames / 4] = make_float4(xq[0].y * xq[0].y, xq[1].y * xq[1].y, xq[2].y * xq[2].y, xq[3].y * xq[3].y);
+    dst[2 * kParFrames / 4] = make_float4(yq[0].x * yq[0].x, yq[1].x * yq[1].x, yq[2].x * yq[2].x, yq[3].x * yq[3].x);
+    dst[3 * kParFrames / 4] = make_float4(yq[0].y * yq[0].y, yq[1].y * yq[1].y, yq[2].y * yq[2].y, yq[3].y * yq[3].y);
+    dst[4 * kParFrames / 4] = make_float4(xq[0].z * xq[0].z, xq[1].z * xq[1].z, xq[2].z * xq[2].z, xq[3].z * xq[3].z);
+    dst[5 * kParFrames / 4] = make_float4(xq[0].w * xq[0].w, xq[1].w * xq[1].w, xq[2].w * xq[2].w, xq[3].w * xq[3].w);
+    dst[6 * kParFrames / 4] = make_float4(yq[0].z * yq[0].z, yq[1].z * yq[1].z, yq[2].z * yq[2].z, yq[3].z * yq[3].z);
+    dst[7 * kParFrames / 4] = make_float4(yq[0].w * yq[0].w, yq[1].w * yq[1].w, yq[2].w * yq[2].w, yq[3].w * yq[3].w);
 }
 
 __device__ __forceinline__ double wave_sum_f64(double v)
@@ -686,17 +712,19 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return v;
 }
 
-template <bool MONO>
-__global__ __launch_bounds__(kParThreads) void rms_par_sum_kernel(const RArgs a)
+template <bool MONO, int PW = 1>
+__global__ __launch_bounds__(kParThreads * PW) void rms_par_sum_kernel(const RArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float sq[4 * kParFrames];
-    const int tid = threadIdx.x, lane = tid & 63, chain = tid >> 6;
+    __shared__ __attribute__((aligned(16))) float sq[PW * 4 * kParFrames];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, chain = wave & 3;
     int blk;
     int64_t b;
-    if (!par_unit(a, &blk, &b)) return;
-    par_stage<MONO>(a, b, blk, sq, tid);
+    if (!par_unit<PW>(a, &blk, &b)) return;
+    if constexpr (PW == 2) par_stage_quad(a, b, blk, sq, tid);
+    else par_stage<MONO>(a, b, blk, sq, tid);
+    b += wave >> 2;                                        // this wave's pair
     __syncthreads();
-    const float *row = sq + chain * kParFrames;
+    const float *row = sq + wave * kParFrames;
     double s = 0.0;
 #pragma unroll
     for (int g = 0; g < kParFrames; g += 256) {
@@ -752,26 +780,30 @@ __device__ __forceinline__ uint32_t par_tally_groups(const float *row, int g0, i
     return q;
 }
 
-template <bool MONO>
-__global__ __launch_bounds__(kParThreads) void rms_par_tally_kernel(const RArgs a)
+template <bool MONO, int PW = 1>
+__global__ __launch_bounds__(kParThreads * PW) void rms_par_tally_kernel(const RArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float sq[4 * kParFrames];
-    const int tid = threadIdx.x, lane = tid & 63, chain = tid >> 6;
+    __shared__ __attribute__((aligned(16))) float sq[PW * 4 * kParFrames];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, chain = wave & 3;
     int unit;
     int64_t b;
-    if (!par_unit(a, &unit, &b)) return;
+    if (!par_unit<PW>(a, &unit, &b)) return;
+    const int64_t b0 = b;
+    b += wave >> 2;                                        // this wave's pair
     if (unit == a.nblocks - 1) {
         // the extra workgroup: the chains' START - block 0 by the recurrence itself, from +0 (its first groups
         // are all ties and binade crossings) - runs beside the tallies of the other blocks instead of holding
         // up the block sums that they wait for
-        par_stage<MONO>(a, b, 0, sq, tid);
+        if constexpr (PW == 2) par_stage_quad(a, b0, 0, sq, tid);
+        else par_stage<MONO>(a, b, 0, sq, tid);
         __syncthreads();
-        const float acc = seq_sum_block<kParFrames, true>(sq + chain * kParFrames, 0.0f, lane);
+        const float acc = seq_sum_block<kParFrames, true>(sq + wave * kParFrames, 0.0f, lane);
         if (lane == 0) a.first[b * 4 + chain] = acc;
         return;
     }
     const int blk = unit + 1;
-    par_stage<MONO>(a, b, blk, sq, tid);
+    if constexpr (PW == 2) par_stage_quad(a, b0, blk, sq, tid);
+    else par_stage<MONO>(a, b, blk, sq, tid);
     // where the running sum stands when this block starts, to within float64 rounding: only its
     // binade matters, and a wrong guess merely sends the block down the sequential path
     const double *sums = a.blk_sum + (b * 4 + chain) * a.nblocks;
@@ -784,7 +816,7 @@ __global__ __launch_bounds__(kParThreads) void rms_par_tally_kernel(const RArgs 
     }
     const int eb = (int)(__float_as_uint((float)pre) >> 23);
     __syncthreads();
-    const float *row = sq + chain * kParFrames;
+    const float *row = sq + wave * kParFrames;
     // group sums (float64) locate the group g* in which the sum is expected to reach the next power of two
     const double next = (double)__uint_as_float((uint32_t)min(eb + 1, 254) << 23);       // 2^(e + 1 - 127)
     int gstar = kParGroups;

@@ -167,7 +167,9 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
         e.exact_rms = 1;
         e.normalize = 1;
         // (wider signals: the pairs of a block side by side in one XCD's queue - par_unit)
-        const unsigned gx = pairs == 1 ? (unsigned)r.nblocks : (unsigned)(((r.nblocks + 7) / 8) * 8 * pairs);
+        // 4k channels with 16-byte-aligned streams: a channel QUAD per workgroup (512 threads, whole 16-byte accesses)
+        const int pw = (pairs > 1 && pairs % 2 == 0 && r.wide) ? 2 : 1;
+        const unsigned gx = pairs == 1 ? (unsigned)r.nblocks : (unsigned)(((r.nblocks + 7) / 8) * 8 * (pairs / pw));
         const dim3 pgrid(gx, (unsigned)batch), tgrid(gx, (unsigned)batch);     // tally: blocks 1.., plus block 0's chain
         const dim3 sgrid((unsigned)(batch * pairs * 4));
         if (Cx == 1) {
@@ -175,6 +177,11 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
             if (r.prefixed) hipLaunchKernelGGL(rms_par_prefix_kernel, dim3((unsigned)(batch * 4)), dim3(kParThreads), 0, stream, r);
             hipLaunchKernelGGL(rms_par_tally_kernel<true>, tgrid, dim3(kParThreads), 0, stream, r);
             hipLaunchKernelGGL(rms_par_stitch_kernel<true>, sgrid, dim3(64), 0, stream, r);
+        } else if (pw == 2) {
+            hipLaunchKernelGGL((rms_par_sum_kernel<false, 2>), pgrid, dim3(2 * kParThreads), 0, stream, r);
+            if (r.prefixed) hipLaunchKernelGGL(rms_par_prefix_kernel, dim3((unsigned)(batch * pairs * 4)), dim3(kParThreads), 0, stream, r);
+            hipLaunchKernelGGL((rms_par_tally_kernel<false, 2>), tgrid, dim3(2 * kParThreads), 0, stream, r);
+            hipLaunchKernelGGL(rms_par_stitch_kernel<false>, sgrid, dim3(64), 0, stream, r);
         } else {
             if (!blk_done) hipLaunchKernelGGL(rms_par_sum_kernel<false>, pgrid, dim3(kParThreads), 0, stream, r);
             if (r.prefixed) hipLaunchKernelGGL(rms_par_prefix_kernel, dim3((unsigned)(batch * pairs * 4)), dim3(kParThreads), 0, stream, r);
