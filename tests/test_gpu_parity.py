@@ -896,6 +896,13 @@ def test_eight_channel_decorrelate_fast_stage_through_the_octet_kernels_sums(vnd
         want = O.decorrelate(xs[b].cpu().numpy(), **kw)
         err = float(np.max(np.abs(ys[b].cpu().numpy().astype(np.float64) - want)) / np.max(np.abs(want)))
         assert err <= 5e-4, (b, err)
+    # ... and the exact stage on the same pool: the octet kernel's store phase leaves the block sums, the tally and stitch follow - NumPy's bits
+    assert 'pieces=channel-octets' in table.describe(pool, n, 8, vnd.MODE_EXACT)
+    table.decorrelate_device(xs.data_ptr(), ys.data_ptr(), pool, n, 8, mode=vnd.MODE_EXACT, ms_encode=False, width=None, normalize=1,
+                             workspace_ptr=ws.data_ptr(), workspace_bytes=ws_bytes, stream=st)
+    torch.cuda.synchronize()
+    for b in (0, pool - 1):
+        assert np.array_equal(ys[b].cpu().numpy(), O.decorrelate(xs[b].cpu().numpy(), **kw)), b
 
 
 @pytest.mark.parametrize('frames', [200000 + 77, 200000 + 78])      # odd: streams only 8-byte aligned (a pair per workgroup); even: 16-byte accesses (a quad per workgroup where C % 4 == 0)
@@ -921,7 +928,8 @@ def test_exact_rms_sums_of_wider_signals_block_parallel_equal_the_per_stream_ker
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device='cuda')
     st = torch.cuda.current_stream().cuda_stream
     out = {}
-    for name, variant in (('block_parallel', -1), ('per_stream', 1 << 19)):
+    # (forced: the per-table quad / octet kernel takes the small launch - for 4k channels its store phase then leaves the block sums)
+    for name, variant in (('block_parallel', -1), ('per_stream', 1 << 19), ('per_table_kernel', 1 << 23)):
         ctx.set_variant(variant)
         try:
             y = torch.empty_like(xs)
@@ -932,5 +940,6 @@ def test_exact_rms_sums_of_wider_signals_block_parallel_equal_the_per_stream_ker
         finally:
             ctx.set_variant(-1)
     assert np.array_equal(out['block_parallel'], out['per_stream'])
+    assert np.array_equal(out['per_table_kernel'], out['per_stream'])
     for b in (1, 2):
         assert np.array_equal(out['block_parallel'][b], O.decorrelate(host[b], **kw)), b

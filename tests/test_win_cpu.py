@@ -435,5 +435,16 @@ def test_quads_and_octets_leave_the_normalisers_sums_in_the_store_phase(native, 
     assert ops['plain'].count('v_add_f64') == 0 and ops['epi'].count('v_add_f64') >= spans * 12          # 2 sums x 6 butterfly steps
     assert ops['epi'].count('ds_bpermute_b32') == spans * 24
     assert ops['epi'].count('ds_read_b128') - ops['plain'].count('ds_read_b128') == spans * (M // 4)   # the lane's own input run
-    # the exact mode has no such build: its sums follow NumPy's order (epilogue_rms_seq_kernel)
-    assert _macro(native.window_kernel_source(offs, idx, w, 0, M, nt), 'VW_EPI') == 0
+    # the exact mode's build leaves the same two sums per (tile, channel wave) - there they are the per-block predictions the
+    # block-parallel NumPy-order sums (rms_par_*) start from, instead of a pass of their own over x and y
+    exact = native.window_kernel_source(offs, idx, w, 0, M, nt)
+    assert _macro(exact, 'VW_EPI') == 1 and _macro(exact, 'VW_EXACT') == 1
+    f = tmp_path / 'exact_epi.hip'
+    f.write_text(exact)
+    out = tmp_path / 'exact_epi.s'
+    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '--cuda-device-only',
+                        '-include', 'hip/hip_runtime.h', '-S', str(f), '-o', str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = out.read_text()
+    assert re.search(r'ScratchSize: 0\b', text), 'the exact quad / octet kernel with block sums must not spill'
+    assert len(re.findall(r'^\s+v_add_f64', text, re.M)) >= spans * 12

@@ -171,7 +171,7 @@ vnd_status vnd_window_kernel_source(int32_t C, const int32_t *tap_offsets, const
     cfg.bc = bc ? 1 : 0;
     // (VND_WIN_SOURCE_EPI=1: with the decorrelate stage's steps in the store phase - stereo: pointwise steps and block sums; quads /
     //  octets, fast mode: the normaliser's sums)
-    cfg.epi = (spec_env("VND_WIN_SOURCE_EPI", 0) != 0 && !bc && !split && (C == 2 || (quad && !cfg.exact))) ? 1 : 0;
+    cfg.epi = (spec_env("VND_WIN_SOURCE_EPI", 0) != 0 && !bc && !split && (C == 2 || quad)) ? 1 : 0;
     if (lds_bytes_per_tile || fmas_per_tile) {
         size_t lb = 0, fm = 0;
         if (cfg.exact) win_traffic_exact(t, frames_per_lane, &lb, &fm);

@@ -339,8 +339,10 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     // (... with the normaliser's sums too where the caller offers room for per-block sums: the window form's store phase leaves them)
     const bool pointwise2 = epi != nullptr && (!epi->normalize || epi->blk_sum != nullptr) && epi->sink == nullptr && C == 2;
     // ... and on 4k channels the normaliser's sums alone (LR mode: no pointwise step exists there), in the quad / octet form's store phase
+    // (fast mode: rows of sums for the fused stage; exact mode: the per-block predictions of the block-parallel NumPy-order sums)
     const bool sums_q = epi != nullptr && epi->sink == nullptr && C % 4 == 0 && Cx == C && !epi->ms_encode && !epi->use_width &&
-                        epi->normalize && epi->blk_sum != nullptr && epi->rows_major && epi->rows != nullptr && mode == VND_MODE_FAST;
+                        epi->blk_sum != nullptr && epi->rows != nullptr &&
+                        ((mode == VND_MODE_FAST && epi->normalize && epi->rows_major) || (mode == VND_MODE_EXACT && !epi->rows_major));
     const bool pointwise = pointwise2 || sums_q;
     // fan-out: a mono input through a stereo table is in scope (one LDS plane, VS_BC); wider fan-outs are not
     const bool bc = Cx == 1 && C == 2;
@@ -625,6 +627,12 @@ static vnd_status launch_spec(vnd_ctx *ctx, const vnd_taps *t, const SpecPlan &p
         if (epi->blk_sum != nullptr && p.cfg.win_q && epi->rows_major && epi->rows != nullptr) {
             a.epi_blk_sum = epi->blk_sum; a.epi_rows_major = 1;
             a.epi_nblocks = p.tiles_total * std::max(1, p.cfg.nt / 64 / (4 * p.cfg.win_q));
+            *epi->rows = a.epi_nblocks;
+        }
+        // ... or, exact mode, the block sums of rms_par_*: only when a channel wave's tile is exactly one of their 2048-frame blocks
+        if (epi->blk_sum != nullptr && p.cfg.win_q && !epi->rows_major && epi->rows != nullptr &&
+            p.cfg.tile() == kParFrames && p.cfg.nt / 64 == 4 * p.cfg.win_q && p.tiles_total == epi->nblocks) {
+            a.epi_blk_sum = epi->blk_sum; a.epi_rows_major = 0; a.epi_nblocks = epi->nblocks;
             *epi->rows = a.epi_nblocks;
         }
     }

@@ -102,7 +102,7 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
     // 4k channels, fast mode, the normaliser alone (LR mode - cfg5 through the class API, decorrelation.py:433-440): the quad / octet
     // kernel's store phase leaves the sums of squares on its way (x still in the ring, y in registers), one streaming pass scales:
     // 16 bytes per sample instead of 24.  Where that kernel does not take the launch nothing has run and the passes below do.
-    bool q_done = false;
+    bool q_done = false, q_blk_done = false;
     if (mode == VND_MODE_FAST && normalize && !want_seq && !ms_encode && !use_width && C % 4 == 0 && Cx == C &&
         ctx->variant_nofuse == 0 && spec_env("VND_EPI_BLOCK_SUMS", 1) != 0) {
         int rows_q = 0;
@@ -147,7 +147,20 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
             st = launch(ctx, t, x, y, batch, n, C, mode, stream, &f, Cx);
             e.ms_encode = e.use_width = 0;                 // done
         } else {
-            st = launch(ctx, t, x, y, batch, n, C, mode, stream, nullptr, Cx);
+            // 4k channels, exact mode: the quad / octet kernel's store phase leaves the per-block sums of squares the block-parallel
+            // NumPy-order sums start from (as the stereo window form does) - when that kernel takes the launch
+            bool launched_q = false;
+            if (par_ok && C > 2 && C % 4 == 0 && Cx == C && normalize && mode == VND_MODE_EXACT && batch < 256 &&
+                ctx->variant_nofuse == 0 && spec_env("VND_EPI_BLOCK_SUMS", 1) != 0) {
+                int rows_q = 0;
+                EpiFuse f{nullptr, 0, 0, 0, e.w_mid, e.w_side};
+                f.path = &conv_path; f.blk_sum = r.blk_sum; f.nblocks = r.nblocks; f.rows = &rows_q; f.spec_only = true;
+                st = launch(ctx, t, x, y, batch, n, C, mode, stream, &f, Cx);
+                if (st != VND_OK) return st;
+                launched_q = conv_path != 0;
+                q_blk_done = conv_path == 1 && rows_q == r.nblocks;
+            }
+            if (!launched_q) st = launch(ctx, t, x, y, batch, n, C, mode, stream, nullptr, Cx);
         }
         if (st != VND_OK || !any) return st;
         // reference-order sums (always in VND_MODE_EXACT, C >= 2: the bit-identical stage); C == 1 is
@@ -159,7 +172,7 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
             hipLaunchKernelGGL(epilogue_pointwise_kernel, grid, dim3(kEpiThreads), 0, stream, e);
         sums_pending = seq;
     }
-    const bool blk_done = conv_path == 1 && want_blk;
+    const bool blk_done = (conv_path == 1 && want_blk) || q_blk_done;
     // (wider signals: the per-stream kernel fills the chip from 256 streams on, as for stereo; below that the pairs' blocks do)
     const bool par_sums = sums_pending && par_ok && (batch <= 64 || par_forced || blk_done || (C > 2 && batch < 256));
     if (par_sums) {
@@ -178,7 +191,7 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
             hipLaunchKernelGGL(rms_par_tally_kernel<true>, tgrid, dim3(kParThreads), 0, stream, r);
             hipLaunchKernelGGL(rms_par_stitch_kernel<true>, sgrid, dim3(64), 0, stream, r);
         } else if (pw == 2) {
-            hipLaunchKernelGGL((rms_par_sum_kernel<false, 2>), pgrid, dim3(2 * kParThreads), 0, stream, r);
+            if (!blk_done) hipLaunchKernelGGL((rms_par_sum_kernel<false, 2>), pgrid, dim3(2 * kParThreads), 0, stream, r);
             if (r.prefixed) hipLaunchKernelGGL(rms_par_prefix_kernel, dim3((unsigned)(batch * pairs * 4)), dim3(kParThreads), 0, stream, r);
             hipLaunchKernelGGL((rms_par_tally_kernel<false, 2>), tgrid, dim3(2 * kParThreads), 0, stream, r);
             hipLaunchKernelGGL(rms_par_stitch_kernel<false>, sgrid, dim3(64), 0, stream, r);
