@@ -111,6 +111,7 @@ POOLS = {
     # (not bench shapes: the quad form where the quad IS the frame - non-temporal stores - and two octets per frame)
     'four_channels': ('g96k_k64_c8', 32, 480000, 4, 1e-6),
     'sixteen_channels': ('g96k_k64_c8', 8, 480000, 16, 1e-6),
+    'six_channels': ('g96k_k64_c8', 32, 480000, 6, 1e-6),            # 4k + 2: two quads, channels 0-3 and 2-5
 }
 
 
@@ -132,7 +133,7 @@ def test_pools_at_bench_shapes_match_the_oracle(env, golden, name):
     assert exact_text.startswith('conv_spec_exact'), exact_text
     if C == 2:
         assert fast_text.startswith('conv_spec_window'), fast_text
-    if C % 4 == 0:
+    if C % 4 == 0 or C >= 6:
         assert fast_text.startswith('conv_spec_window') and exact_text.startswith('conv_spec_exact_window'), (fast_text, exact_text)
         pieces = 'pieces=channel-octets' if C % 8 == 0 else 'pieces=channel-quads'
         assert pieces in fast_text and pieces in exact_text, (fast_text, exact_text)
@@ -291,7 +292,8 @@ def test_window_form_on_wider_signals(env, golden, monkeypatch, C, M, nt):
     table.close()
 
 
-@pytest.mark.parametrize('C,M,nt,Q', [(8, 32, 512, 2), (16, 32, 512, 2), (8, 16, 512, 2), (4, 32, 256, 1), (12, 32, 256, 1), (4, 16, 256, 1), (8, 32, 256, 1), (16, 16, 256, 1)])
+@pytest.mark.parametrize('C,M,nt,Q', [(8, 32, 512, 2), (16, 32, 512, 2), (8, 16, 512, 2), (4, 32, 256, 1), (12, 32, 256, 1), (4, 16, 256, 1), (8, 32, 256, 1), (16, 16, 256, 1),
+                                      (6, 32, 256, 1), (10, 32, 256, 1), (6, 16, 256, 1)])      # 4k + 2 channels: k quads and one more from channel C - 4 (overlapping in one pair)
 def test_window_form_on_channel_quads(env, golden, monkeypatch, C, M, nt, Q):
     """Signals of 4k interleaved channels: a workgroup takes a channel QUAD of a span - 16 bytes of every frame - or (Q = 2, signals
     of 8k channels) an OCTET: two neighbouring quads, 32 bytes of every frame, with 8 channels whole frames.  Its waves are split

@@ -448,3 +448,27 @@ def test_quads_and_octets_leave_the_normalisers_sums_in_the_store_phase(native, 
     text = out.read_text()
     assert re.search(r'ScratchSize: 0\b', text), 'the exact quad / octet kernel with block sums must not spill'
     assert len(re.findall(r'^\s+v_add_f64', text, re.M)) >= spans * 12
+
+
+def test_six_channels_ride_two_overlapping_quads(native, golden, tmp_path, monkeypatch):
+    """4k + 2 channels (6, 10, ...): the quad form with k full quads and one more that starts at channel C - 4 - two workgroups compute
+    and write the shared channel pair with the same bits, every access is still 16 bytes of a frame.  Generated source: two span
+    instantiations, the second one's tap functions are those of pairs 1 and 2; cross-compiled without spills."""
+    fir = np.ascontiguousarray(golden.fir('g96k_k64_c8')[:, :6])
+    offs, idx, w = _table(fir)
+    monkeypatch.setenv('VND_WIN_OCTET', '0')
+    for mode in (2, 0):
+        src = native.window_kernel_source(offs, idx, w, mode, 32, 256)
+        assert _macro(src, 'VW_Q') == 1 and _macro(src, 'VW_C') == 6
+        dispatch = src.split('#define VW_DISPATCH')[1].split('\n')[0]
+        assert dispatch.count('vw_span_qc<') == 2
+        body = src.split('vw_taps_of_channel(int pc')[1].split('#define VW_TAPS_OF_CHANNEL')[0]
+        second = body.split('QD == 1')[1]
+        assert 'vw_taps_1c0(' in second and 'vw_taps_2c1(' in second and 'vw_taps_c0(' not in second
+        f = tmp_path / f'k{mode}.hip'
+        f.write_text(src)
+        out = tmp_path / f'k{mode}.s'
+        r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '--cuda-device-only',
+                            '-include', 'hip/hip_runtime.h', '-S', str(f), '-o', str(out)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert re.search(r'ScratchSize: 0\b', out.read_text())

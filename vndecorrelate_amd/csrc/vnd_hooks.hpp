@@ -153,7 +153,7 @@ vnd_status vnd_window_kernel_source(int32_t C, const int32_t *tap_offsets, const
     // (tables of 4k channels: the quad / octet form, as the launches take it - VND_WIN_QUAD=0: channel pairs)
     bool quad = C % 8 == 0 && spec_env("VND_WIN_QUAD", 1) != 0 && spec_env("VND_WIN_OCTET", 1) != 0 &&
                 win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, 2);
-    quad = quad || (C % 4 == 0 && spec_env("VND_WIN_QUAD", 1) != 0 &&
+    quad = quad || ((C % 4 == 0 || (C % 4 == 2 && C >= 6)) && spec_env("VND_WIN_QUAD", 1) != 0 &&
                     win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, 1));
     const bool split = !quad && C == 2 && spec_env("VND_WIN_SPLIT", 0) != 0 &&
                        win_geometry(t, frames_per_lane, threads, spec_env("VND_WIN_G", 8), false, 160 * 1024, &g, 0, true);

@@ -391,7 +391,8 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     // signals of 4k channels: the window form on channel QUADS / OCTETS (VW_Q, vw_span_qc: a workgroup moves 16 / 32 bytes of every
     // frame, a wave per channel) - VND_WIN_QUAD=0 keeps the pair-read kernel (or, with VND_WIN_WIDE=1 / variant bits 5-7, the
     // window form on channel pairs)
-    const bool win_quad = C % 4 == 0 && Cx == C && (!pointwise || sums_q) && spec_env("VND_WIN_QUAD", 1) != 0;
+    // (4k + 2 channels - 6, 10, ... - ride the quad form too: k quads and one more from channel C - 4, overlapping in one pair)
+    const bool win_quad = (C % 4 == 0 || (C % 4 == 2 && C >= 6 && epi == nullptr)) && Cx == C && (!pointwise || sums_q) && spec_env("VND_WIN_QUAD", 1) != 0;
     // (a geometry whose build failed or spilled is remembered in the table's module map: skipped, the next best taken)
     const bool nt_big = batch * n * C * (int64_t)sizeof(float) >= ((int64_t)spec_env("VND_NT_MIN_MB", 64) << 20);
     auto nt_stores_of = [&](const SpecConfig &c) {
@@ -451,7 +452,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     const int64_t per_cu = p.cfg.win ? p.cfg.win_per_cu
                                      : std::min<int64_t>(std::min<int64_t>(16, 2048 / p.cfg.nt), (int64_t)(160 * 1024) / (int64_t)p.cfg.lds_bytes());
     const int64_t resident = (int64_t)cus * std::max<int64_t>(per_cu, 1);
-    const int64_t units = batch * (p.cfg.win_q ? C / (4 * p.cfg.win_q) : C / 2);      // (stream, channel pair) - or channel quad / octet
+    const int64_t units = batch * (p.cfg.win_q ? (C + 4 * p.cfg.win_q - 1) / (4 * p.cfg.win_q) : C / 2);      // (stream, channel pair) - or channel quad / octet
     // a workgroup needs a span long enough to amortise filling its ring: 8 tiles when there are 16 and more per resident
     // slot; with less, shorter spans (down to 2 tiles) so that the chip still fills - a lone 60 s stream then runs 1.1x
     // (fast) to 1.75x (exact, 128 taps) faster than through the generic kernels, tools/single_stream_try.py - and below

@@ -53,7 +53,8 @@ inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size
     if (split && (t.C != 2 || quad || nt % 128 != 0)) return false;            // a stereo table, whole waves per channel
     if (!(M == 16 || M == 32 || M == 64) || nt % 64 != 0 || nt < 64 || nt > 1024 || G < 1) return false;
     // the quad / octet form: whole channel quads, whole waves per channel, a lane of a 64-frame access inside one entry
-    if (quad && (quad > 2 || t.C % (4 * quad) != 0 || bc || nt % (256 * quad) != 0 || M * quad > 64 || M > 32)) return false;
+    // (4k + 2 channels ride quads too: the last quad starts at channel C - 4)
+    if (quad && (quad > 2 || (t.C % (4 * quad) != 0 && !(quad == 1 && t.C % 4 == 2 && t.C >= 6)) || bc || nt % (256 * quad) != 0 || M * quad > 64 || M > 32)) return false;
     // one lane's tap sum is straight-line code, M/2 packed instructions of 8 bytes per tap: beyond ~1000 taps per channel
     // pair it would be megabytes of code for hipRTC and the 64 KB instruction cache (cfg3's 256 taps: 33 KB) - such
     // tables keep the pair-read form
@@ -600,15 +601,17 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
             for (int ch = 0; ch < 2; ++ch) src += c.exact ? win_taps_function_exact(t, g, c.la, pg, ch) : win_taps_function(t, g, c.la, pg, ch);
         src += "template <int PG> __device__ void vw_taps_of(vw_lchar *const (&b)[2][VW_NBT], float (&o0)[VW_M], float (&o1)[VW_M]);      // (vw_span, vw_span_q: not instantiated)\n";
         src += "template <int QD> __device__ __forceinline__ void vw_taps_of_channel(int pc, vw_lchar *const (&b)[2][VW_NBT], float (&o)[VW_M])\n{\n";
-        for (int qd = 0; qd < t.C / nch; ++qd) {
+        const int nq = (t.C + nch - 1) / nch;                          // (4k + 2 channels, quads: the last one starts at channel C - 4)
+        for (int qd = 0; qd < nq; ++qd) {
+            const int pair0 = (t.C % nch != 0 && qd == nq - 1) ? (t.C - nch) / 2 : qd * nch / 2;
             spec_append(src, "    %sif constexpr (QD == %d) {\n        switch (pc) {\n", qd ? "else " : "", qd);
             for (int pc = 0; pc < nch; ++pc)
                 spec_append(src, "        %s %s(b, o, o); break;\n", pc + 1 < nch ? ("case " + std::to_string(pc) + ":").c_str() : "default:",
-                            win_taps_channel_name(qd * nch / 2 + pc / 2, pc & 1).c_str());
+                            win_taps_channel_name(pair0 + pc / 2, pc & 1).c_str());
             src += "        }\n    }\n";
         }
         src += "}\n#define VW_TAPS_OF_CHANNEL(pc) vw_taps_of_channel<QD>(pc, b, o);\n#define VW_DISPATCH(pg) switch (pg) {";
-        for (int qd = 0; qd < t.C / nch; ++qd) spec_append(src, " case %d: vw_span_qc<%d>(a, lds, stream, t_first, ntiles, flags, pace); break;", qd, qd);
+        for (int qd = 0; qd < nq; ++qd) spec_append(src, " case %d: vw_span_qc<%d>(a, lds, stream, t_first, ntiles, flags, pace); break;", qd, qd);
         src += " default: break; }\n";
     } else if (g.split) {
         for (int ch = 0; ch < 2; ++ch) src += c.exact ? win_taps_function_exact(t, g, c.la, 0, ch) : win_taps_function(t, g, c.la, 0, ch);
