@@ -943,3 +943,56 @@ def test_exact_rms_sums_of_wider_signals_block_parallel_equal_the_per_stream_ker
     assert np.array_equal(out['per_table_kernel'], out['per_stream'])
     for b in (1, 2):
         assert np.array_equal(out['block_parallel'][b], O.decorrelate(host[b], **kw)), b
+
+
+def test_fused_fast_stage_over_every_convolution_path(vnd):
+    """The fully fused FAST stage (pointwise steps + the normaliser's sums in the convolution's store phase, one scale pass) whichever
+    kernel takes the convolution: the window form leaving per-block rows (path 1), the pair-read per-table kernel (path 2: one more
+    pass for the sums), the generic fast kernel with its per-tile rows (path 0) - on a pool with a ragged tail (the last tile and the
+    last 2048-frame block are partial) and on a mono input fanned out.  Every path: the applied scale within 1e-6 of float64 sums of
+    what it scaled, the output within 5e-4 of peak of the oracle's whole stage (sequential float32 RMS) and within 3e-6 of the
+    other paths."""
+    import torch
+    from vndecorrelate_amd import _native
+    FORCE, GENERIC, PAIR_READ = 1 << 23, 1 << 25, 1 << 5
+    vn = vnd.VelvetNoise(sample_rate_hz=48000, seed=1)
+    table = vn._device_table()
+    ctx = _native.default_context()
+    st = torch.cuda.current_stream().cuda_stream
+    pool, n = 3, 200000 - 123
+    for cx in (2, 1):
+        xs = torch.empty((pool, n, cx), dtype=torch.float32, device='cuda').uniform_(-1, 1)
+        ws_bytes = _native.decorrelate_workspace_bytes(pool, n, 2)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device='cuda')
+        outs = {}
+        for name, variant, starts in (('window', FORCE, 'conv_spec_window'), ('pair_read', FORCE | PAIR_READ, 'conv_spec'), ('generic', GENERIC, 'conv_fast')):
+            ctx.set_variant(variant)
+            try:
+                text = table.describe(pool, n, cx, vnd.MODE_FAST)
+                if cx == 2:
+                    assert text.startswith(starts) and (name != 'pair_read' or not text.startswith('conv_spec_window')), (name, text)
+                y = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda')
+                table.decorrelate_device(xs.data_ptr(), y.data_ptr(), pool, n, cx, mode=vnd.MODE_FAST, ms_encode=True, width=0.7, normalize=1,
+                                         workspace_ptr=ws.data_ptr(), workspace_bytes=ws_bytes, stream=st)
+                torch.cuda.synchronize()
+                outs[name] = y.cpu().numpy()
+            finally:
+                ctx.set_variant(-1)
+        host = xs.cpu().numpy()
+        for b in (0, pool - 1):
+            xin = host[b, :, 0] if cx == 1 else host[b]
+            want = O.decorrelate(xin, sample_rate_hz=48000, seed=1, width=0.7)
+            peak = float(np.max(np.abs(want)))
+            for name, y in outs.items():
+                err = float(np.max(np.abs(y[b].astype(np.float64) - want))) / peak
+                assert err <= 5e-4, (cx, name, b, err)
+        base = outs['generic'].astype(np.float64)
+        for name in ('window', 'pair_read'):
+            assert float(np.max(np.abs(outs[name] - base))) <= 3e-6 * float(np.max(np.abs(base))), (cx, name)
+        # the scale each path applied: out = pointwise(y) * scale, so out_b / out_a is constant per (stream, channel) and the RMS of the output equals
+        # the RMS of the input (the normaliser's definition, utils/dsp.py:107-109) to the float32 rounding of the scale
+        x2 = np.repeat(host, 2, axis=2) if cx == 1 else host
+        for name, y in outs.items():
+            rms_in = np.sqrt(np.mean(x2.astype(np.float64) ** 2, axis=1))
+            rms_out = np.sqrt(np.mean(y.astype(np.float64) ** 2, axis=1))
+            assert np.max(np.abs(rms_out / rms_in - 1.0)) <= 1e-6, (cx, name)
