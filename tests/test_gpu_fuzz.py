@@ -24,7 +24,9 @@ CASES = [(2, 700, 40), (8, 700, 24), (3, 64, 20), (2, 2500, 40), (4, 1500, 30), 
          (2, 3000, 60), (4, 8, 6),
          # halos that eight (four) channels cannot round up to a multiple of 16 ring entries inside 160 KB: the ring is cut and its last
          # entries live in a tail (WinGeom::tail) - random taps at every offset the tile's last lanes find there
-         (8, 2719, 30), (8, 2650, 40), (4, 2719, 24), (16, 2719, 10)]
+         (8, 2719, 30), (8, 2650, 40), (4, 2719, 24), (16, 2719, 10),
+         # 4k + 2 channels: k quads and one more that starts at channel C - 4 (two workgroups write the shared pair with the same bits)
+         (6, 2719, 20), (10, 1500, 16), (14, 700, 10)]
 
 
 @pytest.mark.parametrize('seed', range(len(CASES)))
