@@ -60,6 +60,10 @@ vnd_status vnd_window_kernel_source(int32_t num_channels, const int32_t *tap_off
                                     int64_t *fmas_per_tile);
 /* Kernel variant override for tuning runs: -1 = automatic choice. */
 vnd_status vnd_set_variant(vnd_ctx *ctx, int32_t variant);
+/* Reads a tuning variable the way the launch planner does (VND_TUNING=1 sessions only; otherwise *value = fallback).  A name that
+ * is not in the library's registry (kTuningNames, csrc/vnd_spec.hpp) returns VND_ERR_INVALID with the name in vnd_last_error -
+ * the same report a launch gives when the LIBRARY reads such a name (until round 5 a debug-build abort()) - and leaves no trace. */
+vnd_status vnd_tuning_read(const char *name, int32_t fallback, int32_t *value);
 /* Diagnosis (VND_TUNING=1 with VND_WIN_STAMPS=<workgroups>): the window-form kernel that a launch of this shape
  * uses was built with phase stamps - wave 0 of its first workgroups leaves the 100 MHz wall clock at its phase
  * boundaries, 16 uint64 per workgroup ([0] start, [1] ring filled, then per tile: taps done, window dead, outputs

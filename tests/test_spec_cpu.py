@@ -190,3 +190,22 @@ def test_tuning_variables_exist_only_in_a_tuning_session(tmp_path):
         out[tuning] = json.loads(r.stdout.strip().splitlines()[-1])
     assert out[''] == {'VW_G': 8, 'VW_PRIO': 1}, out
     assert out['1'] == {'VW_G': 4, 'VW_PRIO': 3}, out
+
+
+def test_an_unregistered_tuning_name_is_an_error_code(monkeypatch):
+    """The library reads tuning variables only under VND_TUNING=1 (this tier sets it) and only names of its registry; one that is
+    not there used to abort() the host process in debug builds.  Now: VND_ERR_INVALID with the name in vnd_last_error, the
+    process lives, and the next call is clean (vnd_tuning_read is the planner's own read, exposed in the internal header)."""
+    import ctypes
+    from vndecorrelate_amd import _native
+    lib = _native.load_library()
+    value = ctypes.c_int32(-1)
+    monkeypatch.setenv('VND_WIN_PACE', '0')
+    assert lib.vnd_tuning_read(b'VND_WIN_PACE', 1, ctypes.byref(value)) == 0 and value.value == 0          # registered: read live
+    monkeypatch.delenv('VND_WIN_PACE')
+    assert lib.vnd_tuning_read(b'VND_WIN_PACE', 1, ctypes.byref(value)) == 0 and value.value == 1
+    monkeypatch.setenv('VND_NOT_A_TUNING_NAME', '7')
+    rc = lib.vnd_tuning_read(b'VND_NOT_A_TUNING_NAME', 3, ctypes.byref(value))
+    assert rc == 1 and value.value == 3                                                                  # VND_ERR_INVALID, the fallback
+    assert b'VND_NOT_A_TUNING_NAME' in lib.vnd_last_error() and b'kTuningNames' in lib.vnd_last_error()
+    assert lib.vnd_tuning_read(b'VND_WIN_PACE', 1, ctypes.byref(value)) == 0                              # nothing sticks

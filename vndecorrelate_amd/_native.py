@@ -131,6 +131,7 @@ INTERNAL_SIGNATURES = {
                                                 ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                                 ctypes.POINTER(ctypes.c_int64)]),
     'vnd_set_variant': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
+    'vnd_tuning_read': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
     'vnd_debug_read_stamps': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                              ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
 }

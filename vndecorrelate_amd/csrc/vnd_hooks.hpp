@@ -195,6 +195,15 @@ vnd_status vnd_code_object_private_bytes(const void *code, int64_t bytes, const 
     return VND_OK;
 }
 
+vnd_status vnd_tuning_read(const char *name, int32_t fallback, int32_t *value)
+{
+    if (!name || !value) return fail(VND_ERR_INVALID, "null name or value pointer");
+    *value = spec_env(name, fallback);
+    const vnd_status st = tuning_status();                 // (formats the name into vnd_last_error now: the pointer is the caller's)
+    spec_unregistered_name().store(nullptr);
+    return st;
+}
+
 vnd_status vnd_set_variant(vnd_ctx *ctx, int32_t variant)
 {
     if (!ctx) return fail(VND_ERR_INVALID, "null context");
