@@ -712,6 +712,28 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return v;
 }
 
+// the same total by DPP row shifts and row broadcasts (no LDS round trips: the __shfl_xor ladder is twelve ds_bpermute per sum), in
+// another order of additions - for sums that are PREDICTIONS (the tally kernel's group sums: every step they lead to is verified)
+__device__ __forceinline__ double wave_sum_f64_dpp(double v)
+{
+    auto shifted = [](double x, auto ctrl, auto rows) {
+        const unsigned long long bits = __builtin_bit_cast(unsigned long long, x);
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)bits, decltype(ctrl)::value, decltype(rows)::value, 0xf, true);
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(bits >> 32), decltype(ctrl)::value, decltype(rows)::value, 0xf, true);
+        return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    };
+    using std::integral_constant;
+    v += shifted(v, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});      // row_shr:1
+    v += shifted(v, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});      // row_shr:2
+    v += shifted(v, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});      // row_shr:4
+    v += shifted(v, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});      // row_shr:8: lane 15 of a row = row total
+    v += shifted(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});      // row_bcast:15 into rows 1, 3
+    v += shifted(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});      // row_bcast:31 into rows 2, 3
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), 63);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 template <bool MONO, int PW = 1>
 __global__ __launch_bounds__(kParThreads * PW) void rms_par_sum_kernel(const RArgs a)
 {
@@ -824,19 +846,23 @@ __global__ __launch_bounds__(kParThreads * PW) void rms_par_tally_kernel(const R
 #pragma unroll
     for (int g = 0; g < kParGroups; ++g) {
         const float4 v = *(const float4 *)(row + g * kSeqGroup + 4 * lane);
-        const double after = run + wave_sum_f64((double)v.x + (double)v.y + (double)v.z + (double)v.w);
+        const double after = run + wave_sum_f64_dpp((double)v.x + (double)v.y + (double)v.z + (double)v.w);
         if (run < next && after >= next && gstar == kParGroups) gstar = g;
         run = after;
     }
     // per group: the tally against ulp(e) and against ulp(e + 1) (the stitch uses whichever binade the
-    // running sum is really in), and whether each can be trusted
-    uint32_t bad_bits = 0, qtot = 0, mine_e = 0, mine_f = 0;
+    // running sum is really in), and whether each can be trusted.  The tallies against ulp(e + 1) are only computed where the sum
+    // may reach the next binade inside this block - a crossing is foreseen, or the block ends within a thousandth of it (the float32
+    // recurrence drifts from these float64 sums by ~1e-4): elsewhere they are flagged untrustworthy, and a block the stitch finds
+    // in the next binade after all takes its groups' additions (exact either way; a third of this kernel's work for nine blocks in ten)
+    const bool want_f = gstar < kParGroups || run >= next * 0.999;
+    uint32_t bad_bits = want_f ? 0u : 0xff00u, qtot = 0, mine_e = 0, mine_f = 0;
     bool all_zero = true;
 #pragma unroll
     for (int g = 0; g < kParGroups; ++g) {
         bool be = false, bf = false, ze = true, zf = true;
         const uint32_t qe = par_tally_groups(row, g, g + 1, eb, lane, &be, &ze);
-        const uint32_t qf = par_tally_groups(row, g, g + 1, eb + 1, lane, &bf, &zf);
+        const uint32_t qf = want_f ? par_tally_groups(row, g, g + 1, eb + 1, lane, &bf, &zf) : 0u;
         if (be) bad_bits |= 1u << g;
         if (bf) bad_bits |= 1u << (8 + g);
         all_zero &= ze;
