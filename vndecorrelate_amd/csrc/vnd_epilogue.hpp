@@ -856,25 +856,36 @@ __global__ __launch_bounds__(kParThreads * PW) void rms_par_tally_kernel(const R
     // recurrence drifts from these float64 sums by ~1e-4): elsewhere they are flagged untrustworthy, and a block the stitch finds
     // in the next binade after all takes its groups' additions (exact either way; a third of this kernel's work for nine blocks in ten)
     const bool want_f = gstar < kParGroups || run >= next * 0.999;
-    uint32_t bad_bits = want_f ? 0u : 0xff00u, qtot = 0, mine_e = 0, mine_f = 0;
-    bool all_zero = true;
+    // Nine blocks in ten are PLAIN: no tie, no square as large as the sum, no crossing in sight.  Those are tallied as a whole - one
+    // accumulation over the eight groups, one set of flags, one reduction - and the stitch accepts them by their total alone; their
+    // per-group tallies are never computed and are flagged untrustworthy (a plain block that the stitch has to open after all - the
+    // float32 sum left its binade where these float64 sums saw no crossing - takes its groups' additions: exact, and rare).
+    bool whole_bad = false, whole_zero = true;
+    const uint32_t q_whole = par_tally_groups(row, 0, kParGroups, eb, lane, &whole_bad, &whole_zero);
+    const bool per_group = whole_bad || want_f;
+    uint32_t bad_bits = 0xffffu, qtot = q_whole, mine_e = 0, mine_f = 0;
+    bool all_zero = whole_zero;
+    if (per_group) {
+        bad_bits = want_f ? 0u : 0xff00u; qtot = 0; all_zero = true;
 #pragma unroll
-    for (int g = 0; g < kParGroups; ++g) {
-        bool be = false, bf = false, ze = true, zf = true;
-        const uint32_t qe = par_tally_groups(row, g, g + 1, eb, lane, &be, &ze);
-        const uint32_t qf = want_f ? par_tally_groups(row, g, g + 1, eb + 1, lane, &bf, &zf) : 0u;
-        if (be) bad_bits |= 1u << g;
-        if (bf) bad_bits |= 1u << (8 + g);
-        all_zero &= ze;
-        qtot += qe;
-        if (lane == g) mine_e = qe;
-        if (lane == 8 + g) mine_f = qf;
+        for (int g = 0; g < kParGroups; ++g) {
+            bool be = false, bf = false, ze = true, zf = true;
+            const uint32_t qe = par_tally_groups(row, g, g + 1, eb, lane, &be, &ze);
+            const uint32_t qf = want_f ? par_tally_groups(row, g, g + 1, eb + 1, lane, &bf, &zf) : 0u;
+            if (be) bad_bits |= 1u << g;
+            if (bf) bad_bits |= 1u << (8 + g);
+            all_zero &= ze;
+            qtot += qe;
+            if (lane == g) mine_e = qe;
+            if (lane == 8 + g) mine_f = qf;
+        }
     }
+    const uint32_t real_bad = per_group ? bad_bits : 0u;           // what the block's own data flagged (the stitch's prefetch list, kParBad)
     // a block whose only trouble is ties: its round-to-even tally and the two corrections (start even / odd), so that the
     // stitch accepts it with three scalar operations (audio that came from integers has ties in most blocks)
     TieScan sc;
     uint32_t scan_total = 0;
-    bool scan_ok = eb >= 23 && eb < 255 && (bad_bits & 0xffu) != 0;
+    bool scan_ok = eb >= 23 && eb < 255 && (real_bad & 0xffu) != 0;
     if (scan_ok) {
         const float scale = seq_scale(eb);
 #pragma unroll 1
@@ -890,13 +901,13 @@ __global__ __launch_bounds__(kParThreads * PW) void rms_par_tally_kernel(const R
         r.tag = (uint32_t)(eb & 0x1ff);
         if (all_zero) r.tag |= kParZero;
         if (scan_ok) { r.tag |= kParTies; qtot = scan_total; }
-        else if ((bad_bits & 0xffu) != 0 || qtot >= (1u << 24)) r.tag |= kParBad;
+        else if ((real_bad & 0xffu) != 0 || qtot >= (1u << 24)) r.tag |= kParBad;
         if (gstar < kParGroups) r.tag |= kParHint | ((uint32_t)gstar << 16);
         r.qtot = qtot; r.bad = bad_bits;
         // the groups the stitch will most likely have to add one by one: g* itself, before it the groups
         // that cannot be settled against ulp(e), after it those that cannot against ulp(e + 1)
         r.need = gstar < kParGroups ? ((1u << gstar) | (bad_bits & ((1u << gstar) - 1u)) | ((bad_bits >> 8) & 0xffu & ~((2u << gstar) - 1u)))
-                                    : (scan_ok ? 0u : (bad_bits & 0xffu));      // a ties-only block is settled without its squares
+                                    : (scan_ok ? 0u : (real_bad & 0xffu));      // a ties-only block is settled without its squares
         if (scan_ok) r.need |= (((uint32_t)sc.delta0 & 0xfffu) << 8) | (((uint32_t)sc.delta1 & 0xfffu) << 20);
         a.rec[at] = r;
     }
