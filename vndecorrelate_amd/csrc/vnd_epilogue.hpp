@@ -824,18 +824,19 @@ __global__ __launch_bounds__(kParThreads * PW) void rms_par_tally_kernel(const R
         return;
     }
     const int blk = unit + 1;
-    if constexpr (PW == 2) par_stage_quad(a, b0, blk, sq, tid);
-    else par_stage<MONO>(a, b, blk, sq, tid);
     // where the running sum stands when this block starts, to within float64 rounding: only its
     // binade matters, and a wrong guess merely sends the block down the sequential path
+    // (its loads are issued BEFORE the block's own: the two round trips overlap - the kernel is bound by latency, five workgroups per CU)
     const double *sums = a.blk_sum + (b * 4 + chain) * a.nblocks;
     double pre = 0.0;
     if (a.prefixed) {
         pre = sums[blk];
     } else {                                               // short streams: every block adds up its predecessors itself
         for (int j = lane; j < blk; j += 64) pre += sums[j];
-        pre = wave_sum_f64(pre);
     }
+    if constexpr (PW == 2) par_stage_quad(a, b0, blk, sq, tid);
+    else par_stage<MONO>(a, b, blk, sq, tid);
+    if (!a.prefixed) pre = wave_sum_f64_dpp(pre);
     const int eb = (int)(__float_as_uint((float)pre) >> 23);
     __syncthreads();
     const float *row = sq + wave * kParFrames;
