@@ -599,13 +599,10 @@ __device__ __forceinline__ const float *par_pair_base(const RArgs &a, const floa
     return arr + (stream * a.n + f0) * a.C + 2 * pair + ch;
 }
 
-// A block's frames on their way into LDS: eight 16-byte registers per thread.  par_load only ISSUES the loads (a caller that loads
-// two blocks before it commits the first has both round trips in flight); par_commit squares and writes sq[4][2048] (chains: x ch0,
-// x ch1, y ch0, y ch1).  Frames past the end of the stream read 0 and add +0, exact.
-struct ParRegs { v4f xv[2][2], yv[2][2]; };       // [u][h]: frames 4 * tid + 1024 * u + 2 * h + {0, 1} as {L, R, L, R}
-
+// squares of block `blk` of stream b into sq[4][2048] (chains: x ch0, x ch1, y ch0, y ch1); frames
+// past the end of the stream read 0 and add +0, exact
 template <bool MONO>
-__device__ __forceinline__ void par_load(const RArgs &a, int64_t b, int blk, int tid, ParRegs &g)
+__device__ __forceinline__ void par_stage(const RArgs &a, int64_t b, int blk, float *sq, int tid)
 {
     const int64_t f0 = (int64_t)blk * kParFrames;
     if (!MONO && a.C > 2) {
@@ -617,13 +614,14 @@ __device__ __forceinline__ void par_load(const RArgs &a, int64_t b, int blk, int
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int fr = 4 * tid + 1024 * u;
+            v2f xf[4], yf[4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const v2f x0 = buf_load2(rx, (fr + 2 * h) * fb, 0, 0), x1 = buf_load2(rx, (fr + 2 * h + 1) * fb, 0, 0);
-                const v2f y0 = buf_load2(ry, (fr + 2 * h) * fb, 0, 0), y1 = buf_load2(ry, (fr + 2 * h + 1) * fb, 0, 0);
-                g.xv[u][h] = v4f{x0.x, x0.y, x1.x, x1.y};
-                g.yv[u][h] = v4f{y0.x, y0.y, y1.x, y1.y};
-            }
+            for (int k = 0; k < 4; ++k) { xf[k] = buf_load2(rx, (fr + k) * fb, 0, 0); yf[k] = buf_load2(ry, (fr + k) * fb, 0, 0); }
+            float4 *dst = (float4 *)(sq + fr);
+            dst[0 * kParFrames / 4] = make_float4(xf[0].x * xf[0].x, xf[1].x * xf[1].x, xf[2].x * xf[2].x, xf[3].x * xf[3].x);
+            dst[1 * kParFrames / 4] = make_float4(xf[0].y * xf[0].y, xf[1].y * xf[1].y, xf[2].y * xf[2].y, xf[3].y * xf[3].y);
+            dst[2 * kParFrames / 4] = make_float4(yf[0].x * yf[0].x, yf[1].x * yf[1].x, yf[2].x * yf[2].x, yf[3].x * yf[3].x);
+            dst[3 * kParFrames / 4] = make_float4(yf[0].y * yf[0].y, yf[1].y * yf[1].y, yf[2].y * yf[2].y, yf[3].y * yf[3].y);
         }
         return;
     }
@@ -633,48 +631,37 @@ __device__ __forceinline__ void par_load(const RArgs &a, int64_t b, int blk, int
     const v4i ry = make_rsrc(ys, (a.n - f0) * 8);
     // 8 bytes per access where a stream's first sample is only 8-byte aligned (n odd, or a misaligned base): a.wide says when whole
     // 16-byte accesses are safe - they move the same bytes at 1.4-1.8x the rate (MI355X_MICROARCH.md: 8-byte accesses 0.54-0.70x)
+    v4f yv[2][2], xv[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {                         // frames 4*tid + 1024*u + {0..3}
         const int fr = 4 * tid + 1024 * u;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (a.wide) {
-                g.yv[u][h] = buf_load4(ry, (fr + 2 * h) * 8, 0, 0);
-                if constexpr (!MONO) { g.xv[u][h] = buf_load4(rx, (fr + 2 * h) * 8, 0, 0); continue; }
+                yv[u][h] = buf_load4(ry, (fr + 2 * h) * 8, 0, 0);
+                if constexpr (!MONO) { xv[u][h] = buf_load4(rx, (fr + 2 * h) * 8, 0, 0); continue; }
             } else {
                 const v2f y0 = buf_load2(ry, (fr + 2 * h) * 8, 0, 0), y1 = buf_load2(ry, (fr + 2 * h + 1) * 8, 0, 0);
-                g.yv[u][h] = v4f{y0.x, y0.y, y1.x, y1.y};
+                yv[u][h] = v4f{y0.x, y0.y, y1.x, y1.y};
             }
             if constexpr (MONO) {
                 const float m0 = buf_load1(rx, (fr + 2 * h) * 4, 0, 0), m1 = buf_load1(rx, (fr + 2 * h + 1) * 4, 0, 0);
-                g.xv[u][h] = v4f{m0, m0, m1, m1};
+                xv[u][h] = v4f{m0, m0, m1, m1};
             } else {
                 const v2f x0 = buf_load2(rx, (fr + 2 * h) * 8, 0, 0), x1 = buf_load2(rx, (fr + 2 * h + 1) * 8, 0, 0);
-                g.xv[u][h] = v4f{x0.x, x0.y, x1.x, x1.y};
+                xv[u][h] = v4f{x0.x, x0.y, x1.x, x1.y};
             }
         }
     }
-}
-
-__device__ __forceinline__ void par_commit(const ParRegs &g, float *sq, int tid)
-{
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         float4 *dst = (float4 *)(sq + 4 * tid + 1024 * u);
-        const v4f p = g.xv[u][0], q = g.xv[u][1], r = g.yv[u][0], t = g.yv[u][1];
+        const v4f p = xv[u][0], q = xv[u][1], r = yv[u][0], t = yv[u][1];
         dst[0 * kParFrames / 4] = make_float4(p.x * p.x, p.z * p.z, q.x * q.x, q.z * q.z);
         dst[1 * kParFrames / 4] = make_float4(p.y * p.y, p.w * p.w, q.y * q.y, q.w * q.w);
         dst[2 * kParFrames / 4] = make_float4(r.x * r.x, r.z * r.z, t.x * t.x, t.z * t.z);
         dst[3 * kParFrames / 4] = make_float4(r.y * r.y, r.w * r.w, t.y * t.y, t.w * t.w);
     }
-}
-
-template <bool MONO>
-__device__ __forceinline__ void par_stage(const RArgs &a, int64_t b, int blk, float *sq, int tid)
-{
-    ParRegs g;
-    par_load<MONO>(a, b, blk, tid, g);
-    par_commit(g, sq, tid);
 }
 
 // Which (block, stream-or-pair) a workgroup of the sum / tally kernels takes.  Stereo: blockIdx.x = block, blockIdx.y = stream.  Wider
@@ -683,13 +670,12 @@ __device__ __forceinline__ void par_stage(const RArgs &a, int64_t b, int blk, fl
 // the P workgroups of a block are neighbours in their XCD's queue, and the lines come from HBM once, not P times.  grid.x =
 // ceil(nblocks / 8) * 8 * P; returns false for the padding.
 // PW: channel pairs per workgroup (2: a channel QUAD - 16 bytes of every frame per access, par_stage_quad; *b = its first pair).
-// `id`: blockIdx.x, or - the tally kernel's second unit - blockIdx.x + gridDim.x (a multiple of 8: the same XCD class)
 template <int PW = 1>
-__device__ __forceinline__ bool par_unit(const RArgs &a, int *blk, int64_t *b, unsigned id = blockIdx.x)
+__device__ __forceinline__ bool par_unit(const RArgs &a, int *blk, int64_t *b)
 {
-    if (a.pairs <= 1) { *blk = (int)id; *b = blockIdx.y; return (int)id < a.nblocks; }
+    if (a.pairs <= 1) { *blk = (int)blockIdx.x; *b = blockIdx.y; return true; }
     const unsigned per_block = (unsigned)a.pairs / PW;
-    const unsigned xcd = id & 7u, j = id >> 3;
+    const unsigned id = blockIdx.x, xcd = id & 7u, j = id >> 3;
     const unsigned unit = j % per_block;
     *blk = (int)((j / per_block) * 8u + xcd);
     *b = (int64_t)blockIdx.y * a.pairs + unit * PW;
@@ -697,23 +683,18 @@ __device__ __forceinline__ bool par_unit(const RArgs &a, int *blk, int64_t *b, u
 }
 
 // a channel QUAD of a wider signal (pairs b0 and b0 + 1 of its stream): whole 16-byte accesses, 512 threads x 4 frames, squares into
-// sq[8][2048]: rows 0-3 the first pair's chains (x ch0, x ch1, y ch0, y ch1), rows 4-7 the second pair's.  ParRegs [u][h] = frame
-// 4 * tid + 2 * u + h, all four channels.
-__device__ __forceinline__ void par_load_quad(const RArgs &a, int64_t b0, int blk, int tid, ParRegs &g)
+// sq[8][2048]: rows 0-3 the first pair's chains (x ch0, x ch1, y ch0, y ch1), rows 4-7 the second pair's
+__device__ __forceinline__ void par_stage_quad(const RArgs &a, int64_t b0, int blk, float *sq, int tid)
 {
     const int64_t f0 = (int64_t)blk * kParFrames;
     int64_t xb, yb;
     const float *xs = par_pair_base(a, a.x, b0, f0, 0, &xb), *ys = par_pair_base(a, a.y, b0, f0, 0, &yb);
     const v4i rx = make_rsrc(xs, xb), ry = make_rsrc(ys, yb);
     const int fb = a.C * 4, fr = 4 * tid;
+    v4f xq[4], yq[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { g.xv[k >> 1][k & 1] = buf_load4(rx, (fr + k) * fb, 0, 0); g.yv[k >> 1][k & 1] = buf_load4(ry, (fr + k) * fb, 0, 0); }
-}
-
-__device__ __forceinline__ void par_commit_quad(const ParRegs &g, float *sq, int tid)
-{
-    const v4f xq[4] = {g.xv[0][0], g.xv[0][1], g.xv[1][0], g.xv[1][1]}, yq[4] = {g.yv[0][0], g.yv[0][1], g.yv[1][0], g.yv[1][1]};
-    float4 *dst = (float4 *)(sq + 4 * tid);
+    for (int k = 0; k < 4; ++k) { xq[k] = buf_load4(rx, (fr + k) * fb, 0, 0); yq[k] = buf_load4(ry, (fr + k) * fb, 0, 0); }
+    float4 *dst = (float4 *)(sq + fr);
     dst[0 * kParFrames / 4] = make_float4(xq[0].x * xq[0].x, xq[1].x * xq[1].x, xq[2].x * xq[2].x, xq[3].x * xq[3].x);
     dst[1 * kParFrames / 4] = make_float4(xq[0].y * xq[0].y, xq[1].y * xq[1].y, xq[2].y * xq[2].y, xq[3].y * xq[3].y);
     dst[2 * kParFrames / 4] = make_float4(yq[0].x * yq[0].x, yq[1].x * yq[1].x, yq[2].x * yq[2].x, yq[3].x * yq[3].x);
@@ -722,13 +703,6 @@ __device__ __forceinline__ void par_commit_quad(const ParRegs &g, float *sq, int
     dst[5 * kParFrames / 4] = make_float4(xq[0].w * xq[0].w, xq[1].w * xq[1].w, xq[2].w * xq[2].w, xq[3].w * xq[3].w);
     dst[6 * kParFrames / 4] = make_float4(yq[0].z * yq[0].z, yq[1].z * yq[1].z, yq[2].z * yq[2].z, yq[3].z * yq[3].z);
     dst[7 * kParFrames / 4] = make_float4(yq[0].w * yq[0].w, yq[1].w * yq[1].w, yq[2].w * yq[2].w, yq[3].w * yq[3].w);
-}
-
-__device__ __forceinline__ void par_stage_quad(const RArgs &a, int64_t b0, int blk, float *sq, int tid)
-{
-    ParRegs g;
-    par_load_quad(a, b0, blk, tid, g);
-    par_commit_quad(g, sq, tid);
 }
 
 __device__ __forceinline__ double wave_sum_f64(double v)
@@ -828,45 +802,40 @@ __device__ __forceinline__ uint32_t par_tally_groups(const float *row, int g0, i
     return q;
 }
 
-// One unit of the tally kernel = one block of one stream (or channel pair / quad); unit nblocks - 1 is the EXTRA one: the chains'
-// start - block 0 by the recurrence itself, from +0 (its first groups are all ties and binade crossings) - beside the tallies of the
-// other blocks instead of holding up the block sums that they wait for.  par_tally_issue only issues a unit's loads: the float64
-// sums of the blocks before it (where the running sum stands when this block starts, to within float64 rounding: only its binade
-// matters, and a wrong guess merely sends the block down the sequential path) and the block's own frames.
-template <bool MONO, int PW>
-__device__ __forceinline__ void par_tally_issue(const RArgs &a, int unit, int64_t b0, ParRegs &g, double &pre)
+template <bool MONO, int PW = 1>
+__global__ __launch_bounds__(kParThreads * PW) void rms_par_tally_kernel(const RArgs a)
 {
+    __shared__ __attribute__((aligned(16))) float sq[PW * 4 * kParFrames];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, chain = wave & 3;
-    const int64_t b = b0 + (wave >> 2);                    // this wave's pair
-    const bool start = unit == a.nblocks - 1;
-    const int blk = start ? 0 : unit + 1;
-    pre = 0.0;
-    if (!start) {
-        const double *sums = a.blk_sum + (b * 4 + chain) * a.nblocks;
-        if (a.prefixed) {
-            pre = sums[blk];
-        } else {                                           // short streams: every block adds up its predecessors itself
-            for (int j = lane; j < blk; j += 64) pre += sums[j];
-        }
-    }
-    if constexpr (PW == 2) par_load_quad(a, b0, blk, tid, g);
-    else par_load<MONO>(a, b, blk, tid, g);
-}
-
-template <bool MONO, int PW>
-__device__ __forceinline__ void par_tally_unit(const RArgs &a, float *sq, int unit, int64_t b0, const ParRegs &g, double pre)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, chain = wave & 3;
-    const int64_t b = b0 + (wave >> 2);
-    if constexpr (PW == 2) par_commit_quad(g, sq, tid);
-    else par_commit(g, sq, tid);
-    if (unit == a.nblocks - 1) {                           // (uniform over the workgroup)
+    int unit;
+    int64_t b;
+    if (!par_unit<PW>(a, &unit, &b)) return;
+    const int64_t b0 = b;
+    b += wave >> 2;                                        // this wave's pair
+    if (unit == a.nblocks - 1) {
+        // the extra workgroup: the chains' START - block 0 by the recurrence itself, from +0 (its first groups
+        // are all ties and binade crossings) - runs beside the tallies of the other blocks instead of holding
+        // up the block sums that they wait for
+        if constexpr (PW == 2) par_stage_quad(a, b0, 0, sq, tid);
+        else par_stage<MONO>(a, b, 0, sq, tid);
         __syncthreads();
         const float acc = seq_sum_block<kParFrames, true>(sq + wave * kParFrames, 0.0f, lane);
         if (lane == 0) a.first[b * 4 + chain] = acc;
         return;
     }
     const int blk = unit + 1;
+    // where the running sum stands when this block starts, to within float64 rounding: only its
+    // binade matters, and a wrong guess merely sends the block down the sequential path
+    // (its loads are issued BEFORE the block's own: the two round trips overlap - the kernel is bound by latency, five workgroups per CU)
+    const double *sums = a.blk_sum + (b * 4 + chain) * a.nblocks;
+    double pre = 0.0;
+    if (a.prefixed) {
+        pre = sums[blk];
+    } else {                                               // short streams: every block adds up its predecessors itself
+        for (int j = lane; j < blk; j += 64) pre += sums[j];
+    }
+    if constexpr (PW == 2) par_stage_quad(a, b0, blk, sq, tid);
+    else par_stage<MONO>(a, b, blk, sq, tid);
     if (!a.prefixed) pre = wave_sum_f64_dpp(pre);
     const int eb = (int)(__float_as_uint((float)pre) >> 23);
     __syncthreads();
@@ -942,27 +911,6 @@ __device__ __forceinline__ void par_tally_unit(const RArgs &a, float *sq, int un
                                     : (scan_ok ? 0u : (real_bad & 0xffu));      // a ties-only block is settled without its squares
         if (scan_ok) r.need |= (((uint32_t)sc.delta0 & 0xfffu) << 8) | (((uint32_t)sc.delta1 & 0xfffu) << 20);
         a.rec[at] = r;
-    }
-}
-
-// TWO units per workgroup (ids blockIdx.x and blockIdx.x + gridDim.x): the kernel is bound by latency - a unit is a round trip for
-// its prefix sums and its frames, then ~2 us of tallies, and only five workgroups (32 KB of squares each) fit a CU - so both units'
-// loads are issued before the first is tallied: the second round trip hides under the first unit's arithmetic.
-template <bool MONO, int PW = 1>
-__global__ __launch_bounds__(kParThreads * PW) void rms_par_tally_kernel(const RArgs a)
-{
-    __shared__ __attribute__((aligned(16))) float sq[PW * 4 * kParFrames];
-    int unit0 = 0, unit1 = 0;
-    int64_t b0 = 0, b1 = 0;
-    const bool ok0 = par_unit<PW>(a, &unit0, &b0, blockIdx.x), ok1 = par_unit<PW>(a, &unit1, &b1, blockIdx.x + gridDim.x);
-    ParRegs g0, g1;
-    double pre0 = 0.0, pre1 = 0.0;
-    if (ok0) par_tally_issue<MONO, PW>(a, unit0, b0, g0, pre0);
-    if (ok1) par_tally_issue<MONO, PW>(a, unit1, b1, g1, pre1);
-    if (ok0) par_tally_unit<MONO, PW>(a, sq, unit0, b0, g0, pre0);
-    if (ok1) {
-        if (ok0) __syncthreads();                          // every wave is done with the first unit's squares
-        par_tally_unit<MONO, PW>(a, sq, unit1, b1, g1, pre1);
     }
 }
 

@@ -183,9 +183,7 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
         // 4k channels with 16-byte-aligned streams: a channel QUAD per workgroup (512 threads, whole 16-byte accesses)
         const int pw = (pairs > 1 && pairs % 2 == 0 && r.wide) ? 2 : 1;
         const unsigned gx = pairs == 1 ? (unsigned)r.nblocks : (unsigned)(((r.nblocks + 7) / 8) * 8 * (pairs / pw));
-        // (tally: blocks 1 .., plus block 0's chain; two units per workgroup - ids x and x + grid.x, the same XCD class: a multiple of 8)
-        const unsigned tx = pairs == 1 ? (gx + 1) / 2 : ((gx / 2 + 7) / 8) * 8;
-        const dim3 pgrid(gx, (unsigned)batch), tgrid(tx, (unsigned)batch);
+        const dim3 pgrid(gx, (unsigned)batch), tgrid(gx, (unsigned)batch);     // tally: blocks 1.., plus block 0's chain
         const dim3 sgrid((unsigned)(batch * pairs * 4));
         if (Cx == 1) {
             if (!blk_done) hipLaunchKernelGGL(rms_par_sum_kernel<true>, pgrid, dim3(kParThreads), 0, stream, r);
