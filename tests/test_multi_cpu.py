@@ -157,3 +157,33 @@ def test_the_gpu_workers_fail_loudly_without_a_device():
     import vndecorrelate_amd.decorrelation as vnd
     with pytest.raises(RuntimeError):
         vnd.convolve_velvet_noise_batched(x, fir, devices='all')
+
+
+def test_two_callers_share_a_pool():
+    """Two host threads through the same pool at once (the GPU workers serialise per device on their context's mutex; here the
+    checker has no such lock): every caller gets its own batch back, whole."""
+    fir, arrays = _arrays()
+    log = []
+    pool = _pool(3, log)
+    rng = np.random.default_rng(5)
+    batches = [rng.uniform(-1, 1, (7, 1500, 2)).astype(np.float32), rng.uniform(-1, 1, (4, 2100, 2)).astype(np.float32)]
+    outs = [np.empty_like(b) for b in batches]
+    errors = []
+
+    def caller(k):
+        try:
+            for _ in range(5):
+                pool.map_streams(arrays, batches[k], outs[k], 'convolve', 0)
+        except Exception as exc:                        # pragma: no cover
+            errors.append(exc)
+    threads = [threading.Thread(target=caller, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    for k in range(2):
+        want = np.stack([O.convolve_velvet_noise(batches[k][b], fir) for b in range(len(batches[k]))])
+        assert np.array_equal(outs[k], want)
+    assert pool.made == [3]
+    pool.close()

@@ -186,13 +186,14 @@ class DevicePool:
         if x.ndim != 3 or out.ndim != 3 or out.shape[:2] != x.shape[:2]:
             raise ValueError(f'expected (batch, n, C) arrays of one batch, got {x.shape} and {out.shape}')
         workers = self.workers(arrays)
-        self.last_blocks = blocks(x.shape[0], len(self.devices))
+        cut = blocks(x.shape[0], len(self.devices))
+        self.last_blocks = cut                            # (what the last call did: for tests and tools; callers may overlap)
 
         def run(part):
-            first, count = self.last_blocks[part]
+            first, count = cut[part]
             if count:
                 getattr(workers[part], op)(x[first:first + count], out[first:first + count], mode, **kw)
-        busy = [p for p, (_, count) in enumerate(self.last_blocks) if count]
+        busy = [p for p, (_, count) in enumerate(cut) if count]
         if len(busy) == 1:
             run(busy[0])                                  # (no thread hop for one block)
         else:
