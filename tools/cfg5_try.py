@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """cfg5 (96 kHz, 8 channels, 64 taps; pool of 16 ten-second signals) and cfg3 through bench.py's own timing loop, fast and exact, for the
-settings given on the command line (KEY=VALUE ..., read live: VND_TUNING) - one fresh table per call.  usage: cfg5_try.py [cfg3] KEY=VALUE ..."""
+settings given on the command line (KEY=VALUE ..., read live: VND_TUNING) - one fresh table per call.  usage: cfg5_try.py [cfg2|cfg3] KEY=VALUE ...   (cfg2: a pool of 512 signals)"""
 import os, pathlib, sys
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
 os.environ['VND_TUNING'] = '1'
-which = 'cfg3' if 'cfg3' in sys.argv[1:] else 'cfg5'
+which = 'cfg3' if 'cfg3' in sys.argv[1:] else ('cfg2' if 'cfg2' in sys.argv[1:] else 'cfg5')
 for kv in sys.argv[1:]:
     if '=' in kv:
         k, v = kv.split('=', 1); os.environ[k] = v
@@ -14,7 +14,9 @@ import vndecorrelate_amd.decorrelation as vnd
 from vndecorrelate_amd import _native
 from vndecorrelate_amd.taps import function_path_arrays
 ctx = _native.default_context()
-if which == 'cfg5':
+if which == 'cfg2':
+    fir = vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1); shape = (512, 480000, 2)
+elif which == 'cfg5':
     fir = vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=64, num_outs=8, sample_rate_hz=96000, seed=1); shape = (16, 960000, 8)
 else:
     fir = vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=128, num_outs=2, sample_rate_hz=48000, log_distribution_strength=0.0, seed=1); shape = (24, 2880000, 2)
