@@ -28,7 +28,10 @@ typedef __attribute__((address_space(3))) char lds_char;
 
 // FILL: 0 zeros, 1 one word repeated, 2 random bits as floats in [1, 2) (mantissa only), 3 uniform [-1, 1) (sign + mantissa + a few exponent bits)
 // FMAS: packed FMAs per 16-byte read (0: reads alone; 3 = the octet kernel's 2048 FMAs per 333 reads, lane and tile, as v_pk_fma_f32)
-template <int NT, int FMAS>
+// OP (round 6): what consumes a read - 0 v_pk_fma_f32 (acc += x * w), 1 v_pk_add_f32 (acc +- x: the reference's class-path association,
+// decorrelation.py:402-414 - add and subtract inside a segment, ONE multiply per segment; the sign is a neg_lo / neg_hi source modifier),
+// 2 three v_pk_add_f32 to one v_pk_fma_f32 (a 30-tap table's mix once the segment boundaries of both accumulator sets are FMAs)
+template <int NT, int FMAS, int OP = 0>
 __global__ __launch_bounds__(NT) void reads_kernel(float *out, int trips, int wave_stride, int fill, unsigned seed)
 {
     extern __shared__ __attribute__((aligned(16))) float lds_generic[];
@@ -64,8 +67,12 @@ __global__ __launch_bounds__(NT) void reads_kernel(float *out, int trips, int wa
                 acc[0] += v2f{c.x, c.y}; acc[1] += v2f{c.z, c.w};
             } else {
 #pragma unroll
-                for (int f = 0; f < FMAS; ++f)
-                    acc[f % 8] = __builtin_elementwise_fma((f & 1) ? v2f{c.z, c.w} : v2f{c.x, c.y}, w, acc[f % 8]);
+                for (int f = 0; f < FMAS; ++f) {
+                    const v2f xv = (f & 1) ? v2f{c.z, c.w} : v2f{c.x, c.y};
+                    if (OP == 0 || (OP == 2 && f % 4 == 3)) acc[f % 8] = __builtin_elementwise_fma(xv, w, acc[f % 8]);
+                    else if ((f >> 1) & 1) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[1,0] neg_hi:[1,0]" : "=v"(acc[f % 8]) : "v"(xv), "0"(acc[f % 8]));
+                    else asm("v_pk_add_f32 %0, %1, %2" : "=v"(acc[f % 8]) : "v"(xv), "0"(acc[f % 8]));
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -80,6 +87,8 @@ __global__ __launch_bounds__(NT) void reads_kernel(float *out, int trips, int wa
 // nothing extra to issue when the shift is a DPP modifier of the FMA itself (v_fmac_f32 ... row_shr:1) - but DPP exists on the single
 // v_fmac_f32 only, not on v_pk_fma_f32: one FMA per lane and instruction instead of two.  KIND 0: v_pk_fma_f32 on held registers;
 // 1: v_fmac_f32 with a row_shr:1 operand; 2: v_mov_b32 row_shr:1 into a temporary + v_pk_fma_f32 (a shifted PAIR costs two moves).
+// Round 6 - is an ADD cheaper than an FMA in watts?  KIND 4: v_pk_add_f32 acc += x; 5: v_pk_fma_f32 with the product's sign alternating
+// per pass (neg modifier: the accumulator walks instead of growing); 6: v_pk_add_f32 with the same alternating sign; 7: v_pk_mul_f32.
 template <int KIND>
 __global__ __launch_bounds__(512) void fma_kernel(float *out, int trips, unsigned seed)
 {
@@ -101,6 +110,16 @@ __global__ __launch_bounds__(512) void fma_kernel(float *out, int trips, unsigne
             if constexpr (KIND == 0) {
                 v2f a = {acc[j], acc[j + 1]};
                 a = __builtin_elementwise_fma(v2f{x[j], x[j + 1]}, v2f{w, w}, a);
+                acc[j] = a.x; acc[j + 1] = a.y;
+            } else if constexpr (KIND >= 4) {
+                v2f a = {acc[j], acc[j + 1]};
+                const v2f xv = {x[j], x[j + 1]}, wv = {w, w};
+                if constexpr (KIND == 4) asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(a) : "v"(xv));
+                else if constexpr (KIND == 5) { if (rep & 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(a) : "v"(xv), "v"(wv));
+                                                else asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a) : "v"(xv), "v"(wv)); }
+                else if constexpr (KIND == 6) { if (rep & 1) asm volatile("v_pk_add_f32 %0, %1, %0 neg_lo:[1,0] neg_hi:[1,0]" : "+v"(a) : "v"(xv));
+                                                else asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(a) : "v"(xv)); }
+                else asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(a) : "v"(xv), "v"(wv));
                 acc[j] = a.x; acc[j + 1] = a.y;
             } else if constexpr (KIND == 3) {
                 asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[j]) : "v"(x[j]), "v"(w));
@@ -182,16 +201,16 @@ struct Sampler {
     }
 };
 
-template <int FMAS, int NT = 512>
+template <int FMAS, int NT = 512, int OP = 0>
 static void run(Sampler &smp, bool have, const char *what, int fill, double seconds)
 {
     const int grid = 256, lds_bytes = 158 * 1024, trips = 2000;
     float *out;
     CK(hipMalloc(&out, 4));
-    CK(hipFuncSetAttribute((const void *)reads_kernel<NT, FMAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void *)reads_kernel<NT, FMAS, OP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    reads_kernel<NT, FMAS><<<grid, NT, lds_bytes>>>(out, trips, NT == 512 ? 19 * 1024 : 38 * 1024, fill, 1u);
+    reads_kernel<NT, FMAS, OP><<<grid, NT, lds_bytes>>>(out, trips, NT == 512 ? 19 * 1024 : 38 * 1024, fill, 1u);
     CK(hipDeviceSynchronize());
     if (have) smp.start();
     const auto t0 = std::chrono::steady_clock::now();
@@ -199,7 +218,7 @@ static void run(Sampler &smp, bool have, const char *what, int fill, double seco
     long launches = 0;
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
         CK(hipEventRecord(e0));
-        for (int r = 0; r < 20; ++r) reads_kernel<NT, FMAS><<<grid, NT, lds_bytes>>>(out, trips, NT == 512 ? 19 * 1024 : 38 * 1024, fill, (unsigned)(launches + r));
+        for (int r = 0; r < 20; ++r) reads_kernel<NT, FMAS, OP><<<grid, NT, lds_bytes>>>(out, trips, NT == 512 ? 19 * 1024 : 38 * 1024, fill, (unsigned)(launches + r));
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         ms_total += ms; ms_last = ms / 20; launches += 20;
@@ -272,5 +291,21 @@ int main(int argc, char **argv)
     run_fma<3>(smp, have, "v_fmac_f32 (one FMA per lane and instruction)", seconds);
     run_fma<1>(smp, have, "v_fmac_f32 with a DPP row_shr:1 operand (one FMA per lane and instruction)", seconds);
     run_fma<2>(smp, have, "v_mov_b32 row_shr:1 x 2 + v_pk_fma_f32 (a shifted pair)", seconds);
+    printf("-- round 6: adds instead of FMAs (decorrelation.py:402-414: add / subtract inside a segment, one multiply per segment). Same reads, random data\n");
+    run<3>(smp, have, "8 waves: reads + 3 v_pk_fma_f32 per read, random (again, for this box's clock)", 3, seconds);
+    run<3, 512, 1>(smp, have, "8 waves: reads + 3 v_pk_add_f32 per read, random", 3, seconds);
+    run<4>(smp, have, "8 waves: reads + 4 v_pk_fma_f32 per read, random (again)", 3, seconds);
+    run<4, 512, 1>(smp, have, "8 waves: reads + 4 v_pk_add_f32 per read, random", 3, seconds);
+    run<4, 512, 2>(smp, have, "8 waves: reads + 3 v_pk_add_f32 + 1 v_pk_fma_f32 per read, random", 3, seconds);
+    run<6, 512, 1>(smp, have, "8 waves: reads + 6 v_pk_add_f32 per read, random", 3, seconds);
+    run<11>(smp, have, "8 waves: reads + 11 v_pk_fma_f32 per read, random (again)", 3, seconds);
+    run<11, 512, 1>(smp, have, "8 waves: reads + 11 v_pk_add_f32 per read, random", 3, seconds);
+    run<11, 512, 2>(smp, have, "8 waves: reads + 11 per read, one in four an FMA, random", 3, seconds);
+    printf("-- the instruction alone, held registers, random operands\n");
+    run_fma<0>(smp, have, "v_pk_fma_f32 acc += x * w (again)", seconds);
+    run_fma<4>(smp, have, "v_pk_add_f32 acc += x", seconds);
+    run_fma<5>(smp, have, "v_pk_fma_f32 acc +- x * w, sign alternating per pass", seconds);
+    run_fma<6>(smp, have, "v_pk_add_f32 acc +- x, sign alternating per pass", seconds);
+    run_fma<7>(smp, have, "v_pk_mul_f32 acc = x * w", seconds);
     return 0;
 }
