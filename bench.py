@@ -82,7 +82,7 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=10.0, help='budget of the CPU baseline leg')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-exact', action='store_true', help='skip the extra exact-mode timing')
-    ap.add_argument('--no-secondary', action='store_true', help='skip cfg3/cfg5/cfg4, the next rows and end_to_end')
+    ap.add_argument('--no-secondary', action='store_true', help='skip cfg3/cfg5/cfg4, the audio leg, the next rows, end_to_end and the cfg4 strong-scaling leg')
     ap.add_argument('--no-strong', action='store_true', help='skip the cfg4 strong-scaling leg')
     ap.add_argument('--no-power', action='store_true', help='do not sample board power / shader clock')
     ap.add_argument('--detail', default=None, help='where the detail document goes (default: bench_detail.json beside bench.py)')
@@ -212,12 +212,29 @@ def cpu_baseline(budget_s: float) -> dict:
             'best_value': round(x.size / best / 1e6, 3)}
 
 
-def device_rate(torch, table, shape, mode, *, min_ms=30.0, buffers=1, taps=None, exact_pool=False, power=None):
+def board_under(torch, power, fn, seconds=0.6):
+    """The board's power (W) and shader clock (MHz) under `fn` launched back to back for `seconds` - NOT timed: the hwmon power
+    figure is a slow average, so the reading is the median over the second half of the run.  None when the box shows no hwmon files."""
+    if power is None or not power.files:
+        return None
+    s0, k = time.perf_counter(), 0
+    while time.perf_counter() - s0 < seconds:
+        fn(k); k += 1
+        if k % 8 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    s1 = time.perf_counter()
+    return power.window(s0 + (s1 - s0) / 2, s1)
+
+
+def device_rate(torch, table, shape, mode, *, min_ms=30.0, buffers=1, taps=None, exact_pool=False, power=None, xs_given=None, check_streams=None):
     """Kernel milliseconds per launch of `table` over a resident (batch, n, C) pool (HIP events on the
     launch stream, >= min_ms timed after a clock-settling warm-up).  `buffers` > 1 rotates distinct
-    pools so that small shapes still stream from HBM, not from the 256 MiB Infinity Cache."""
+    pools so that small shapes still stream from HBM, not from the 256 MiB Infinity Cache.
+    `xs_given`: the pools to run on (default: uniform random in [-1, 1))."""
     batch, n, c = shape
-    xs = [torch.empty(shape, dtype=torch.float32, device='cuda').uniform_(-1.0, 1.0) for _ in range(buffers)]
+    xs = xs_given if xs_given is not None else [torch.empty(shape, dtype=torch.float32, device='cuda').uniform_(-1.0, 1.0) for _ in range(buffers)]
+    buffers = len(xs)
     ys = [torch.empty_like(xs[0]) for _ in range(buffers)]
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -246,17 +263,7 @@ def device_rate(torch, table, shape, mode, *, min_ms=30.0, buffers=1, taps=None,
         iters *= 2
     per = ms / iters
     bytes_per_launch = ALGO_BYTES_PER_SAMPLE * batch * n * c
-    board = None
-    if power is not None and power.files:
-        # 0.6 s more of the same launches, not timed: the board's power figure is a slow average (medians of the last 0.3 s)
-        s0, k = time.perf_counter(), 0
-        while time.perf_counter() - s0 < 0.6:
-            launch(k); k += 1
-            if k % 8 == 0:
-                torch.cuda.synchronize()
-        torch.cuda.synchronize()
-        s1 = time.perf_counter()
-        board = power.window(s0 + (s1 - s0) / 2, s1)
+    board = board_under(torch, power, launch)      # 0.6 s more of the same launches, not timed
     rec = {'kernel_ms': round(per, 4), 'board': board, 'achieved_GBs': round(bytes_per_launch / (per * 1e-3) / 1e9, 1),
            'frac_of_8TBs': round(bytes_per_launch / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
            'Msamples_s': round(batch * n * c / (per * 1e-3) / 1e6, 1), 'launches_timed': iters,
@@ -270,8 +277,9 @@ def device_rate(torch, table, shape, mode, *, min_ms=30.0, buffers=1, taps=None,
         rec['flop_per_byte'] = round(2.0 * fmas / bytes_per_launch, 1)
         rec['bound'] = 'fp32 vector' if 2.0 * fmas / bytes_per_launch > FP32_VECTOR_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS else 'hbm'
         # one stream of what the timed launches wrote, against the C oracle (the last stream: the highest addresses)
-        rec['parity_vs_oracle_of_peak'] = oracle_parity(xs[(iters - 1) % buffers][batch - 1], ys[(iters - 1) % buffers][batch - 1], taps, mode)
-        rec['parity_stream'] = batch - 1
+        last = (iters - 1) % buffers
+        rec['parity_vs_oracle_of_peak'] = max(oracle_parity(xs[last][b], ys[last][b], taps, mode) for b in (check_streams or [batch - 1]))
+        rec['parity_stream'] = check_streams or batch - 1
         if mode != 0 and exact_pool:
             # EVERY stream of the pool against the exact kernel (= the oracle, bit for bit: asserted on a stream of its own leg): the
             # worst stream's error as a fraction of the pool's output peak - the north star's 1e-6 is asserted on this number
@@ -312,8 +320,7 @@ def secondary_configs(torch, vnd, _native, ctx, mode, power=None) -> dict:
         ('cfg3', dict(duration_seconds=0.03, num_impulses=128, num_outs=2, sample_rate_hz=48000,
                       log_distribution_strength=0.0, seed=1), (24, 2880000, 2), 1,
          '48 kHz stereo, 60 s, 128 taps (segmented decay, kappa 0); pool of 24',
-         'vector issue and its waits: 128 FMAs per sample; the window form reads 183 B of LDS per sample (435 in round 2) and is '
-         'no longer on the power cap (profiles/r03_cfg3_window_pmc.txt)'),
+         'FP32 vector pipe under the board power cap (32 flop per byte: past the 19.7 flop/B ridge); see `board` (W, MHz) of this leg and DESIGN.md 3.4'),
         ('cfg3_kappa1', dict(duration_seconds=0.03, num_impulses=128, num_outs=2, sample_rate_hz=48000,
                              log_distribution_strength=1.0, seed=1), (24, 2880000, 2), 1,
          '48 kHz stereo, 60 s, 128 impulses log-distributed (kappa 1): the function path keeps 123 distinct taps per channel '
@@ -321,10 +328,9 @@ def secondary_configs(torch, vnd, _native, ctx, mode, power=None) -> dict:
          'as cfg3'),
         ('cfg5', dict(duration_seconds=0.03, num_impulses=64, num_outs=8, sample_rate_hz=96000, seed=1),
          (16, 960000, 8), 1, '96 kHz 8-channel, 10 s, 64 log-distributed taps; pool of 16',
-         'LDS reads (2.6 B per FMA with 32-frame runs; a fifth of the LDS cycles are bank conflicts of the wave at the ring\'s end) and '
-         'vector issue: the window form on channel OCTETS moves whole 32-byte frames per workgroup (512 lanes, a wave per channel; 8 '
-         'waves per CU hold the 2720-frame halo of all 8 channels in 158 KB of LDS); until late round 3 a workgroup owned one channel '
-         'pair (8-byte pieces, 0.44-0.48 ms: profiles/r03_cfg5_request_floor.txt, profiles/r03_cfg5_octets.txt)'),
+         'LDS window reads (2.6 B per tap and output with 32-frame runs, bank conflicts 0.008 of the LDS cycles) and the FP32 pipe under the board '
+         'power cap; one workgroup of 512 lanes per CU (a wave per channel; the 2720-frame halo of all 8 channels takes 158 KB of LDS), so a '
+         'tile\'s exchange / store / refill phase is not covered by another workgroup (DESIGN.md 3.4, profiles/r05_cfg5_probe.txt)'),
         ('cfg4', dict(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1),
          (1024, 48000, 2), 2, '1024 independent 1 s stereo streams, 30 taps, one launch; 2 rotating pools',
          'board power cap, as cfg2'),
@@ -333,13 +339,13 @@ def secondary_configs(torch, vnd, _native, ctx, mode, power=None) -> dict:
         try:
             torch.manual_seed(5000 + k)                 # the pools are seeded: a run's parity figures are a fact about the code, not about the draw
             t, taps = table_of(**kw)
-            r = device_rate(torch, t, shape, mode, buffers=buffers, taps=taps, exact_pool=True, power=power if name in ('cfg3', 'cfg5') else None)
+            r = device_rate(torch, t, shape, mode, buffers=buffers, taps=taps, exact_pool=True, power=power)
             assert r['parity_vs_oracle_of_peak'] <= 1e-6, f"{name}: timed output off by {r['parity_vs_oracle_of_peak']:.2e} of peak"
             r.update({'workload': what, 'binding_limit': limit})
             if mode != vnd.MODE_EXACT and name != 'cfg3_kappa1':
                 # the API's default mode on the same pool: bit-identical to the oracle (asserted inside), its own per-table kernel
-                ex = device_rate(torch, t, shape, vnd.MODE_EXACT, buffers=buffers, taps=taps)
-                r['exact_mode'] = {k: ex[k] for k in ('kernel_ms', 'achieved_GBs', 'frac_of_8TBs', 'launch')}
+                ex = device_rate(torch, t, shape, vnd.MODE_EXACT, buffers=buffers, taps=taps, power=power)
+                r['exact_mode'] = {k: ex[k] for k in ('kernel_ms', 'achieved_GBs', 'frac_of_8TBs', 'board', 'launch')}
                 r['exact_mode']['parity'] = 'bit-identical to the C oracle on the checked stream (asserted in this run)'
             out[name] = r
             t.close()
@@ -381,7 +387,41 @@ def end_to_end(torch, vnd, mode) -> dict:
     return out
 
 
-def next_rows(torch, vnd, _native) -> dict:
+def audio_leg(torch, vnd, _native, ctx, pool, power=None) -> dict:
+    """The path on AUDIO instead of uniform random floats (SURVEY 8d's synthetic input is the worst case for the board's power cap,
+    DESIGN.md 3.4): BASELINE configs[0]'s material - the 1 s stereo excerpt of the reference's viola recording kept in
+    tests/golden/golden.npz (`viola_excerpt_in`, 44.1 kHz; /root/reference/tests/test_example.py:19-49 runs the whole file) - tiled to
+    10 s streams, every stream starting at another frame of the excerpt, as many streams as make the headline pool's bytes; the table
+    is that test's (20 ms, 30 impulses, seed 1).  Fast and exact kernels, three streams of each against the C oracle."""
+    from vndecorrelate_amd.taps import function_path_arrays
+    z = np.load(REPO / 'tests' / 'golden' / 'golden.npz')
+    excerpt = torch.from_numpy(np.ascontiguousarray(z['viola_excerpt_in'])).cuda()          # (44100, 2) float32
+    fs, reps = int(excerpt.shape[0]), 10
+    n = fs * reps
+    streams = max(3, int(round(pool * SAMPLE_RATE * SECONDS / n)))
+    base = excerpt.repeat(reps + 1, 1)
+    x = torch.empty((streams, n, 2), dtype=torch.float32, device='cuda')
+    for b in range(streams):
+        off = (b * 1009) % fs
+        x[b].copy_(base[off:off + n])
+    arr = function_path_arrays(vnd.generate_velvet_noise(duration_seconds=0.02, num_impulses=TAPS, num_outs=2, sample_rate_hz=fs, seed=1))
+    taps = (arr.tap_offsets, arr.tap_index, arr.tap_weight)
+    table = _native.TapTable.create(ctx, *taps)
+    out = {'what': f'{streams} streams x {reps} s of the viola excerpt (44.1 kHz stereo, peak {float(excerpt.abs().max()):.3f}, rms {float(excerpt.square().mean().sqrt()):.4f}), '
+                   f'one launch; table: 20 ms / 30 impulses / seed 1 at 44.1 kHz (tests/test_example.py:19-34 of the reference)',
+           'streams': streams, 'frames': n}
+    checked = sorted({0, streams // 2, streams - 1})
+    for label, mode in (('fast', vnd.MODE_FAST), ('exact', vnd.MODE_EXACT)):
+        r = device_rate(torch, table, (streams, n, 2), mode, taps=taps, power=power, xs_given=[x], check_streams=checked)
+        assert r['parity_vs_oracle_of_peak'] <= 1e-6, f"audio {label}: timed output off by {r['parity_vs_oracle_of_peak']:.2e} of peak"
+        out[label] = {k: r[k] for k in ('kernel_ms', 'achieved_GBs', 'frac_of_8TBs', 'board', 'parity_vs_oracle_of_peak', 'parity_stream', 'launch')}
+    table.close()
+    del x, base
+    torch.cuda.empty_cache()
+    return out
+
+
+def next_rows(torch, vnd, _native, power=None) -> dict:
     """SURVEY 8(f) rows on one GPU, host to host or device resident as stated (rates only; parity is tests/)."""
     import contextlib
     import io
@@ -462,6 +502,7 @@ def next_rows(torch, vnd, _native) -> dict:
                 e1.record()
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / reps
+                board = board_under(torch, power, lambda k: run())
                 moved = bytes_per_sample * pool * n * 2
                 worst = 0.0
                 for b in sorted({0, pool // 2, pool - 1}):
@@ -474,7 +515,7 @@ def next_rows(torch, vnd, _native) -> dict:
                 assert worst <= 5e-4, f'f1_pool: fused fast stage off by {worst:.2e} of peak'
                 rec[f'pool{pool}_{label}'] = {
                     'ms_per_call': round(ms, 4), 'bytes_per_sample_moved': bytes_per_sample, 'achieved_GBs': round(moved / (ms * 1e-3) / 1e9, 1),
-                    'frac_of_8TBs': round(moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'Msamples_s': round(pool * n * 2 / (ms * 1e-3) / 1e6, 1),
+                    'frac_of_8TBs': round(moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'Msamples_s': round(pool * n * 2 / (ms * 1e-3) / 1e6, 1), 'board': board,
                     'parity': ('bit-identical to the oracle\'s whole stage on streams 0 / middle / last (asserted in this run)' if mode == vnd.MODE_EXACT
                                else f'{worst:.1e} of peak from the oracle\'s stage (its RMS is the correctly rounded one: bar 5e-4)'),
                     'launch': table.describe(pool, n, 2, mode)[:200]}
@@ -518,6 +559,7 @@ def next_rows(torch, vnd, _native) -> dict:
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
+            board = board_under(torch, power, lambda k: run())
             b = pool8 - 1
             want = O.decorrelate(x[b].cpu().numpy(), **kw8)
             got = y[b].cpu().numpy()
@@ -530,7 +572,7 @@ def next_rows(torch, vnd, _native) -> dict:
             moved = bytes_per_sample * pool8 * n8 * 8
             rec[label] = {'ms_per_call': round(ms, 4), 'bytes_per_sample_moved': bytes_per_sample, 'achieved_GBs': round(moved / (ms * 1e-3) / 1e9, 1),
                           'frac_of_8TBs': round(moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'Msamples_s': round(pool8 * n8 * 8 / (ms * 1e-3) / 1e6, 1),
-                          'parity_vs_oracle_stage_of_peak': worst, 'launch': table.describe(pool8, n8, 8, mode)[:200]}
+                          'parity_vs_oracle_stage_of_peak': worst, 'board': board, 'launch': table.describe(pool8, n8, 8, mode)[:200]}
         rec['what'] = ('vnd_decorrelate_f32_dev of 16 x 10 s 96 kHz 8-channel signals (LR mode: the per-channel RMS normaliser alone), class-path table of 64 '
                        'taps per channel; fractions by the bytes the stage must move: 16 B per sample fused (convolution 8 + scale pass 8), 24 exact (+ 8: the '
                        'reference-order sums read x and y)')
@@ -568,6 +610,7 @@ def next_rows(torch, vnd, _native) -> dict:
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 200
+            board = board_under(torch, power, lambda k: run(mode))
             # stream 0 and the last one of what the timed launches wrote, against the C oracle on the replicated input
             worst = 0.0
             for b in (0, pool - 1):
@@ -576,7 +619,7 @@ def next_rows(torch, vnd, _native) -> dict:
             assert worst <= 1e-6, f'mono_to_stereo {label}: off by {worst:.2e} of peak'
             rec[label] = {'kernel_ms': round(ms, 4), 'output_Msamples_s': round(pool * n * 2 / ms / 1e3, 1),
                           'achieved_GBs_12B_per_frame': round(12e-6 * pool * n / ms, 1), 'frac_of_8TBs': round(12e-9 * pool * n / ms / 8.0, 4),
-                          'parity_vs_oracle_of_peak': worst, 'launch': table.describe(pool, n, 1, mode)}
+                          'parity_vs_oracle_of_peak': worst, 'board': board, 'launch': table.describe(pool, n, 1, mode)}
         out['mono_to_stereo_fast'] = dict(rec['fast'], what='128 x 10 s mono signals in, stereo out, one launch (12 algorithmic bytes per frame: 4 read, 8 written)',
                                           exact_mode=rec['exact'])
         table.close()
@@ -730,27 +773,34 @@ def dig(record, *path, default=None):
 # what the short keys of `config` are (the detail document carries the full records they come from)
 COMPACT_KEYS = {
     'parity': 'headline: worst of the checked streams of the timed output vs the C oracle, fraction of the output peak',
+    'cfg4_strong': 'this run\'s ranks on the 1024 x 1 s batch: max-over-ranks ms per pass, whole-job Msamples/s - the strong-scaling figure',
+    'proj_N1_us / proj_N8_us / proj_copy_N8_us / proj_speedup': 'one-GPU projection of the cfg4 strong cut: a rank\'s pass at N = 1 and N = 8, a copy of the N = 8 shard, N1 / N8',
     'exact_ms / exact_frac': 'VND_MODE_EXACT (bit-identical, the API default) on the headline pool: kernel ms, fraction of 8 TB/s',
     'class_exact_frac': 'the class path\'s table (VelvetNoise.convolve) in exact mode on the same pool',
     'cfgK_ms / cfgK_frac / cfgK_exact_frac': 'BASELINE configs[K-1] on one GPU: kernel ms and fraction of 8 TB/s by 8 B per sample, fast and exact',
     'cfg3_fp32_frac': 'cfg3 against the FP32 vector peak (157.3 TFLOP/s): its binding limit',
     'cfg3k1_frac': 'cfg3 with kappa 1 (123 distinct taps per channel)',
+    'cfgK_parity': 'fast mode: the worst stream of that timed pool against the exact kernel (= the reference), of the pool\'s peak',
+    'worst_parity_over_pools': 'the largest of them',
+    'audio_frac / audio_exact_frac': 'the headline pool\'s bytes as 10 s streams of the reference\'s viola recording (44.1 kHz stereo, its 20 ms table) instead of random floats',
     'f1_P_exact_frac / f1_P_fast_frac': 'the whole decorrelate stage over a pool of P 10 s stereo signals, by its own 24 / 16 B per sample',
     'f1_c8_frac': 'VelvetNoise.decorrelate of 8-channel 96 kHz signals (LR mode, RMS normaliser), fused fast stage, by 16 B per sample',
     'm2s_frac / m2s_exact_frac': 'mono in, stereo out, 12 B per frame',
     'scan_ms / chain_ms': 'f3 grid scan of 400 candidates, f4 resident chain: host to host',
     'e2e_cfg2_ms / e2e_cfg4_ms': 'host API, pageable buffers, PCIe inclusive: one cfg2 signal, the cfg4 batch',
-    'proj_N1_us / proj_N8_us / proj_copy_N8_us / proj_speedup': 'one-GPU projection of the cfg4 strong cut: a rank\'s pass at N = 1 and N = 8, a copy of the N = 8 shard, N1 / N8',
-    'worst_parity_over_pools': 'fast mode: the worst stream of every timed secondary pool against the exact kernel, of the pool\'s peak',
     'single_us': 'one cfg2 signal per launch, device resident: launch to synchronise, median (fast mode)',
-    'cfg4_strong': 'this run\'s ranks on the 1024 x 1 s batch: max-over-ranks ms per pass, whole-job Msamples/s',
+    '<leg>_W / <leg>_MHz': 'board power and shader clock under that leg\'s kernel (hwmon, median of the second half of 0.6 s of launches)',
 }
+
+# the order of `config`: the driver's parsed record keeps the FIRST 24 keys - what the north star asks about comes first
+COMPACT_ORDER = ('workload', 'pool', 'frames', 'channels', 'mode', 'parity', 'world_size', 'ranks_seen', 'backend', 'cfg4_strong', 'proj_speedup', 'proj_N1_us',
+                 'proj_N8_us', 'proj_copy_N8_us', 'exact_frac', 'class_exact_frac', 'cfg3_frac', 'cfg3_fp32_frac', 'cfg5_frac', 'cfg4_frac', 'audio_frac',
+                 'worst_parity_over_pools', 'cfg3_exact_frac', 'cfg5_exact_frac')
 
 
 def compact(d: dict) -> dict:
     """The stdout line: the contract's keys plus one short numeric key per claim, all under `config`, `roofline` and
     `cpu_baseline` (which the driver's record keeps whole), no string above 120 characters."""
-    r4 = lambda v: None if v is None else round(float(v), 4)
     cfg, roof, sec, nxt = d['config'], d['roofline'], d.get('secondary') or {}, d.get('next_rows') or {}
     c = {'workload': f"cfg2: 48 kHz stereo f32, 10 s, 30 taps / 30 ms, seed 1; pool of {cfg['pool_signals_per_gpu']} signals per GPU, one launch per step",
          'pool': cfg['pool_signals_per_gpu'], 'frames': cfg['frames'], 'channels': cfg['channels'], 'mode': cfg['arithmetic'],
@@ -758,6 +808,12 @@ def compact(d: dict) -> dict:
          'ranks_seen': cfg['ranks_seen_by_all_reduce'],
          'exact_ms': dig(d, 'exact_mode', 'kernel_ms'), 'exact_frac': dig(d, 'exact_mode', 'frac_of_8TBs'),
          'class_exact_frac': dig(d, 'exact_mode', 'class_path_table', 'frac_of_8TBs')}
+
+    def board(prefix, rec):
+        if isinstance(rec, dict) and rec.get('power_W') is not None:
+            c[prefix + '_W'], c[prefix + '_MHz'] = round(rec['power_W']), rec.get('sclk_MHz')
+    board('exact', dig(d, 'exact_mode', 'board'))
+    board('class_exact', dig(d, 'exact_mode', 'class_path_table', 'board'))
     worst = None
     for name, short in (('cfg3', 'cfg3'), ('cfg3_kappa1', 'cfg3k1'), ('cfg5', 'cfg5'), ('cfg4', 'cfg4')):
         rec = sec.get(name) or {}
@@ -771,25 +827,38 @@ def compact(d: dict) -> dict:
         c[short + '_frac'] = rec.get('frac_of_8TBs')
         if short == 'cfg3':
             c['cfg3_fp32_frac'] = rec.get('frac_of_fp32_vector_peak')
-        if rec.get('board'):
-            c[short + '_W'], c[short + '_MHz'] = rec['board']['power_W'], rec['board']['sclk_MHz']
+        board(short, rec.get('board'))
         if 'exact_mode' in rec:
             c[short + '_exact_frac'] = dig(rec, 'exact_mode', 'frac_of_8TBs')
+            board(short + '_exact', dig(rec, 'exact_mode', 'board'))
         if rec.get('parity_max_over_pool') is not None:
             worst = max(worst or 0.0, rec['parity_max_over_pool'])
+            c[short + '_parity'] = float(f"{rec['parity_max_over_pool']:.3g}")
     if worst is not None:
         c['worst_parity_over_pools'] = float(f'{worst:.3g}')
+    audio = d.get('audio') or {}
+    if 'error' in audio:
+        c['audio_error'] = audio['error'][:100]
+    for label, short in (('fast', 'audio'), ('exact', 'audio_exact')):
+        if dig(audio, label, 'frac_of_8TBs') is not None:
+            c[short + '_frac'] = audio[label]['frac_of_8TBs']
+            board(short, audio[label].get('board'))
     for pool in (256, 128):
         for label, short in (('exact', 'exact'), ('fast_fused', 'fast')):
             v = dig(nxt, 'f1_pool', f'pool{pool}_{label}', 'frac_of_8TBs')
             if v is not None:
                 c[f'f1_{pool}_{short}_frac'] = v
+                board(f'f1_{pool}_{short}', dig(nxt, 'f1_pool', f'pool{pool}_{label}', 'board'))
     for key, path in (('f1_c8_frac', ('f1_c8', 'fast_fused', 'frac_of_8TBs')), ('f1_c8_exact_frac', ('f1_c8', 'exact', 'frac_of_8TBs')),
                       ('m2s_frac', ('mono_to_stereo_fast', 'frac_of_8TBs')), ('m2s_exact_frac', ('mono_to_stereo_fast', 'exact_mode', 'frac_of_8TBs')),
                       ('scan_ms', ('f3_grid_scan', 'ms_host_to_host')), ('chain_ms', ('f4_resident_chain', 'ms_host_to_host'))):
         v = dig(nxt, *path)
         if v is not None:
             c[key] = v
+    board('f1_c8', dig(nxt, 'f1_c8', 'fast_fused', 'board'))
+    board('f1_c8_exact', dig(nxt, 'f1_c8', 'exact', 'board'))
+    board('m2s', dig(nxt, 'mono_to_stereo_fast', 'board'))
+    board('m2s_exact', dig(nxt, 'mono_to_stereo_fast', 'exact_mode', 'board'))
     for key, path in (('e2e_cfg2_ms', ('cfg2_one_signal', 'pageable', 'ms_per_call')), ('e2e_cfg4_ms', ('cfg4_batch', 'pageable', 'ms_per_call'))):
         v = dig(d, 'end_to_end', *path)
         if v is not None:
@@ -805,6 +874,10 @@ def compact(d: dict) -> dict:
         st = d['cfg4_strong']
         c['cfg4_strong'] = {k: st.get(k) for k in ('ranks', 'streams_on_rank0', 'ms_per_pass_max_over_ranks', 'Msamples_s')}
     c['detail'] = 'bench_detail.json; stderr'
+    # what matters most first (COMPACT_ORDER), the rest as gathered, the *_W / *_MHz readings last
+    rest = [k for k in c if k not in COMPACT_ORDER]
+    ordered = [k for k in COMPACT_ORDER if k in c] + [k for k in rest if not k.endswith(('_W', '_MHz'))] + [k for k in rest if k.endswith(('_W', '_MHz'))]
+    c = {k: c[k] for k in ordered}
     line = {k: d[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
                               'dtype', 'data')}
     line['config'] = c
@@ -950,6 +1023,7 @@ def main():
         e_elapsed, e_kernel_ms = timed(vnd.MODE_EXACT, max(args.steps // 2, 1), 2)
         if rank == 0:
             assert np.array_equal(y[args.pool - 1].cpu().numpy(), want), 'exact mode differs from the oracle'
+            exact_board = board_under(torch, power, lambda k: run(vnd.MODE_EXACT))
             # the class path's table (VelvetNoise.convolve: every weight +-1, segment gains; decorrelation.py:393-415) in the
             # same bit-exact mode on the same pool: one packed add per tap, per-table kernel built by default
             cls_info = None
@@ -969,6 +1043,7 @@ def main():
                 c1.record()
                 torch.cuda.synchronize()
                 c_ms = c0.elapsed_time(c1) / reps
+                cls_board = board_under(torch, power, lambda k: run_cls())
                 from oracle import vnd_oracle as O
                 taps = O.generate_class_taps(sample_rate_hz=SAMPLE_RATE, seed=1)
                 want_cls = O.class_convolve(xs, taps, (0.85, 0.55, 0.35, 0.2), 2)
@@ -976,13 +1051,14 @@ def main():
                 cls_info = {'kernel_ms': round(c_ms, 4),
                             'achieved_GBs': round(ALGO_BYTES_PER_SAMPLE * samples_per_step / (c_ms * 1e-3) / 1e9, 1),
                             'frac_of_8TBs': round(ALGO_BYTES_PER_SAMPLE * samples_per_step / (c_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            'board': cls_board,
                             'launch': cls_table.describe(args.pool, n, CHANNELS, vnd.MODE_EXACT)}
             except Exception as exc:
                 cls_info = {'error': repr(exc)}
             exact_info = {'kernel_ms': round(e_kernel_ms, 4),
                           'achieved_GBs': round(ALGO_BYTES_PER_SAMPLE * samples_per_step / (e_kernel_ms * 1e-3) / 1e9, 1),
                           'frac_of_8TBs': round(ALGO_BYTES_PER_SAMPLE * samples_per_step / (e_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                          'warmup_actual': warmups[-1],
+                          'warmup_actual': warmups[-1], 'board': exact_board,
                           'parity': 'bit-identical to the oracle (sha-checked in tests)',
                           'launch': table.describe(args.pool, n, CHANNELS, vnd.MODE_EXACT),
                           'class_path_table': cls_info}
@@ -1057,7 +1133,7 @@ def main():
     torch.cuda.empty_cache()
 
     strong = None
-    if not args.no_strong:
+    if not (args.no_strong or args.no_secondary):           # (--no-secondary: the headline alone)
         strong = cfg4_strong(torch, dist, vnd, _native, ctx, image, mode, world, rank, device, args.backend,
                              taps=(arrays.tap_offsets, arrays.tap_index, arrays.tap_weight) if rank == 0 else None)
 
@@ -1113,8 +1189,8 @@ def main():
                                                 'non-temporal loads and stores; device_copy_GBs is torch\'s Tensor.copy_): what a '
                                                 'kernel that reads 4 B and writes 4 B per sample can reach on this box',
 
-                         'limit': 'board power cap (1400 W; the shader clock falls to ~1.9 GHz under this kernel: '
-                                  'profiles/r03_cfg2_power.txt), DESIGN.md 3.5',
+                         'limit': 'board power cap (`power`: watts and shader clock under this kernel and under the plain copy, this run) on boxes whose copy '
+                                  'runs 6.4-6.6 TB/s, HBM itself on boxes whose copy runs 5.6 TB/s (`frac_of_streaming_copy`): DESIGN.md 3.4',
                          'power': power_info,
                          'algorithmic_bytes_per_launch': ALGO_BYTES_PER_SAMPLE * samples_per_step},
         }
@@ -1126,7 +1202,11 @@ def main():
                 detail['end_to_end'] = end_to_end(torch, vnd, mode)
             except Exception as exc:                    # as above: never at the headline's expense
                 detail['end_to_end'] = {'error': repr(exc)}
-            detail['next_rows'] = next_rows(torch, vnd, _native)
+            try:
+                detail['audio'] = audio_leg(torch, vnd, _native, ctx, args.pool, power)
+            except Exception as exc:
+                detail['audio'] = {'error': repr(exc)}
+            detail['next_rows'] = next_rows(torch, vnd, _native, power)
         if power is not None:
             power.close()
         if world == 1 and not args.no_cpu:
@@ -1144,7 +1224,12 @@ def main():
         print(json.dumps(detail), file=sys.stderr, flush=True)
         line = compact(detail)
         text = json.dumps(line, separators=(',', ':'))
-        assert len(text) < 4096, f'the bench line grew to {len(text)} bytes: the driver keeps a tail'
+        if len(text) >= 4096:                            # the driver keeps a tail: shed the least important keys rather than lose the run
+            print(f'bench.py: the line grew to {len(text)} bytes; dropping trailing config keys', file=sys.stderr)
+            keys = list(line['config'])
+            while len(text) >= 4096 and len(keys) > 12:
+                line['config'].pop(keys.pop())
+                text = json.dumps(line, separators=(',', ':'))
         print(text, flush=True)
     if world > 1:
         dist.destroy_process_group()

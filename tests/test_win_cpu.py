@@ -271,9 +271,11 @@ def test_window_reads_fewer_lds_bytes_than_a_read_per_tap(native, golden):
     assert per['g48k_k30', 16] > per['g48k_k30', 32] > per['g48k_k30', 64]
 
 
+@pytest.mark.parametrize('adds', [1, 0])
 @pytest.mark.parametrize('gname,M,nt', [('g48k_k30', 32, 256), ('g48k_k128_u', 32, 128)])
-def test_window_source_compiles_for_gfx950_with_the_intended_isa(native, golden, tmp_path, gname, M, nt):
+def test_window_source_compiles_for_gfx950_with_the_intended_isa(native, golden, tmp_path, gname, M, nt, adds, monkeypatch):
     offs, idx, w = _table(golden.fir(gname))
+    monkeypatch.setenv('VND_WIN_ADDS', str(adds))
     src = native.window_kernel_source(offs, idx, w, 2, M, nt)
     f = tmp_path / 'k.hip'
     f.write_text(src)
@@ -287,11 +289,20 @@ def test_window_source_compiles_for_gfx950_with_the_intended_isa(native, golden,
     count = {o: ops.count(o) for o in set(ops)}
     assert count.get('flat_load_dwordx4', 0) == 0, 'LDS reads fell back to flat loads'
     taps = len(idx)
-    # a tap costs M/2 packed FMAs when its offset is even, M/2 - 1 packed + 2 single ones when odd; the first
-    # product of an accumulator is a multiply
+    # a tap costs M/2 packed operations when its offset is even, M/2 - 1 packed + 2 single ones when odd
     odd = int((idx & 1).sum())
-    packed = count['v_pk_fma_f32'] + count.get('v_pk_mul_f32', 0)
-    assert taps * (M // 2) - odd - 16 <= packed <= taps * (M // 2) - odd        # (hipcc may split a few first products)
+    if adds:
+        # the reference's class-path association (decorrelation.py:402-414): a v_pk_add_f32 per (tap, output pair) inside a run of
+        # equal |w| - the sign is a source modifier - a v_pk_fma_f32 (sum x gain ratio +- x) where a chain meets the next |w|, and one
+        # v_pk_mul_f32 per finished output pair: the table's 4 gains make 3 FMAs per chain of E / P accumulators
+        chains = 2 * (M // 2 + M // 2 - 1)
+        assert count['v_pk_fma_f32'] <= 3 * chains + 8 and count['v_pk_mul_f32'] == 2 * (M // 2)
+        assert taps * (M // 2) - odd - 3 * chains - 16 <= count['v_pk_add_f32'] <= taps * (M // 2) - odd - 3 * chains + 2 * (M // 2)      # (+ the merge, where hipcc packs it)
+        assert 'neg_lo:[0,1] neg_hi:[0,1]' in asm or 'neg_lo:[1,0] neg_hi:[1,0]' in asm
+    else:
+        # one FMA per tap; the first product of an accumulator is a multiply
+        packed = count['v_pk_fma_f32'] + count.get('v_pk_mul_f32', 0)
+        assert taps * (M // 2) - odd - 16 <= packed <= taps * (M // 2) - odd        # (hipcc may split a few first products)
     assert count['s_barrier'] == 3                        # the prologue's and the two of a tile
     # one 16-byte read per chunk of the union of the windows, each an immediate offset from a base register
     n_reads = len(re.findall(r'q\[\d+\] = VW_RD\(', src))

@@ -38,7 +38,8 @@ vnd_status vnd_ctx_create(int32_t device, vnd_ctx **out)
     vnd_ctx *c = new (std::nothrow) vnd_ctx;
     if (!c) return fail(VND_ERR_NOMEM, "out of host memory");
     c->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&c->prop, device) != hipSuccess) {
+    DeviceScope on(device);                       // (the caller's current device is the caller's: restored on every way out)
+    if (!on.ok || hipGetDeviceProperties(&c->prop, device) != hipSuccess) {
         delete c;
         return fail(VND_ERR_HIP, "cannot open device %d", device);
     }
@@ -78,7 +79,7 @@ vnd_status vnd_ctx_create(int32_t device, vnd_ctx **out)
 vnd_status vnd_ctx_destroy(vnd_ctx *c)
 {
     if (!c) return VND_OK;
-    (void)hipSetDevice(c->device);
+    DeviceScope on(c->device);
     if (c->scratch_x) (void)hipFree(c->scratch_x);
     if (c->scratch_y) (void)hipFree(c->scratch_y);
     if (c->work) (void)hipFree(c->work);
@@ -162,7 +163,8 @@ vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, 
 
     std::vector<Tap> packed((size_t)total);
     for (int32_t k = 0; k < total; ++k) { packed[k].idx = tap_index[k]; packed[k].w = tap_weight[k]; }
-    hipError_t e = hipSetDevice(ctx->device);
+    DeviceScope on(ctx->device);
+    hipError_t e = on.ok ? hipSuccess : hipErrorInvalidDevice;
     if (e == hipSuccess) e = upload(&t->d_taps, packed.data(), (size_t)total);
     // fast-mode image: per channel the even-offset taps, then the odd-offset ones;
     // idx <- LDS byte offset (i & ~1) * 4, w <- weight * segment gain; 16 zero records of
@@ -240,7 +242,7 @@ vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, 
 vnd_status vnd_taps_destroy(vnd_taps *t)
 {
     if (!t) return VND_OK;
-    (void)hipSetDevice(t->ctx->device);
+    DeviceScope on(t->ctx->device);
     free_taps_dev(t);
     for (auto &kv : t->spec_modules)
         if (kv.second && kv.second->module) (void)hipModuleUnload(kv.second->module);
@@ -341,10 +343,11 @@ static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64
                 else snprintf(split, sizeof split, "%d spans x %d tiles", sp.spans, sp.tiles_per_span);
                 snprintf(text, (size_t)len,
                          "conv_spec%s_window (hipRTC, per table) frames_per_lane=%d tile=%d reads_ahead=%d "
-                         "nt_stores=%d mode=%d lds=%zuB workgroups=%u (%u units: %s per stream) threads=%d store_phase=%s",
+                         "nt_stores=%d mode=%d lds=%zuB workgroups=%u (%u units: %s per stream) threads=%d store_phase=%s%s",
                          sp.cfg.exact ? "_exact" : "", sp.cfg.win, sp.cfg.tile(), sp.cfg.la, sp.cfg.nt_stores, mode,
                          sp.cfg.lds_bytes(), sp.nblocks, sp.units, split, sp.cfg.nt,
-                         sp.cfg.win_s ? "planar waves=split-by-channel" : sp.cfg.win_q == 2 ? "planar pieces=channel-octets waves=split-by-channel" : (sp.cfg.win_q ? "planar pieces=channel-quads waves=split-by-channel" : (sp.cfg.win_xpose ? "frame-pairs" : "planar")));
+                         sp.cfg.win_s ? "planar waves=split-by-channel" : sp.cfg.win_q == 2 ? "planar pieces=channel-octets waves=split-by-channel" : (sp.cfg.win_q ? "planar pieces=channel-quads waves=split-by-channel" : (sp.cfg.win_xpose ? "frame-pairs" : "planar")),
+                         sp.cfg.adds ? " taps=adds-per-segment" : "");
                 return VND_OK;
             }
             snprintf(text, (size_t)len,

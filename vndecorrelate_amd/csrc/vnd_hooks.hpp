@@ -169,6 +169,7 @@ vnd_status vnd_window_kernel_source(int32_t C, const int32_t *tap_offsets, const
     cfg.win_xpose = spec_env("VND_WIN_XPOSE_PAIRS", 1) != 0 ? 1 : 0;
     cfg.exact = mode == VND_MODE_EXACT ? 1 : 0;
     cfg.bc = bc ? 1 : 0;
+    cfg.adds = (!cfg.exact && spec_env("VND_WIN_ADDS", 1) != 0 && win_adds_ok(t)) ? 1 : 0;      // (as make_spec_plan)
     // (VND_WIN_SOURCE_EPI=1: with the decorrelate stage's steps in the store phase - stereo: pointwise steps and block sums; quads /
     //  octets, fast mode: the normaliser's sums)
     cfg.epi = (spec_env("VND_WIN_SOURCE_EPI", 0) != 0 && !bc && !split && (C == 2 || quad)) ? 1 : 0;
@@ -198,10 +199,13 @@ vnd_status vnd_code_object_private_bytes(const void *code, int64_t bytes, const 
 vnd_status vnd_tuning_read(const char *name, int32_t fallback, int32_t *value)
 {
     if (!name || !value) return fail(VND_ERR_INVALID, "null name or value pointer");
-    *value = spec_env(name, fallback);
-    const vnd_status st = tuning_status();                 // (formats the name into vnd_last_error now: the pointer is the caller's)
-    spec_unregistered_name().store(nullptr);
-    return st;
+    // (the caller's pointer never reaches the process-wide record of spec_env: that one holds pointers into the library's own
+    //  literals only, and another thread's launch may be reading it - or have just written its own finding - right now)
+    const char *known = nullptr;
+    for (const char *k : kTuningNames) if (strcmp(k, name) == 0) known = k;
+    if (!known) { *value = fallback; return fail(VND_ERR_INVALID, "'%.64s' is not a registered tuning variable (kTuningNames, csrc/vnd_spec.hpp)", name); }
+    *value = spec_env(known, fallback);
+    return VND_OK;
 }
 
 vnd_status vnd_set_variant(vnd_ctx *ctx, int32_t variant)

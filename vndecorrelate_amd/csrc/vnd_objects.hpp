@@ -27,6 +27,22 @@
 
 using namespace vnd;
 
+// Every entry point works on its context's device whatever the caller's current device is, and leaves the caller's current
+// device as it found it (a torch user's next allocation must not land on another GPU because this library was called).
+struct DeviceScope {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceScope(int dev)
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); ok = hipSetDevice(dev) == hipSuccess; return; }
+        if (cur != dev) { ok = hipSetDevice(dev) == hipSuccess; if (ok) prev = cur; }
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+
 // ------------------------------------------------------------------------------
 // errors
 // ------------------------------------------------------------------------------

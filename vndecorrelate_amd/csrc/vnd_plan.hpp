@@ -321,6 +321,7 @@ struct EpiFuse {                 // non-null => launch the fused-epilogue instan
     // blk_sum (rows_major); *rows = rows per stream it writes.  spec_only: launch nothing if the per-table kernel does not take it
     // (*path stays 0: the caller goes on with its unfused passes)
     int *rows = nullptr;
+    int rows_max = 0;            // rows per stream the caller's workspace has room for: a plan that would write more is refused BEFORE anything runs
     bool spec_only = false;
 };
 
@@ -356,6 +357,9 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
         if (off) { p.why = "exact mode specialisation switched off"; return p; }
     }
     const bool force = v >= 0 && ((v >> 23) & 1);
+    // the fast mode's window forms in the reference's class-path association (adds inside a segment, the gain ratio once per segment:
+    // vnd_win.hpp, win_adds_ok) wherever the table has few distinct |w| - every generated table has; VND_WIN_ADDS=0: one FMA per tap
+    const int adds_now = (mode == VND_MODE_FAST && spec_env("VND_WIN_ADDS", 1) != 0 && win_adds_ok(t->spec_table)) ? 1 : 0;
     if (spec_disabled_by_env() || (v >= 0 && ((v >> 25) & 1))) { p.why = "disabled"; return p; }
     // access shape: 16 bytes per frame pair (stereo) or 8 per frame, from every stream's first sample
     const uintptr_t align = C == 2 ? 16 : 8, align_x = bc ? 8 : align;
@@ -403,6 +407,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     auto rejected = [&](const SpecConfig &c0) {
         SpecConfig c = c0;
         c.nt_stores = nt_stores_of(c0); c.exact = mode == VND_MODE_EXACT ? 1 : 0; c.epi = pointwise ? 1 : 0; c.bc = bc ? 1 : 0;
+        c.adds = c0.win ? adds_now : 0;
         std::lock_guard<std::mutex> g(const_cast<vnd_taps *>(t)->spec_mutex);
         auto it = t->spec_modules.find(c);
         return it != t->spec_modules.end() && !it->second->building && it->second->failed;
@@ -489,10 +494,20 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     per_span = std::min(per_span, max_tiles);
     spans = (tiles_total + per_span - 1) / per_span;
     if (units * spans > 0x7fffffffLL) { p.why = "grid too large"; return p; }
+    // the fused fast stage of a 4k-channel table: the store phase writes a row of sums per (tile, wave of a channel) into the caller's
+    // workspace - a geometry with more rows than that has room for (several waves per channel on a short signal) is not taken: the
+    // caller's unfused passes run instead (spec_only), nothing is written past the rows
+    if (sums_q && epi->rows_major && epi->rows_max > 0 &&
+        tiles_total * std::max<int64_t>(1, p.cfg.nt / 64 / (4 * std::max(1, p.cfg.win_q))) > (int64_t)epi->rows_max) {
+        p.use = false;
+        p.why = "the store phase's rows of sums do not fit the caller's workspace";
+        return p;
+    }
     p.cfg.nt_stores = nt_stores_of(p.cfg);
     p.cfg.exact = mode == VND_MODE_EXACT ? 1 : 0;
     p.cfg.epi = pointwise ? 1 : 0;
     p.cfg.bc = bc ? 1 : 0;
+    p.cfg.adds = p.cfg.win ? adds_now : 0;
     // exact mode counts VS_LA in steps of RR to 2*RR reads: the LDS queue holds 15, three steps fill it
     if (p.cfg.exact && !p.cfg.win && spec_env("VND_SPEC_LA", -1) < 0) p.cfg.la = 3;
     p.tiles_total = (int)tiles_total; p.tiles_per_span = (int)per_span; p.spans = (int)spans;

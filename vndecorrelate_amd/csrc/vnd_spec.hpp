@@ -51,6 +51,7 @@ struct SpecConfig {
     int win_xpose = 0; // the store phase transposes through LDS as interleaved frame pairs (1) or as planar chunks (0: fewer registers)
     int win_q = 0;     // window form on channel QUADS (1: signals of 4k channels, a quarter of the workgroup's lanes per channel) or OCTETS (2: 8k channels, an eighth)
     int win_s = 0;     // window form with the waves SPLIT over the two channels of a stereo signal
+    int adds = 0;      // window form, fast mode: adds inside a run of equal |w|, the gain ratio once where |w| changes (vnd_win.hpp: win_adds_ok)
     int tile() const { return win ? (win_s ? nt / 2 : (win_q ? nt / (4 * win_q) : nt)) * win : 2 * nt * rr; }
     size_t lds_bytes() const
     {
@@ -60,8 +61,8 @@ struct SpecConfig {
     }
     bool operator<(const SpecConfig &o) const
     {
-        return std::tie(nt, rr, pp, dd, la, nt_stores, exact, epi, bc, shift, win, win_g, win_xpose, win_q, win_s) <
-               std::tie(o.nt, o.rr, o.pp, o.dd, o.la, o.nt_stores, o.exact, o.epi, o.bc, o.shift, o.win, o.win_g, o.win_xpose, o.win_q, o.win_s);
+        return std::tie(nt, rr, pp, dd, la, nt_stores, exact, epi, bc, shift, win, win_g, win_xpose, win_q, win_s, adds) <
+               std::tie(o.nt, o.rr, o.pp, o.dd, o.la, o.nt_stores, o.exact, o.epi, o.bc, o.shift, o.win, o.win_g, o.win_xpose, o.win_q, o.win_s, o.adds);
     }
 };
 
@@ -89,7 +90,7 @@ static const char *const kTuningNames[] = {
     "VND_SPEC_NT", "VND_SPEC_RR", "VND_SPEC_DD", "VND_SPEC_LA", "VND_SPEC_SHIFT", "VND_SPEC_QUAD_STORES", "VND_WIN_M", "VND_WIN_G", "VND_WIN_QUAD_M",
     "VND_WIN_SPLIT_LATE", "VND_WIN_SPLIT_SMALL_NT", "VND_WIN_TAIL",
     // which form runs
-    "VND_WIN_EXACT", "VND_WIN_QUAD", "VND_WIN_OCTET", "VND_WIN_WIDE", "VND_WIN_SPLIT", "VND_WIN_SPLIT_FANOUT", "VND_WIN_XPOSE_PAIRS", "VND_WIN_FAR_FIRST",
+    "VND_WIN_EXACT", "VND_WIN_QUAD", "VND_WIN_OCTET", "VND_WIN_WIDE", "VND_WIN_SPLIT", "VND_WIN_SPLIT_FANOUT", "VND_WIN_XPOSE_PAIRS", "VND_WIN_FAR_FIRST", "VND_WIN_ADDS",
     "VND_WIN_SOURCE_FANOUT", "VND_WIN_SOURCE_EPI", "VND_EPI_BLOCK_SUMS", "VND_EPI_WIDE", "VND_EPI_SEQ_SPLIT",
     // one-round launches, pacing, priorities, cache policies
     "VND_WIN_CHUNKS", "VND_WIN_CHUNK_LEN0", "VND_WIN_STAGGER_TICKS", "VND_WIN_PACE", "VND_WIN_PACE_MIN_TILES", "VND_WIN_PRIO", "VND_SPEC_LOAD_AUX",

@@ -107,7 +107,7 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
         ctx->variant_nofuse == 0 && spec_env("VND_EPI_BLOCK_SUMS", 1) != 0) {
         int rows_q = 0;
         EpiFuse f{(double *)workspace, 0, 0, e.normalize, e.w_mid, e.w_side};
-        f.path = &conv_path; f.blk_sum = (double *)workspace; f.rows_major = 1; f.rows = &rows_q; f.spec_only = true;
+        f.path = &conv_path; f.blk_sum = (double *)workspace; f.rows_major = 1; f.rows = &rows_q; f.rows_max = (int)std::min<int64_t>(epi_rows_max(n), INT32_MAX); f.spec_only = true;
         st = launch(ctx, t, x, y, batch, n, C, mode, stream, &f, Cx);
         if (st != VND_OK) return st;
         if (conv_path == 1 && rows_q > 0 && rows_q <= epi_rows_max(n)) { e.rows = rows_q; q_done = true; }
@@ -246,7 +246,8 @@ static vnd_status decorrelate_host(vnd_ctx *ctx, const vnd_taps *t, const float 
     if (batch == 0 || n == 0) return VND_OK;
     if (!x || !y) return fail(VND_ERR_INVALID, "null signal pointer");
     HostLock lock(ctx->host_mutex);
-    HIP_TRY(hipSetDevice(ctx->device));
+    DeviceScope on(ctx->device);
+    if (!on.ok) return fail(VND_ERR_HIP, "cannot select device %d", ctx->device);
     const size_t in_elems = (size_t)batch * n * Cx, out_elems = (size_t)batch * n * C;
     st = ensure_scratch(ctx, out_elems);
     if (st != VND_OK) return st;
@@ -341,7 +342,8 @@ vnd_status vnd_convolve_promote_host(vnd_ctx *ctx, int32_t C, const int32_t *tap
     if (total == 0) return VND_OK;
     if (!x || !y) return fail(VND_ERR_INVALID, "null signal pointer");
     HostLock lock(ctx->host_mutex);
-    HIP_TRY(hipSetDevice(ctx->device));
+    DeviceScope on(ctx->device);
+    if (!on.ok) return fail(VND_ERR_HIP, "cannot select device %d", ctx->device);
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t xb = (size_t)total * (x_is_f64 ? 8 : 4), yb = (size_t)total * 4;
     const size_t wb = (size_t)taps * 8, ob = (size_t)(C + 1) * 4, ib = (size_t)taps * 4;
@@ -423,7 +425,8 @@ vnd_status vnd_scan_bank_f32_host(vnd_ctx *ctx, const vnd_taps *t, const float *
     if (!moments || (n > 0 && !x)) return fail(VND_ERR_INVALID, "null pointer");
     const int32_t pairs = t->C / 2;
     HostLock lock(ctx->host_mutex);
-    HIP_TRY(hipSetDevice(ctx->device));
+    DeviceScope on(ctx->device);
+    if (!on.ok) return fail(VND_ERR_HIP, "cannot select device %d", ctx->device);
     // Fused form: the convolution kernel's store phase reduces each tile to the eight moments per
     // candidate (KArgs.sink_partials) - the [n][2F] output, 1.6 GB there and back for 400 candidates
     // of a 5.7 s signal, is never written.  Needs the two-channels-per-workgroup epilogue instantiation.
@@ -516,7 +519,8 @@ vnd_status vnd_haas_f64_host(vnd_ctx *ctx, const float *x, double *y, int64_t ba
     if (batch == 0 || total == 0) return VND_OK;
     if (!y || (n > 0 && !x)) return fail(VND_ERR_INVALID, "null signal pointer");
     HostLock lock(ctx->host_mutex);
-    HIP_TRY(hipSetDevice(ctx->device));
+    DeviceScope on(ctx->device);
+    if (!on.ok) return fail(VND_ERR_HIP, "cannot select device %d", ctx->device);
     const size_t in_bytes = (size_t)batch * n * in_channels * sizeof(float);
     const size_t out_bytes = (size_t)batch * total * 2 * sizeof(double);
     st = ensure_work(ctx, out_bytes + std::max<size_t>(in_bytes, 16));

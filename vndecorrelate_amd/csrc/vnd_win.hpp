@@ -122,7 +122,7 @@ inline int win_workgroups_per_cu(const WinGeom &g)
     return std::max(1, std::min(by_lds, by_regs));
 }
 
-struct WinOp { int kind, acc, half; float w; };          // kind 0: E pair, 1: P pair, 2: O0 (second element of the half), 3: OL (first)
+struct WinOp { int kind, acc, half; float w; int tap; };  // kind 0: E pair, 1: P pair, 2: O0 (second element of the half), 3: OL (first); tap: its offset
 struct WinRead { int ch, o; std::vector<WinOp> ops; };
 
 // the read schedule of one channel: chunks in ascending order, each with the FMAs it feeds (taps ascending inside)
@@ -142,11 +142,11 @@ inline std::vector<WinRead> win_schedule(const SpecTable &t, int ch, int M)
             for (int h = 0; h < 2; ++h) {
                 const int j = o + 2 * h - i;
                 if ((i & 1) == 0) {
-                    if (j >= 0 && j <= M - 2) rd.ops.push_back(WinOp{0, j / 2, h, tp.second});
+                    if (j >= 0 && j <= M - 2) rd.ops.push_back(WinOp{0, j / 2, h, tp.second, i});
                 } else {
-                    if (j >= 1 && j <= M - 3) rd.ops.push_back(WinOp{1, (j - 1) / 2, h, tp.second});
-                    else if (j == -1) rd.ops.push_back(WinOp{2, 0, h, tp.second});
-                    else if (j == M - 1) rd.ops.push_back(WinOp{3, 0, h, tp.second});
+                    if (j >= 1 && j <= M - 3) rd.ops.push_back(WinOp{1, (j - 1) / 2, h, tp.second, i});
+                    else if (j == -1) rd.ops.push_back(WinOp{2, 0, h, tp.second, i});
+                    else if (j == M - 1) rd.ops.push_back(WinOp{3, 0, h, tp.second, i});
                 }
             }
         }
@@ -198,7 +198,35 @@ inline std::string win_rd(const WinGeom &g, int ch, int o)
     return buf;
 }
 
-inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int la, int pg = 0, int only_ch = -1)
+// ---- VND_MODE_FAST in the reference's CLASS-PATH association: adds inside a segment, one multiply per segment -------------
+// VelvetNoise.convolve adds and subtracts x[n + i] per segment and multiplies the segment's sum by its gain once
+// (decorrelation.py:402-414); every generated table has at most len(segment_envelope) distinct |w| (:621-625, :539-542).  Under the
+// board's power cap a launch's time is its energy, and a v_pk_add_f32 costs less of it than a v_pk_fma_f32: the same window reads
+// sustain 12-16 % more packed adds than packed FMAs per second on random data (tools/micro/lds_power.hip, profiles/r06_lds_power.txt).
+// So an accumulator holds its partial sum in UNITS of the gain g of the taps it is taking:
+//     same |w| as the last tap:   acc = acc +- x                       v_pk_add_f32, the sign a neg_lo / neg_hi modifier
+//     another |w| = g':           acc = fma(acc, g / g', +-x)          the one multiply per segment, riding in an FMA
+//     first tap:                  acc = 0 +- x
+// and the lane's finished outputs are multiplied by the last unit (one v_pk_mul_f32 per output pair).  The chunks still arrive from
+// the FAR end of the window, and inside a chunk the taps now descend too, so a chain walks the segments far to near and changes its
+// unit once per segment.  Every output is fl(fl(E + O) * g): a function of the table and of the output's position alone, as before.
+inline bool win_adds_ok(const SpecTable &t)
+{
+    std::vector<float> mags;
+    for (size_t k = 0; k < t.w.size(); ++k) {
+        const float m = std::fabs(t.w[k]);
+        if (m == 0.0f) continue;
+        if (!std::isfinite(m) || m < 1e-18f || m > 1e18f) return false;         // (every ratio of two gains a normal float32)
+        if (std::find(mags.begin(), mags.end(), m) == mags.end()) mags.push_back(m);
+        if (mags.size() > 8) return false;
+    }
+    return !mags.empty();
+}
+
+// the ratio that takes a sum from units of `from` to units of `to`, rounded once
+inline float win_unit_ratio(float from, float to) { return (float)((double)from / (double)to); }
+
+inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int la, int pg = 0, int only_ch = -1, bool adds = false)
 {
     const int M = g.M;
     std::string s;
@@ -206,6 +234,7 @@ inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int l
     const std::string fname = only_ch < 0 ? win_taps_name(pg) : win_taps_channel_name(pg, only_ch);
     s += "__device__ __forceinline__ void " + fname + "(vw_lchar *const (&b)[2][VW_NBT], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
     spec_append(s, "    v4f q[%d];\n    v2f E[%d], P[%d];\n    float O0, OL;\n", la + 1, M / 2, M / 2);
+    if (adds) s += "    const v2f Z2 = {0.0f, 0.0f};\n";
     // one read stream over both channels: the pipeline stays full across the channel boundary
     std::vector<WinRead> reads;
     size_t first_of_ch[3] = {0, 0, 0};
@@ -219,6 +248,8 @@ inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int l
         if (only_ch >= 0 && ch != only_ch) continue;
         std::vector<WinRead> one = win_schedule(t, 2 * pg + ch, M);
         if (far_first) std::reverse(one.begin(), one.end());
+        if (adds && far_first)
+            for (WinRead &r : one) std::stable_sort(r.ops.begin(), r.ops.end(), [](const WinOp &a, const WinOp &b) { return a.tap > b.tap; });
         for (WinRead &r : one) { r.ch = ch; reads.push_back(std::move(r)); }      // ch: the LDS plane set
     }
     first_of_ch[2] = reads.size();
@@ -237,16 +268,61 @@ inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int l
             spec_append(s, "    o%d[%d] = %s;\n", ch, j, rhs.c_str());
         }
     };
+    // adds: the merge in units - pair (2k, 2k+1) of the outputs is fl(E + O) times the chains' last unit, one packed multiply per pair
+    // (chains that end in different units - a table whose nearest taps are all of one parity - are scaled one by one first)
+    auto emit_merge_units = [&](int ch, const std::vector<float> &e_unit, const std::vector<float> &p_unit, float o0_unit, float ol_unit) {
+        float common = 0.0f;
+        bool uniform = true;
+        auto see = [&](float u) { if (u == 0.0f) return; if (common == 0.0f) common = u; else if (u != common) uniform = false; };
+        for (float u : e_unit) see(u);
+        for (float u : p_unit) see(u);
+        see(o0_unit); see(ol_unit);
+        for (int j = 0; j < M; ++j) {
+            const float eu = e_unit[j / 2];
+            const float ou = j == 0 ? o0_unit : (j == M - 1 ? ol_unit : p_unit[(j - 1) / 2]);
+            std::string ev = eu != 0.0f ? ("E[" + std::to_string(j / 2) + "]." + ((j & 1) ? "y" : "x")) : std::string();
+            std::string ov;
+            if (ou != 0.0f) ov = j == 0 ? std::string("O0") : (j == M - 1 ? std::string("OL") : "P[" + std::to_string((j - 1) / 2) + "]." + ((j & 1) ? "x" : "y"));
+            if (!uniform) {
+                if (!ev.empty()) ev = "(" + ev + " * " + spec_float(eu) + ")";
+                if (!ov.empty()) ov = "(" + ov + " * " + spec_float(ou) + ")";
+            }
+            const std::string rhs = ev.empty() ? (ov.empty() ? std::string("0.0f") : ov) : (ov.empty() ? ev : ev + " + " + ov);
+            spec_append(s, "    o%d[%d] = %s;\n", ch, j, rhs.c_str());
+        }
+        if (uniform && common != 0.0f && common != 1.0f) {
+            const std::string u = spec_float(common);
+            for (int k = 0; k < M / 2; ++k)
+                spec_append(s, "    { const v2f t2 = v2f{o%d[%d], o%d[%d]} * v2f{%s, %s}; o%d[%d] = t2.x; o%d[%d] = t2.y; }\n", ch, 2 * k, ch, 2 * k + 1, u.c_str(), u.c_str(),
+                            ch, 2 * k, ch, 2 * k + 1);
+        }
+    };
     for (size_t k = 0; k < std::min(reads.size(), (size_t)la); ++k) emit_read(k);
     for (int ch = 0; ch < 2; ++ch) {
         if (only_ch >= 0 && ch != only_ch) continue;
         std::vector<char> e_used(M / 2, 0), p_used(M / 2, 0);
         bool o0_used = false, ol_used = false;
+        std::vector<float> e_unit(M / 2, 0.0f), p_unit(M / 2, 0.0f);      // adds: the gain whose units the chain is in (0: not open yet)
+        float o0_unit = 0.0f, ol_unit = 0.0f;
         for (size_t k = first_of_ch[ch]; k < first_of_ch[ch + 1]; ++k) {
             if (k + la < reads.size()) emit_read(k + la);
             const std::string qk = "q[" + std::to_string(k % (size_t)(la + 1)) + "]";
             for (const WinOp &op : reads[k].ops) {
                 const std::string w = spec_float(op.w);
+                if (adds) {
+                    const bool pair = op.kind <= 1, is0 = op.kind == 2;
+                    const std::string acc = pair ? std::string(op.kind == 0 ? "E[" : "P[") + std::to_string(op.acc) + "]" : std::string(is0 ? "O0" : "OL");
+                    const std::string x = pair ? qk + (op.half ? ".zw" : ".xy") : qk + (is0 ? (op.half ? ".w" : ".y") : (op.half ? ".z" : ".x"));
+                    float &unit = pair ? (op.kind == 0 ? e_unit[op.acc] : p_unit[op.acc]) : (is0 ? o0_unit : ol_unit);
+                    const float mag = std::fabs(op.w);
+                    const char sign = std::signbit(op.w) ? '-' : '+';
+                    if (unit == 0.0f) spec_append(s, "    %s = %s %c %s;\n", acc.c_str(), pair ? "Z2" : "0.0f", sign, x.c_str());
+                    else if (unit == mag) spec_append(s, "    %s = %s %c %s;\n", acc.c_str(), acc.c_str(), sign, x.c_str());
+                    else if (pair) spec_append(s, "    %s = VW_FMA(%s, %s, %s%s);\n", acc.c_str(), acc.c_str(), spec_float(win_unit_ratio(unit, mag)).c_str(), sign == '-' ? "-" : "", x.c_str());
+                    else spec_append(s, "    %s = __builtin_fmaf(%s, %s, %s%s);\n", acc.c_str(), acc.c_str(), spec_float(win_unit_ratio(unit, mag)).c_str(), sign == '-' ? "-" : "", x.c_str());
+                    unit = mag;
+                    continue;
+                }
                 if (op.kind <= 1) {
                     const std::string acc = std::string(op.kind == 0 ? "E[" : "P[") + std::to_string(op.acc) + "]";
                     const std::string x = qk + (op.half ? ".zw" : ".xy");
@@ -266,7 +342,8 @@ inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int l
             }
             s += "    VW_SB;\n";
         }
-        emit_merge(ch, e_used, p_used, o0_used, ol_used);
+        if (adds) emit_merge_units(ch, e_unit, p_unit, o0_unit, ol_unit);
+        else emit_merge(ch, e_used, p_used, o0_used, ol_used);
     }
     s += "}\n";
     return s;
@@ -378,12 +455,13 @@ inline void win_traffic_exact(const SpecTable &t, int M, size_t *lds_bytes, size
 // both channels' FMAs: cfg2's table 178 reads per tile and lane instead of 157 + 160, 1.48 B of LDS per FMA instead of 2.64.  Each
 // channel keeps its own E / P chains in the read order of win_taps_function - FAR end of the window first by default (small terms first,
 // VND_WIN_FAR_FIRST), ascending offsets when that is switched off: the results are those of a pass per channel, bit for bit.
-inline std::string win_taps_function_merged(const SpecTable &t, const WinGeom &g, int la, int pg = 0)
+inline std::string win_taps_function_merged(const SpecTable &t, const WinGeom &g, int la, int pg = 0, bool adds = false)
 {
     const int M = g.M;
     std::string s;
     s += "__device__ __forceinline__ void " + win_taps_name(pg) + "(vw_lchar *const (&b)[2][VW_NBT], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
     spec_append(s, "    v4f q[%d];\n    v2f E0[%d], P0[%d], E1[%d], P1[%d];\n    float O00, OL0, O01, OL1;\n", la + 1, M / 2, M / 2, M / 2, M / 2);
+    if (adds) s += "    const v2f Z2 = {0.0f, 0.0f};\n";
     struct Rd { int o; std::vector<std::pair<int, WinOp>> ops; };           // (channel, op)
     std::map<int, Rd> by_o;
     for (int ch = 0; ch < 2; ++ch)
@@ -394,10 +472,16 @@ inline std::string win_taps_function_merged(const SpecTable &t, const WinGeom &g
         }
     std::vector<Rd> reads;
     for (auto &kv : by_o) reads.push_back(std::move(kv.second));
-    if (spec_env("VND_WIN_FAR_FIRST", 1) != 0) std::reverse(reads.begin(), reads.end());      // (small terms first: win_taps_function)
+    if (spec_env("VND_WIN_FAR_FIRST", 1) != 0) {      // (small terms first: win_taps_function)
+        std::reverse(reads.begin(), reads.end());
+        if (adds)
+            for (Rd &r : reads) std::stable_sort(r.ops.begin(), r.ops.end(), [](const std::pair<int, WinOp> &a, const std::pair<int, WinOp> &b) { return a.second.tap > b.second.tap; });
+    }
     auto emit_read = [&](size_t k) {
         spec_append(s, "    q[%zu] = %s;\n", k % (size_t)(la + 1), win_rd(g, 0, reads[k].o).c_str());
     };
+    std::vector<float> e_unit[2] = {std::vector<float>(M / 2, 0.0f), std::vector<float>(M / 2, 0.0f)}, p_unit[2] = {std::vector<float>(M / 2, 0.0f), std::vector<float>(M / 2, 0.0f)};
+    float o0_unit[2] = {0.0f, 0.0f}, ol_unit[2] = {0.0f, 0.0f};      // adds: the chains' units (win_taps_function)
     std::vector<char> e_used[2] = {std::vector<char>(M / 2, 0), std::vector<char>(M / 2, 0)}, p_used[2] = {std::vector<char>(M / 2, 0), std::vector<char>(M / 2, 0)};
     bool o0_used[2] = {false, false}, ol_used[2] = {false, false};
     for (size_t k = 0; k < std::min(reads.size(), (size_t)la); ++k) emit_read(k);
@@ -408,6 +492,20 @@ inline std::string win_taps_function_merged(const SpecTable &t, const WinGeom &g
             const int ch = cop.first;
             const WinOp &op = cop.second;
             const std::string w = spec_float(op.w), c = std::to_string(ch);
+            if (adds) {
+                const bool pair = op.kind <= 1, is0 = op.kind == 2;
+                const std::string acc = pair ? std::string(op.kind == 0 ? "E" : "P") + c + "[" + std::to_string(op.acc) + "]" : std::string(is0 ? "O0" : "OL") + c;
+                const std::string x = pair ? qk + (op.half ? ".zw" : ".xy") : qk + (is0 ? (op.half ? ".w" : ".y") : (op.half ? ".z" : ".x"));
+                float &unit = pair ? (op.kind == 0 ? e_unit[ch][op.acc] : p_unit[ch][op.acc]) : (is0 ? o0_unit[ch] : ol_unit[ch]);
+                const float mag = std::fabs(op.w);
+                const char sign = std::signbit(op.w) ? '-' : '+';
+                if (unit == 0.0f) spec_append(s, "    %s = %s %c %s;\n", acc.c_str(), pair ? "Z2" : "0.0f", sign, x.c_str());
+                else if (unit == mag) spec_append(s, "    %s = %s %c %s;\n", acc.c_str(), acc.c_str(), sign, x.c_str());
+                else if (pair) spec_append(s, "    %s = VW_FMA(%s, %s, %s%s);\n", acc.c_str(), acc.c_str(), spec_float(win_unit_ratio(unit, mag)).c_str(), sign == '-' ? "-" : "", x.c_str());
+                else spec_append(s, "    %s = __builtin_fmaf(%s, %s, %s%s);\n", acc.c_str(), acc.c_str(), spec_float(win_unit_ratio(unit, mag)).c_str(), sign == '-' ? "-" : "", x.c_str());
+                unit = mag;
+                continue;
+            }
             if (op.kind <= 1) {
                 const std::string acc = std::string(op.kind == 0 ? "E" : "P") + c + "[" + std::to_string(op.acc) + "]";
                 const std::string x = qk + (op.half ? ".zw" : ".xy");
@@ -427,17 +525,32 @@ inline std::string win_taps_function_merged(const SpecTable &t, const WinGeom &g
         }
         s += "    VW_SB;\n";
     }
-    for (int ch = 0; ch < 2; ++ch)
+    for (int ch = 0; ch < 2; ++ch) {
+        const std::string c = std::to_string(ch);
+        float common = 0.0f;
+        bool uniform = true;
+        auto see = [&](float u) { if (u == 0.0f) return; if (common == 0.0f) common = u; else if (u != common) uniform = false; };
+        if (adds) { for (float u : e_unit[ch]) see(u); for (float u : p_unit[ch]) see(u); see(o0_unit[ch]); see(ol_unit[ch]); }
         for (int j = 0; j < M; ++j) {
-            const std::string c = std::to_string(ch);
-            std::string ev = e_used[ch][j / 2] ? ("E" + c + "[" + std::to_string(j / 2) + "]." + ((j & 1) ? "y" : "x")) : std::string();
+            const bool e_on = adds ? e_unit[ch][j / 2] != 0.0f : e_used[ch][j / 2] != 0;
+            const bool o_on = j == 0 ? (adds ? o0_unit[ch] != 0.0f : o0_used[ch]) : (j == M - 1 ? (adds ? ol_unit[ch] != 0.0f : ol_used[ch]) : (adds ? p_unit[ch][(j - 1) / 2] != 0.0f : p_used[ch][(j - 1) / 2] != 0));
+            std::string ev = e_on ? ("E" + c + "[" + std::to_string(j / 2) + "]." + ((j & 1) ? "y" : "x")) : std::string();
             std::string ov;
-            if (j == 0) { if (o0_used[ch]) ov = "O0" + c; }
-            else if (j == M - 1) { if (ol_used[ch]) ov = "OL" + c; }
-            else if (p_used[ch][(j - 1) / 2]) ov = "P" + c + "[" + std::to_string((j - 1) / 2) + "]." + ((j & 1) ? "x" : "y");
+            if (o_on) ov = j == 0 ? "O0" + c : (j == M - 1 ? "OL" + c : "P" + c + "[" + std::to_string((j - 1) / 2) + "]." + ((j & 1) ? "x" : "y"));
+            if (adds && !uniform) {
+                if (!ev.empty()) ev = "(" + ev + " * " + spec_float(e_unit[ch][j / 2]) + ")";
+                if (!ov.empty()) ov = "(" + ov + " * " + spec_float(j == 0 ? o0_unit[ch] : (j == M - 1 ? ol_unit[ch] : p_unit[ch][(j - 1) / 2])) + ")";
+            }
             const std::string rhs = ev.empty() ? (ov.empty() ? std::string("0.0f") : ov) : (ov.empty() ? ev : ev + " + " + ov);
             spec_append(s, "    o%d[%d] = %s;\n", ch, j, rhs.c_str());
         }
+        if (adds && uniform && common != 0.0f && common != 1.0f) {
+            const std::string u = spec_float(common);
+            for (int k = 0; k < M / 2; ++k)
+                spec_append(s, "    { const v2f t2 = v2f{o%d[%d], o%d[%d]} * v2f{%s, %s}; o%d[%d] = t2.x; o%d[%d] = t2.y; }\n", ch, 2 * k, ch, 2 * k + 1, u.c_str(), u.c_str(),
+                            ch, 2 * k, ch, 2 * k + 1);
+        }
+    }
     s += "}\n";
     return s;
 }
@@ -598,7 +711,7 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
         // quads / octets: one function per channel, the workgroup's 4Q of them picked by the wave's channel number
         const int nch = 4 * g.quad;
         for (int pg = 0; pg < t.C / 2; ++pg)
-            for (int ch = 0; ch < 2; ++ch) src += c.exact ? win_taps_function_exact(t, g, c.la, pg, ch) : win_taps_function(t, g, c.la, pg, ch);
+            for (int ch = 0; ch < 2; ++ch) src += c.exact ? win_taps_function_exact(t, g, c.la, pg, ch) : win_taps_function(t, g, c.la, pg, ch, c.adds != 0);
         src += "template <int PG> __device__ void vw_taps_of(vw_lchar *const (&b)[2][VW_NBT], float (&o0)[VW_M], float (&o1)[VW_M]);      // (vw_span, vw_span_q: not instantiated)\n";
         src += "template <int QD> __device__ __forceinline__ void vw_taps_of_channel(int pc, vw_lchar *const (&b)[2][VW_NBT], float (&o)[VW_M])\n{\n";
         const int nq = (t.C + nch - 1) / nch;                          // (4k + 2 channels, quads: the last one starts at channel C - 4)
@@ -614,12 +727,12 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
         for (int qd = 0; qd < nq; ++qd) spec_append(src, " case %d: vw_span_qc<%d>(a, lds, stream, t_first, ntiles, flags, pace); break;", qd, qd);
         src += " default: break; }\n";
     } else if (g.split) {
-        for (int ch = 0; ch < 2; ++ch) src += c.exact ? win_taps_function_exact(t, g, c.la, 0, ch) : win_taps_function(t, g, c.la, 0, ch);
+        for (int ch = 0; ch < 2; ++ch) src += c.exact ? win_taps_function_exact(t, g, c.la, 0, ch) : win_taps_function(t, g, c.la, 0, ch, c.adds != 0);
         src += "template <int PG> __device__ void vw_taps_of(vw_lchar *const (&b)[2][VW_NBT], float (&o0)[VW_M], float (&o1)[VW_M]);      // (vw_span: not instantiated)\n";
         src += "#define VW_DISPATCH(pg) vw_span_s(a, lds, stream, t_first, ntiles, flags, pace);\n";
     } else {
         const bool merged = c.bc && !c.exact;      // (one read stream for both channels of a mono input)
-        for (int pg = 0; pg < t.C / 2; ++pg) src += c.exact ? win_taps_function_exact(t, g, c.la, pg) : (merged ? win_taps_function_merged(t, g, c.la, pg) : win_taps_function(t, g, c.la, pg));
+        for (int pg = 0; pg < t.C / 2; ++pg) src += c.exact ? win_taps_function_exact(t, g, c.la, pg) : (merged ? win_taps_function_merged(t, g, c.la, pg, c.adds != 0) : win_taps_function(t, g, c.la, pg, -1, c.adds != 0));
         src += win_taps_dispatch(t);
     }
     src += fixed.substr(at + marker.size());

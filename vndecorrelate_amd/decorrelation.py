@@ -249,6 +249,34 @@ def _fir_key(fir: np.ndarray, channels: int):
     return (view.shape, str(view.dtype), _digest16(view), _native.default_context().device)
 
 
+class _ArraysCache:
+    """Function-path tap arrays (and their transport image) of the filters last spread over a device list: the several-device
+    call otherwise rebuilds them - a scan of the dense FIR and a serialisation - on every call.  Keyed by the filter's content."""
+
+    def __init__(self, capacity: int = 32):
+        self.capacity, self._lock, self._items = capacity, threading.Lock(), OrderedDict()
+
+    def get(self, fir: np.ndarray, channels: int):
+        view = np.ascontiguousarray(fir[:, :channels])
+        key = (view.shape, str(view.dtype), _digest16(view))
+        with self._lock:
+            found = self._items.get(key)
+            if found is not None:
+                self._items.move_to_end(key)
+                return found
+        arrays = function_path_arrays(fir, channels)
+        image = arrays.to_bytes()
+        arrays.to_bytes = lambda: image                      # (immutable from here on: the pool keys its device copies by the image)
+        with self._lock:
+            self._items[key] = arrays
+            while len(self._items) > self.capacity:
+                self._items.popitem(last=False)
+        return arrays
+
+
+_fir_arrays = _ArraysCache()
+
+
 def _promoted_convolve(x: NDArray, fir: NDArray, num_channels: int, mode: int) -> Optional[NDArray]:
     """The operand types NumPy multiplies in float64 (a float64 or int32/int64 signal, or any
     signal with a float64 filter such as ``VelvetNoise.FIR``): in the exact mode they take the
@@ -331,7 +359,7 @@ def convolve_velvet_noise_batched(input_signals: NDArray, velvet_noise_filters: 
         return np.zeros(x.shape, dtype=np.float32)
     if devices is not None:
         from . import multi
-        arrays = function_path_arrays(fir, num_channels)
+        arrays = _fir_arrays.get(fir, num_channels)
         out = _native.pinned_pool.empty(x.shape[:-1] + (arrays.num_channels,), np.float32)
         return multi.pool_for(devices).map_streams(arrays, x, out, 'convolve', mode)
     table = _fir_tables.get(_fir_key(fir, num_channels),
