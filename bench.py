@@ -391,14 +391,15 @@ def audio_leg(torch, vnd, _native, ctx, pool, power=None) -> dict:
     """The path on AUDIO instead of uniform random floats (SURVEY 8d's synthetic input is the worst case for the board's power cap,
     DESIGN.md 3.4): BASELINE configs[0]'s material - the 1 s stereo excerpt of the reference's viola recording kept in
     tests/golden/golden.npz (`viola_excerpt_in`, 44.1 kHz; /root/reference/tests/test_example.py:19-49 runs the whole file) - tiled to
-    10 s streams, every stream starting at another frame of the excerpt, as many streams as make the headline pool's bytes; the table
+    the headline pool's shape (as many streams, as many frames), every stream starting at another frame of the excerpt; the table
     is that test's (20 ms, 30 impulses, seed 1).  Fast and exact kernels, three streams of each against the C oracle."""
     from vndecorrelate_amd.taps import function_path_arrays
     z = np.load(REPO / 'tests' / 'golden' / 'golden.npz')
     excerpt = torch.from_numpy(np.ascontiguousarray(z['viola_excerpt_in'])).cuda()          # (44100, 2) float32
-    fs, reps = int(excerpt.shape[0]), 10
-    n = fs * reps
-    streams = max(3, int(round(pool * SAMPLE_RATE * SECONDS / n)))
+    fs = int(excerpt.shape[0])
+    # the headline pool's shape exactly - as many streams of as many frames (10.9 s at 44.1 kHz) - so that the data and the table are all that differ
+    streams, n = max(3, pool), SAMPLE_RATE * SECONDS
+    reps = -(-n // fs)
     base = excerpt.repeat(reps + 1, 1)
     x = torch.empty((streams, n, 2), dtype=torch.float32, device='cuda')
     for b in range(streams):
@@ -407,7 +408,7 @@ def audio_leg(torch, vnd, _native, ctx, pool, power=None) -> dict:
     arr = function_path_arrays(vnd.generate_velvet_noise(duration_seconds=0.02, num_impulses=TAPS, num_outs=2, sample_rate_hz=fs, seed=1))
     taps = (arr.tap_offsets, arr.tap_index, arr.tap_weight)
     table = _native.TapTable.create(ctx, *taps)
-    out = {'what': f'{streams} streams x {reps} s of the viola excerpt (44.1 kHz stereo, peak {float(excerpt.abs().max()):.3f}, rms {float(excerpt.square().mean().sqrt()):.4f}), '
+    out = {'what': f'{streams} streams x {n} frames of the viola excerpt, tiled (44.1 kHz stereo, peak {float(excerpt.abs().max()):.3f}, rms {float(excerpt.square().mean().sqrt()):.4f}), '
                    f'one launch; table: 20 ms / 30 impulses / seed 1 at 44.1 kHz (tests/test_example.py:19-34 of the reference)',
            'streams': streams, 'frames': n}
     checked = sorted({0, streams // 2, streams - 1})

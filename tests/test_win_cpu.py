@@ -259,6 +259,39 @@ def test_one_lane_of_the_exact_tap_function_is_bit_identical(native, golden, tmp
         assert got.tobytes() == want.tobytes(), f'own={own}: {np.abs(got - want).max():.3e}'
 
 
+@pytest.mark.parametrize('case', ['g48k_k30', 'g48k_k128_l', 'g44k_k30'])
+@pytest.mark.parametrize('M,nt', [(32, 128), (16, 64)])
+def test_one_lane_of_the_merged_exact_fanout_function_is_bit_identical(native, golden, tmp_path, case, M, nt, monkeypatch):
+    """A mono input through a function-path stereo table, VND_MODE_EXACT (decorrelation.py:428-431 then :649-658): ONE ascending read
+    stream over the union of both channels' windows, the products f32(x * |w|) shared by the two channels - and still each channel's
+    sums in table order, bit for bit the reference's.  Fewer window reads than a pass per channel."""
+    from vndecorrelate_amd.taps import function_path_arrays
+    rng = np.random.default_rng(zlib.crc32(f'merged/{case}/{M}'.encode()))
+    arr = function_path_arrays(golden.fir(case))
+    monkeypatch.setenv('VND_WIN_SOURCE_FANOUT', '1')
+    src = native.window_kernel_source(arr.tap_offsets, arr.tap_index, arr.tap_weight, 0, M, nt)
+    assert '#define VW_EXACT 1' in src and '#define VW_BC 1' in src
+    body = src[src.index('void vw_taps('):src.index('#if VW_EPI')]
+    assert 'S0[' in body and 'S1[' in body and 'VW_RD(b[1]' not in body          # both channels' sums from the one plane set
+    monkeypatch.setenv('VND_WIN_EXACT_MERGED', '0')
+    apart = native.window_kernel_source(arr.tap_offsets, arr.tap_index, arr.tap_weight, 0, M, nt)
+    reads = lambda text: len(re.findall(r'= VW_RD\(', text[text.index('void vw_taps('):text.index('#if VW_EPI')]))
+    products = lambda text: len(re.findall(r'const v2f p\d+ = ', text[text.index('void vw_taps('):text.index('#if VW_EPI')]))
+    assert reads(src) < 0.75 * reads(apart) and products(src) < products(apart)
+    R, G, plane = _macro(src, 'VW_R'), _macro(src, 'VW_G'), _macro(src, 'VW_PLANE')
+    lib = _host_lane(src, tmp_path, f'exm_{case}_{M}')
+    mono = rng.uniform(-1, 1, R * M).astype(np.float32)
+    mono[rng.integers(0, len(mono), 40)] = 0.0
+    x = np.stack([mono, mono], 1)
+    want = _want_exact(x, arr, M)
+    for own in (0, R - 1, int(rng.integers(0, R))):
+        img = _lds_image(x, own, M, R, G, plane)
+        o0, o1 = np.zeros(M, np.float32), np.zeros(M, np.float32)
+        lib.run_lane(img.ctypes.data, own, o0.ctypes.data, o1.ctypes.data)
+        got = np.stack([o0, o1], 1)
+        assert got.tobytes() == want.tobytes(), f'own={own}: {np.abs(got - want).max():.3e}'
+
+
 def test_window_reads_fewer_lds_bytes_than_a_read_per_tap(native, golden):
     """The point of the form: bytes read from LDS per (tap, output) product; the pair-read kernel pays 4."""
     per = {}

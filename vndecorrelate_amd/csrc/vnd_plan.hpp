@@ -430,7 +430,11 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     //    frames (rejected builds fall back to the plain form) (tools/win_split_try.py, profiles/r03_split_waves.txt)
     // a mono input fanned out, fast mode: the plain form with ONE read stream for both output channels (win_taps_function_merged:
     // the two channels' taps lie almost alike, their windows' union is little more than one channel's - 1.48 B of LDS per FMA)
-    if (!picked && win_mode_ok && bc && mode == VND_MODE_FAST && vw == 0)
+    // ... and in the exact mode for function-path tables (one ascending pass per channel: win_taps_function_exact_merged - the reads and
+    // the products f32(x * |w|) shared by both channels, every sum the same operation as in a pass per channel); VND_WIN_EXACT_MERGED=0
+    // keeps the split form with the input staged into both plane sets
+    const bool merged_exact = bc && mode == VND_MODE_EXACT && win_exact && spec_env("VND_WIN_EXACT_MERGED", 1) != 0 && win_exact_merged_ok(t->spec_table);
+    if (!picked && win_mode_ok && bc && (mode == VND_MODE_FAST || merged_exact) && vw == 0)
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, true, &p.cfg, rejected);
     const int split_env = spec_env("VND_WIN_SPLIT", 1);
     // (a mono input fanned out rides the same form: its one channel staged into both plane sets, VW_BC - cfg1's shape 0.177 -> 0.15 ms

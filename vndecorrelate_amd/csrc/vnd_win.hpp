@@ -670,6 +670,103 @@ inline std::string win_taps_function_exact(const SpecTable &t, const WinGeom &g,
     return s;
 }
 
+// VND_MODE_EXACT, a mono input fanned out through a FUNCTION-path stereo table (VW_BC, plain form): both channels read the one plane
+// set, so ONE ascending read stream over the union of both channels' windows feeds both channels' sums - each channel still takes its
+// taps in table order (the stream ascends, and so does a function-path table: one pass per channel, win_exact_passes), every sum is the
+// same float32 operation on the same operands as in a pass per channel: bit-identical.  And f32(x * |w|) is formed once per (chunk,
+// pair, |w|) for BOTH channels: a velvet table's two channels share their segment grid, the nearest taps often their very offsets.
+inline bool win_exact_merged_ok(const SpecTable &t)
+{
+    if (t.C != 2 || t.has_seg) return false;
+    for (int ch = 0; ch < 2; ++ch) if (win_exact_passes(t, ch).size() != 1) return false;      // ascending: one pass per channel
+    return true;
+}
+
+inline std::string win_taps_function_exact_merged(const SpecTable &t, const WinGeom &g, int la, int pg = 0)
+{
+    const int M = g.M;
+    const size_t ring = (size_t)la + 2;
+    std::string s;
+    s += "__device__ __forceinline__ void " + win_taps_name(pg) + "(vw_lchar *const (&b)[2][VW_NBT], float (&o0)[VW_M], float (&o1)[VW_M])\n{\n";
+    spec_append(s, "    v4f q[%zu];\n    v2f S0[%d], S1[%d];\n    const v2f Z2 = {0.0f, 0.0f};\n", ring, M / 2, M / 2);
+    struct Rd { int o; std::vector<std::pair<int, WinExOp>> ops; };           // (channel, update), each channel's in table order
+    std::map<int, Rd> by_o;
+    for (int ch = 0; ch < 2; ++ch) {
+        std::vector<WinExRead> one;
+        const std::vector<WinExPass> ps = win_exact_passes(t, 2 * pg + ch);
+        if (!ps.empty()) win_exact_reads(ps, M, &one, 0);
+        for (const WinExRead &r : one) {
+            Rd &rd = by_o[r.o];
+            rd.o = r.o;
+            for (const WinExOp &op : r.ops) rd.ops.push_back({ch, op});
+        }
+    }
+    std::vector<Rd> reads;
+    for (auto &kv : by_o) reads.push_back(std::move(kv.second));
+    auto emit_read = [&](size_t k) { spec_append(s, "    q[%zu] = %s;\n", k % ring, win_rd(g, 0, reads[k].o).c_str()); };
+    for (size_t k = 0; k < std::min(reads.size(), (size_t)la); ++k) emit_read(k);
+    std::vector<char> live[2] = {std::vector<char>(M, 0), std::vector<char>(M, 0)};
+    for (size_t rk = 0; rk < reads.size(); ++rk) {
+        if (rk + la < reads.size()) emit_read(rk + la);
+        const Rd &rd = reads[rk];
+        if (rd.ops.empty()) continue;
+        const std::string qk = "q[" + std::to_string(rk % ring) + "]";
+        s += "    {\n";
+        const std::string xs[2] = {qk + ".xy", qk + ".zw"};
+        std::vector<std::pair<float, int>> prods;
+        std::string sums;
+        auto value_of = [&](float w, int type) -> std::string {
+            const float m = std::fabs(w);
+            if (m == 1.0f) return xs[type];
+            size_t at = 0;
+            while (at < prods.size() && !(prods[at].first == m && prods[at].second == type)) ++at;
+            if (at == prods.size()) {
+                prods.push_back({m, type});
+                const std::string gw = spec_float(m);
+                spec_append(s, "        const v2f p%zu = %s * v2f{%s, %s};\n", at, xs[type].c_str(), gw.c_str(), gw.c_str());
+            }
+            return "p" + std::to_string(at);
+        };
+        for (const auto &cop : rd.ops) {
+            const int ch = cop.first;
+            const WinExOp &op = cop.second;
+            const std::string S = ch ? "S1" : "S0";
+            std::vector<char> &e_live = live[ch];
+            const char sign = std::signbit(op.w) ? '-' : '+';
+            const std::string v = value_of(op.w, op.type & 1);       // (aligned pairs only: odd offsets are single sums - types 4 | pair)
+            if (op.type & 4) {
+                for (int e = 0; e < 2; ++e) {
+                    const int j = op.k + e;
+                    if (j < 0 || j >= M) continue;
+                    const std::string acc = S + "[" + std::to_string(j / 2) + "]." + ((j & 1) ? "y" : "x");
+                    const std::string first = e_live[j] ? acc : std::string("0.0f");
+                    spec_append(sums, "        %s = %s(%s, %s.%s);\n", acc.c_str(), sign == '-' ? "vw_sub1" : "vw_add1", first.c_str(), v.c_str(), e ? "y" : "x");
+                    e_live[j] = 1;
+                }
+                continue;
+            }
+            const int j0 = 2 * op.k;
+            if (!e_live[j0] && !e_live[j0 + 1]) {
+                spec_append(sums, "        %s[%d] = Z2 %c %s;\n", S.c_str(), op.k, sign, v.c_str());
+            } else {
+                if (!e_live[j0]) spec_append(sums, "        %s[%d].x = 0.0f;\n", S.c_str(), op.k);
+                if (!e_live[j0 + 1]) spec_append(sums, "        %s[%d].y = 0.0f;\n", S.c_str(), op.k);
+                spec_append(sums, "        %s[%d] = %s[%d] %c %s;\n", S.c_str(), op.k, S.c_str(), op.k, sign, v.c_str());
+            }
+            e_live[j0] = e_live[j0 + 1] = 1;
+        }
+        s += sums;
+        s += "    }\n    VW_SB;\n";
+    }
+    for (int ch = 0; ch < 2; ++ch)
+        for (int j = 0; j < M; ++j) {
+            if (live[ch][j]) spec_append(s, "    o%d[%d] = S%d[%d].%s;\n", ch, j, ch, j / 2, (j & 1) ? "y" : "x");
+            else spec_append(s, "    o%d[%d] = 0.0f;\n", ch, j);
+        }
+    s += "}\n";
+    return s;
+}
+
 inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
 {
     std::string s;
@@ -732,7 +829,8 @@ inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecCo
         src += "#define VW_DISPATCH(pg) vw_span_s(a, lds, stream, t_first, ntiles, flags, pace);\n";
     } else {
         const bool merged = c.bc && !c.exact;      // (one read stream for both channels of a mono input)
-        for (int pg = 0; pg < t.C / 2; ++pg) src += c.exact ? win_taps_function_exact(t, g, c.la, pg) : (merged ? win_taps_function_merged(t, g, c.la, pg, c.adds != 0) : win_taps_function(t, g, c.la, pg, -1, c.adds != 0));
+        const bool merged_exact = c.bc && c.exact && win_exact_merged_ok(t) && spec_env("VND_WIN_EXACT_MERGED", 1) != 0;
+        for (int pg = 0; pg < t.C / 2; ++pg) src += c.exact ? (merged_exact ? win_taps_function_exact_merged(t, g, c.la, pg) : win_taps_function_exact(t, g, c.la, pg)) : (merged ? win_taps_function_merged(t, g, c.la, pg, c.adds != 0) : win_taps_function(t, g, c.la, pg, -1, c.adds != 0));
         src += win_taps_dispatch(t);
     }
     src += fixed.substr(at + marker.size());
