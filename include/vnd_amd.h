@@ -55,13 +55,22 @@ typedef enum vnd_mode {
     VND_MODE_EXACT = 0,  /* acc = f32(acc + f32(x*w)), taps in table order: bit-identical
                             to the reference's NumPy paths (decorrelation.py:656-658, :405-414) */
     VND_MODE_FMA = 1,    /* acc = fma(x, w, acc) in table order: one rounding per tap       */
-    VND_MODE_FAST = 2    /* fma, free summation order, segment gains folded into the weights:
-                            the throughput mode; <= 1e-6 of the output peak from the reference */
+    VND_MODE_FAST = 2    /* the throughput mode: free summation order - per output two chains (even / odd
+                            offsets), far taps first; the per-table kernels add and subtract inside a run of
+                            equal |w| and apply the gain once per run, the reference's own class-path
+                            association (decorrelation.py:402-414).  Distance from the reference (= from
+                            VND_MODE_EXACT), as a fraction of the output peak, MEASURED on uniform random
+                            input (profiles/r06_k128_unseeded.json): 30 taps 3.1-4.3e-7, 64 taps 5.1-6.9e-7
+                            - below 1e-6 with a margin of 1.5x and more; 128 taps 6.1-9.0e-7 of a pool's
+                            peak over 64 unseeded pools of 69 M frames (none above 1e-6; 1.05e-6 of one
+                            stream's own peak once).  That distance is the reference's own float32
+                            rounding noise - no summation order lands closer - so it is not bounded by
+                            construction and grows with the tap count: VND_MODE_EXACT is the guaranteed mode */
 } vnd_mode;
 
-/* One per (process, device).  Every call runs on the context's device: the *_dev entry points
- * switch to it for the launch and restore the caller's current device, the *_host ones leave it
- * current.  Device pointers and streams passed in must belong to that device.            */
+/* One per (process, device).  Every call - vnd_ctx_create and the *_host entry points included -
+ * runs on the context's device and restores the caller's current HIP device before it returns.
+ * Device pointers and streams passed in must belong to the context's device.            */
 typedef struct vnd_ctx vnd_ctx;
 typedef struct vnd_taps vnd_taps;   /* device-resident tap table, immutable            */
 

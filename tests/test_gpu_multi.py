@@ -363,3 +363,32 @@ def test_single_process_rccl_communicator_carries_the_table():
         assert tables[0] is first and all(t.to_bytes() == arr.to_bytes() for t in tables)
     finally:
         rccl.destroy(comms)
+
+
+def test_the_callers_current_device_is_left_alone():
+    """A torch user calls the drop-in functions with a device list (or any entry point of a context on another device): the process's
+    current HIP device afterwards is the one it was - vnd_ctx_create and the *_host entry points switch to their context's device
+    inside a scope and restore it (round 5's advice: they used to leave the LAST device of the list current).  With one visible GPU
+    the assertion is trivially true; with more it is taken on the last device while the work runs on the others."""
+    import torch
+    import vndecorrelate_amd.decorrelation as vnd
+    from vndecorrelate_amd import _native, multi
+    n_dev = _native.device_count()
+    mine = n_dev - 1
+    torch.cuda.set_device(mine)
+    try:
+        fir = vnd.generate_velvet_noise(duration_seconds=0.03, num_impulses=30, num_outs=2, sample_rate_hz=48000, seed=1)
+        x = np.random.default_rng(5).uniform(-1, 1, (7, 20000, 2)).astype(np.float32)
+        want = vnd.convolve_velvet_noise_batched(x, fir)
+        for devices in ([0], 'all'):
+            got = vnd.convolve_velvet_noise_batched(x, fir, devices=devices)
+            assert np.array_equal(got, want)
+            assert torch.cuda.current_device() == mine
+        for d in range(n_dev):
+            ctx = _native.context_for(d)
+            assert ctx.device == d and torch.cuda.current_device() == mine
+        y = vnd.VelvetNoise(sample_rate_hz=48000, seed=1).decorrelate_batched(x, devices='all')
+        assert y.shape == x.shape and torch.cuda.current_device() == mine
+    finally:
+        multi.close_pools()
+        torch.cuda.set_device(0)

@@ -187,3 +187,41 @@ def test_two_callers_share_a_pool():
         assert np.array_equal(outs[k], want)
     assert pool.made == [3]
     pool.close()
+
+
+def test_a_failed_rccl_communicator_means_an_upload_per_device_not_a_failed_call(monkeypatch):
+    """The default table transport of the several-device call is one RCCL broadcast; where the single-process communicator cannot be
+    made (no librccl, ncclCommInitAll refusing the fabric) every device deserialises the 8-bytes-per-tap image itself - still the
+    GPUs' tables, a warning, and `last_transport` says which way it went.  (Fake contexts and tables: no device here.)"""
+    from vndecorrelate_amd import _native
+    _, arrays = _arrays()
+    made = []
+
+    class FakeTable:
+        def __init__(self, ctx, image=None):
+            self.ctx, self.image = ctx, image
+
+        @classmethod
+        def create(cls, ctx, offsets, index, weight, **kw):
+            return cls(ctx, arrays.to_bytes())
+
+        @classmethod
+        def from_bytes(cls, ctx, image):
+            made.append((ctx, len(image)))
+            return cls(ctx, image)
+
+        def to_bytes(self):
+            return self.image
+
+    class BrokenRccl:
+        def __init__(self):
+            raise RuntimeError('librccl.so could not be loaded')
+    monkeypatch.setattr(_native, 'context_for', lambda d: f'ctx{d}')
+    monkeypatch.setattr(_native, 'TapTable', FakeTable)
+    monkeypatch.setattr(multi, '_Rccl', BrokenRccl)
+    pool = multi.DevicePool([0, 1, 2])
+    with pytest.warns(UserWarning, match='uploading the table to each device'):
+        workers = pool._gpu_workers(pool.devices, arrays)
+    assert [w.ctx for w in workers] == ['ctx0', 'ctx1', 'ctx2'] and [c for c, _ in made] == ['ctx1', 'ctx2']
+    assert pool.last_transport.startswith('upload (rccl unavailable') and all(w.table.image == arrays.to_bytes() for w in workers)
+    pool._threads.shutdown(wait=True)

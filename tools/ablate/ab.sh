@@ -15,7 +15,9 @@ export VND_TUNING=1
 for ((r = 0; r < repeats; ++r)); do
   for g in "${groups[@]}"; do
     echo "== [$r] ${g:-defaults}"
-    env $g timeout -k 10 300 "${cmd[@]}" 2>&1 | grep -v amdgpu.ids || exit 1
+    # (the probe's own exit code decides, not grep's: a probe that prints nothing is not a failure, one that fails is)
+    env $g timeout -k 10 300 "${cmd[@]}" 2>&1 | grep -v amdgpu.ids
+    [[ ${PIPESTATUS[0]} -eq 0 ]] || { echo "probe failed (rc ${PIPESTATUS[0]})"; exit 1; }
   done
 done
 if [[ -n $pmc ]]; then

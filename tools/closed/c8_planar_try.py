@@ -2,7 +2,7 @@
 """cfg5 (96 kHz, 8 channels, 64 taps) as it is - interleaved frames, one launch - against the same arithmetic on
 PLANAR channel pairs (four stereo launches, each with its pair's taps): what the 8-byte pieces of 32-byte frames cost."""
 import pathlib, sys
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import numpy as np
 import torch
 import vndecorrelate_amd.decorrelation as vnd

@@ -3,7 +3,7 @@
 (VS_QUAD_STORES: one store instruction writes four consecutive frames' pieces instead of every other frame's).
 usage: c8_quad_try.py [channels=8]   (8: cfg5's table; 4 / 6: 48 kHz, 30 taps per channel)"""
 import os, pathlib, sys, time
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 os.environ['VND_TUNING'] = '1'
 import numpy as np, torch
 import vndecorrelate_amd.decorrelation as vnd

@@ -5,7 +5,7 @@
     the pair-read per-table kernel and the window form on channel pairs, fast and exact.
 usage: c8_quad_win_try.py [seconds per variant] [skip-small]"""
 import os, pathlib, sys, time
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import numpy as np
 os.environ.setdefault('VND_TUNING', '1')
 import torch

@@ -2,7 +2,7 @@
 """cfg5 (96 kHz, 8 channels, 64 taps): the generic fast kernel against the per-table kernel (forced: it is
 off by default for more than two channels) in several geometries."""
 import os, pathlib, sys, time
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import numpy as np
 os.environ.setdefault('VND_TUNING', '1')      # geometry variables are read live
 import torch

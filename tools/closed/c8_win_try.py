@@ -3,7 +3,7 @@
 against the pair-read per-table kernel: parity vs the exact kernel and sustained rate, fast and exact.
 usage: c8_win_try.py [seconds per variant]"""
 import os, pathlib, sys, time
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import numpy as np
 os.environ.setdefault('VND_TUNING', '1')
 import torch

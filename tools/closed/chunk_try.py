@@ -3,7 +3,7 @@
 exact kernel / the C oracle first, then the per-pass time of a hipGraph replay for each setting.
 usage: chunk_try.py [streams frames]..."""
 import os, pathlib, sys, time
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 os.environ['VND_TUNING'] = '1'
 import numpy as np
 import torch

@@ -2,7 +2,7 @@
 """VND_MODE_EXACT on the CLASS-path table (VelvetNoise.convolve: +-1 weights, segment gains - what VelvetNoise.decorrelate
 runs by default) on the cfg2 pool: the per-table (hipRTC) kernel against the generic ordered kernel."""
 import pathlib, sys, time, os
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import numpy as np
 import torch
 import vndecorrelate_amd.decorrelation as vnd

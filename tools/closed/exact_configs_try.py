@@ -2,7 +2,7 @@
 """VND_MODE_EXACT, per-table kernel (default) against the generic ordered kernel on the other BASELINE shapes:
 cfg3 (128 taps, 60 s stereo), cfg5 (96 kHz, 8 channels, 64 taps), cfg4 (1024 x 1 s stereo) and its N = 8 shard."""
 import pathlib, sys
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import torch
 import vndecorrelate_amd.decorrelation as vnd
 from vndecorrelate_amd import _native

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """VND_MODE_EXACT, per-table kernel with the shifted plane copies: tile geometries on the cfg2 pool, function- and class-path tables."""
 import os, pathlib, sys
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import torch
 import vndecorrelate_amd.decorrelation as vnd
 from vndecorrelate_amd import _native

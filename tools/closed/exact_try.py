@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """VND_MODE_EXACT on the cfg2 pool: the per-table (hipRTC) kernel against the generic ordered kernel."""
 import pathlib, sys, time
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import numpy as np
 import torch
 import vndecorrelate_amd.decorrelation as vnd

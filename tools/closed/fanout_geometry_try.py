@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Mono -> stereo, throughput mode, per-table kernel (VS_BC): tile geometries on the cfg2 shape (128 x 10 s mono in)."""
 import os, pathlib, sys
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import torch
 import vndecorrelate_amd.decorrelation as vnd
 from vndecorrelate_amd import _native

@@ -2,7 +2,7 @@
 """Mono -> stereo on the cfg2 shape (pool of 128 x 10 s mono in, stereo out; 12 B per frame): the per-table kernels (one LDS
 plane, VS_BC) against the generic fan-out kernels, fast and exact mode, function-path and class-path tables."""
 import pathlib, sys
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import torch
 import vndecorrelate_amd.decorrelation as vnd
 from vndecorrelate_amd import _native

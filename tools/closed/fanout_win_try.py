@@ -3,7 +3,7 @@
 taps at equal offsets) against the window forms - the plain one (one plane, a pass per channel) and the split one (round 4: 64-frame
 runs, the waves split over the two OUTPUT channels, the mono input staged into both plane sets) - fast and exact mode."""
 import os, pathlib, sys, time
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import numpy as np
 os.environ.setdefault('VND_TUNING', '1')
 import torch

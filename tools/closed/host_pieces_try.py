@@ -2,7 +2,7 @@
 """One cfg2 signal (and a 60 s one) through the synchronous host API: ms per call for the piece count in
 VND_HOST_TIME_PIECES (0 = the library's own choice; VND_HOST_TIME_CHUNKS=0 = one piece)."""
 import os, pathlib, sys, time
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import numpy as np
 import torch
 import vndecorrelate_amd.decorrelation as vnd

@@ -2,7 +2,7 @@
 """Launches of 128 ten-second streams (the f1 pool, the mono fan-out of the bench): the CU-chunk plan (a chunk of 30 tiles per CU as
 17 + 13) against uniform spans (4 x 15 tiles) with and without pacing - stereo and mono input, fast and exact; interleaved repeats."""
 import os, pathlib, sys
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 os.environ['VND_TUNING'] = '1'
 import torch
 import vndecorrelate_amd.decorrelation as vnd

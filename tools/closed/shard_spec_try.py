@@ -2,7 +2,7 @@
 """The N = 8 shard of cfg4 (128 x 1 s stereo) through forced per-table kernels of several geometries (C launch loop,
 7 rotating buffers), against the generic kernel."""
 import os, pathlib, sys
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import numpy as np, torch
 import vndecorrelate_amd.decorrelation as vnd
 from vndecorrelate_amd import _native

@@ -3,7 +3,7 @@
 automatic choice and of forced per-table variants, passes on ONE HIP stream and alternating over TWO (the tail of a pass
 beside the head of the next: consecutive passes are independent batches).  usage: shard_try.py [streams ...]"""
 import os, pathlib, sys, time
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import numpy as np
 os.environ.setdefault('VND_TUNING', '1')      # geometry variables are read live
 import torch

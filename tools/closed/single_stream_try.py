@@ -2,7 +2,7 @@
 """One long stream (cfg3's 60 s, 128 taps; and 10 s / 60 s with 30 taps): generic kernels against per-table kernels forced
 with several minimum span lengths - where does the persistent kernel start to pay for little work?"""
 import pathlib, sys
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import torch
 import vndecorrelate_amd.decorrelation as vnd
 from vndecorrelate_amd import _native

@@ -2,7 +2,7 @@
 """Specialised (hipRTC) fast kernel against the generic one on the cfg2 pool: parity and sustained rate.
 usage: spec_try.py [seconds per variant]"""
 import pathlib, sys, time
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import os
 import numpy as np
 os.environ.setdefault('VND_TUNING', '1')      # geometry variables are read live

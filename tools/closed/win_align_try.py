@@ -2,7 +2,7 @@
 """The window kernel with the ring's length rounded up to a multiple of 16 entries (the wrap falls on a bank period) against
 the exact-fit ring: cfg2, cfg3, cfg4, fast and exact.  A fresh table per setting."""
 import os, pathlib, sys, time
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 os.environ['VND_TUNING'] = '1'
 import numpy as np, torch
 import vndecorrelate_amd.decorrelation as vnd

@@ -3,7 +3,7 @@
 copies) and the generic ordered kernel: bit-equality on the whole pool, one stream against the C oracle, sustained rate.
 usage: win_exact_try.py [seconds per variant] [cfg2|cfg3]"""
 import os, pathlib, sys, time
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import numpy as np
 os.environ.setdefault('VND_TUNING', '1')      # geometry variables are read live
 import torch

@@ -2,7 +2,7 @@
 """64-frame runs (one wave per SIMD, half the LDS reads per FMA of 32-frame runs on a dense table) with deeper read
 pipelines - a lane alone on its SIMD has 512 registers: cfg3 and cfg2, fast and exact, against the 32-frame default."""
 import os, pathlib, sys, time
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 os.environ['VND_TUNING'] = '1'
 import numpy as np, torch
 import vndecorrelate_amd.decorrelation as vnd

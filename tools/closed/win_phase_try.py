@@ -4,7 +4,7 @@ A fresh table per setting (a table keeps its built kernels; these switches are n
   VND_WIN_DEBUG=1  no stores, 4: no barriers (wrong results on purpose)      VND_WIN_PRIO=k  s_setprio k between the tile's two barriers
 usage: win_phase_try.py [cfg2|cfg3|cfg4] [seconds per setting]"""
 import os, pathlib, sys, time
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import numpy as np
 os.environ.setdefault('VND_TUNING', '1')
 import torch

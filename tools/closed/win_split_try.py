@@ -5,7 +5,7 @@ three waves per SIMD) against the plain window form (a lane computes both channe
 (2) cfg3 (24 x 60 s, 128 taps), cfg3 kappa 1, cfg2 (128 x 10 s, 30 taps), the class-path table: sustained rate, fast and exact.
 usage: win_split_try.py [seconds per variant] [skip-small]"""
 import os, pathlib, sys, time
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import numpy as np
 os.environ.setdefault('VND_TUNING', '1')
 import torch

@@ -3,7 +3,7 @@
 generic one: parity (vs the exact kernel on a few streams, whole pool vs the pair-read kernel) and sustained rate.
 usage: win_try.py [seconds per variant] [cfg2|cfg3|cfg4] [quick]"""
 import os, pathlib, sys, time
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import numpy as np
 os.environ.setdefault('VND_TUNING', '1')      # geometry variables are read live
 import torch

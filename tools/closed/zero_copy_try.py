@@ -3,7 +3,7 @@
 directly on page-locked host memory (reads and writes cross PCIe inside the launch, both directions at once).
 usage: zero_copy_try.py"""
 import os, pathlib, sys, time
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 import numpy as np
 os.environ.setdefault('VND_TUNING', '1')      # VND_HOST_DIRECT is read live
 import torch

@@ -4,8 +4,9 @@
 # headline: kernel trace + one --pmc pass per counter group of bench.py (tools/profile.sh), then the same groups for cfg3 and cfg5
 # (tools/secondary_profile.py), then the kernel traces of the f1 pool stage and of the N = 8 shard.  One counter group per
 # rocprofv3 pass, never combined with API tracing.  What to skip: SKIP="f1 shard" etc.
-tag=${1:-r05}
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+tag=${1:-r06}
+root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}      # (the GPU box exports GRAFT_REPO_ROOT; anywhere else: this script's repository)
+cd /tmp && export TMPDIR=/tmp && cd "$root" || exit 1
 skip=" ${SKIP:-} "
 if [[ $skip != *" headline "* ]]; then bash tools/profile.sh "$tag" > "gpurun_out/prof_$tag.log" 2>&1; echo "headline rc=$?"; fi
 for cfg in cfg3 cfg5; do

@@ -214,7 +214,7 @@ vnd_status vnd_taps_create(vnd_ctx *ctx, int32_t C, const int32_t *tap_offsets, 
         }
         // VND_MODE_EXACT in the window form: ahead of the pair-read exact kernel on every stereo table measured once its
         // odd-offset taps became single adds (cfg2 function path 4.48 against 4.20 TB/s, class path 4.77 against 4.64; cfg3
-        // 1.93 against 1.40 and 2.03 against 1.74: tools/win_exact_try.py, profiles/r03_exact_window.txt)
+        // 1.93 against 1.40 and 2.03 against 1.74: tools/closed/win_exact_try.py, profiles/r03_exact_window.txt)
         t->win_exact_pays = t->spec_exact_ok && C % 2 == 0;
     }
     if (e == hipSuccess) e = upload(&t->d_taps_fast, fast.data(), fast.size());

@@ -65,7 +65,7 @@ static vnd_status convolve_dev(vnd_ctx *ctx, const vnd_taps *t, const float *x, 
 // is the unchunked call's, bit for bit in VND_MODE_EXACT.
 static int host_time_pieces(int64_t batch, int64_t n, size_t bytes, bool pinned)
 {
-    // Measured (tools/host_pieces_try.py, profiles/r03_host_pieces.txt): every extra copy call costs ~50 us of fixed time on
+    // Measured (tools/closed/host_pieces_try.py, profiles/r03_host_pieces.txt): every extra copy call costs ~50 us of fixed time on
     // this platform, so one 10 s signal (3.84 MB each way, 0.20 ms in one piece) only loses - 0.25 ms in 2 pieces, 0.36 in
     // 6 - and a pageable 60 s one too (its upload is staged by the CPU, call by call); a PAGE-LOCKED 60 s stream gains 5 %
     // with 4 pieces (0.85 vs 0.90 ms).  So: page-locked input of 16 MB and more per stream; VND_HOST_TIME_PIECES forces.
@@ -197,7 +197,7 @@ static vnd_status convolve_host(vnd_ctx *ctx, const vnd_taps *t, const float *x,
     const size_t in_elems = (size_t)batch * n * Cx, out_elems = (size_t)batch * n * C;
     // Page-locked buffers on BOTH sides: the kernel works on them in place - its loads and stores cross PCIe inside the
     // launch, both directions at once, with no staging copy before or after (one 10 s stereo signal 0.147 against 0.185 ms,
-    // 1024 x 1 s 9.95 against 14.1 ms: tools/zero_copy_try.py).  Every frame is read once plus the halo at span seams, and
+    // 1024 x 1 s 9.95 against 14.1 ms: tools/closed/zero_copy_try.py).  Every frame is read once plus the halo at span seams, and
     // written once: the bytes over PCIe are the staged path's.  VND_HOST_DIRECT=0 keeps the staged path.
     // (measured and dropped, same tool: a mapped input read in place with a staged download per group - 15.1 ms for the
     //  1024 streams; a staged upload with every group written in place - 13.7 ms with page-locked, 9.8-10.1 with pageable

@@ -351,7 +351,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     if (!(mode == VND_MODE_EXACT ? t->spec_exact_ok : t->spec_ok)) { p.why = "table outside the specialised kernel's scope"; return p; }
     // VND_MODE_EXACT specialises by default as well: with the shifted plane copies (odd offsets as aligned pairs) the per-table
     // kernel is ahead of the generic ordered one by 24 % on a function-path table, 37 % on a class-path one and 23-50 % on a mono
-    // input fanned out (cfg2 pool; tools/exact_geometry_try.py, tools/fanout_spec_try.py).  VND_SPEC_EXACT=0 keeps the generic kernel.
+    // input fanned out (cfg2 pool; tools/closed/exact_geometry_try.py, tools/closed/fanout_spec_try.py).  VND_SPEC_EXACT=0 keeps the generic kernel.
     if (mode == VND_MODE_EXACT && !(v >= 0 && ((v >> 15) & 1))) {
         static const bool off = [] { const char *e = getenv("VND_SPEC_EXACT"); return e && e[0] == '0'; }();
         if (off) { p.why = "exact mode specialisation switched off"; return p; }
@@ -385,11 +385,11 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     bool picked = false;
     // (a mono input fanned out keeps the pair-read form unless forced: there the two channels' taps share the reads of the
     //  one plane at equal offsets, the window form makes a pass per channel - 0.163 against 0.169 ms for 128 x 10 s,
-    //  tools/fanout_win_try.py)
+    //  tools/closed/fanout_win_try.py)
     // (wider signals - a workgroup per channel PAIR, VW_C - keep the pair-read kernel unless variant bits 5-7 or VND_WIN_WIDE=1
     //  ask for the window form: there a workgroup moves 8 bytes of every frame, the memory pipeline's time per useful byte
     //  is 2-4x a stereo signal's and the window form's few waves per CU do not hide it - cfg5 0.54 ms against 0.45, while
-    //  the same tables on planar channel pairs run 0.33 against 0.39: tools/c8_win_try.py, profiles/r03_cfg5_request_floor.txt)
+    //  the same tables on planar channel pairs run 0.33 against 0.39: tools/closed/c8_win_try.py, profiles/r03_cfg5_request_floor.txt)
     const int win_wide_env = spec_env("VND_WIN_WIDE", 0);
     const bool win_c = C == 2 || (C % 2 == 0 && (win_wide_env != 0 || vw >= 2));
     // signals of 4k channels: the window form on channel QUADS / OCTETS (VW_Q, vw_span_qc: a workgroup moves 16 / 32 bytes of every
@@ -427,7 +427,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     //  * 64-FRAME runs (half the LDS reads per FMA: every 16-byte window read costs the SIMD ~1.45 packed-FMA slots,
     //    profiles/r03_fp32_issue_rate.txt) fit two waves per SIMD only in this form: VND_MODE_EXACT on function-path tables
     //    +14-16 % at cfg3 (0.579 -> 0.497 ms), +6 % at cfg2 - taken there; class-path tables and the fast mode spill at 64
-    //    frames (rejected builds fall back to the plain form) (tools/win_split_try.py, profiles/r03_split_waves.txt)
+    //    frames (rejected builds fall back to the plain form) (tools/closed/win_split_try.py, profiles/r03_split_waves.txt)
     // a mono input fanned out, fast mode: the plain form with ONE read stream for both output channels (win_taps_function_merged:
     // the two channels' taps lie almost alike, their windows' union is little more than one channel's - 1.48 B of LDS per FMA)
     // ... and in the exact mode for function-path tables (one ascending pass per channel: win_taps_function_exact_merged - the reads and
@@ -438,7 +438,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, true, &p.cfg, rejected);
     const int split_env = spec_env("VND_WIN_SPLIT", 1);
     // (a mono input fanned out rides the same form: its one channel staged into both plane sets, VW_BC - cfg1's shape 0.177 -> 0.15 ms
-    //  for 128 x 10 s against the pair-read form, tools/fanout_win_try.py; VND_WIN_SPLIT_FANOUT=0 keeps that)
+    //  for 128 x 10 s against the pair-read form, tools/closed/fanout_win_try.py; VND_WIN_SPLIT_FANOUT=0 keeps that)
     const bool split_scope = C == 2 && (Cx == 2 || (bc && spec_env("VND_WIN_SPLIT_FANOUT", 1) != 0)) && !pointwise;
     //    In the FAST mode (E and P: 128 accumulator registers) the 64-frame split form needs its refill loaded late (VW_LATE: 15
     //    of a wave's 16 accesses per tile at the start of the store phase that consumes them, not a tile ahead) and the per-access
@@ -464,7 +464,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     const int64_t units = batch * (p.cfg.win_q ? (C + 4 * p.cfg.win_q - 1) / (4 * p.cfg.win_q) : C / 2);      // (stream, channel pair) - or channel quad / octet
     // a workgroup needs a span long enough to amortise filling its ring: 8 tiles when there are 16 and more per resident
     // slot; with less, shorter spans (down to 2 tiles) so that the chip still fills - a lone 60 s stream then runs 1.1x
-    // (fast) to 1.75x (exact, 128 taps) faster than through the generic kernels, tools/single_stream_try.py - and below
+    // (fast) to 1.75x (exact, 128 taps) faster than through the generic kernels, tools/closed/single_stream_try.py - and below
     // about two million frames per channel pair the generic kernels (many small workgroups) stay ahead
     int64_t min_span = (v >= 0 && ((v >> 20) & 7)) ? ((v >> 20) & 7) : 8;
     if (!(v >= 0 && ((v >> 20) & 7)))
@@ -551,7 +551,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     }
     p.use = true;
     // (window form: 8192-frame tiles down to 3 per span - 256 one-second streams 42.6 us with them, 45.7 with 4096-frame
-    //  tiles; at 2 per span - 128 such streams - the smaller tiles win, 26.3 against 28.1 us: tools/shard_try.py)
+    //  tiles; at 2 per span - 128 such streams - the smaller tiles win, 26.3 against 28.1 us: tools/closed/shard_try.py)
     if (per_span >= (p.cfg.win ? 3 : 12) || rr_hint > 0 || p.chunk_tiles > 0) break;
     }
     return p;

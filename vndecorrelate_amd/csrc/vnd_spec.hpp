@@ -136,14 +136,14 @@ inline bool spec_pick_config(const SpecTable &t, size_t lds_limit, int rr_hint, 
                              bool small_tiles = false, bool bc = false, bool shift_wanted = false)
 {
     const int reach = (t.max_index | 1) + 1;          // frames past a pair's first frame that an (aligned) read touches
-    // (threads, pairs per lane), best first.  Measured on cfg2 and cfg3 (tools/spec_try.py, several boxes):
+    // (threads, pairs per lane), best first.  Measured on cfg2 and cfg3 (tools/closed/spec_try.py, several boxes):
     // the geometries land within 7 % of each other - the kernel runs on the board's power cap - with
     // 3-wave workgroups of 1536-frame tiles ahead (3 ring slots, 4 workgroups per CU).
     // Short spans (a ring is filled once per span, three tiles of loads before the first output) do
     // better with 1024-frame tiles: small_tiles starts the list there.
     static const int kLong[][2] = {{192, 4}, {256, 4}, {128, 4}, {256, 2}, {128, 2}, {256, 1}};
     static const int kShort[][2] = {{128, 4}, {256, 2}, {128, 2}, {256, 1}, {192, 4}, {256, 4}};
-    // exact mode with the shifted plane copies (tools/exact_geometry_try.py, cfg2): 256 threads x 2 pairs (1024-frame tiles,
+    // exact mode with the shifted plane copies (tools/closed/exact_geometry_try.py, cfg2): 256 threads x 2 pairs (1024-frame tiles,
     // 4 ring slots, 74 KB: two workgroups = 8 waves per CU) ahead of 192 x 4 by 5-11 %, everything else behind
     static const int kExact[][2] = {{256, 2}, {192, 4}, {320, 2}, {128, 4}, {128, 2}, {256, 1}};
     const int (&kShapes)[6][2] = shift_wanted ? kExact : (small_tiles ? kShort : kLong);

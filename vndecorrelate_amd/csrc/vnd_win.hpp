@@ -788,7 +788,7 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
     spec_append(s, "#define VW_STAMP_PHASES %d\n", spec_env("VND_WIN_STAMP_PHASES", 1) != 0 ? 1 : 0);
     spec_append(s, "#define VW_STAMP_WAVE %d\n", std::max(0, spec_env("VND_WIN_STAMP_WAVE", 0)));      // (whose clock readings the phase stamps are)
     spec_append(s, "#define VW_STAMPS %d\n", std::min(std::max(spec_env("VND_WIN_STAMPS", 0), 0), 4096));
-    // s_setprio of the store / refill phase (0: none): cfg2 +1.0 % fast, +0.5 % exact at 1, 2 or 3; cfg3 unchanged (tools/win_phase_try.py)
+    // s_setprio of the store / refill phase (0: none): cfg2 +1.0 % fast, +0.5 % exact at 1, 2 or 3; cfg3 unchanged (tools/closed/win_phase_try.py)
     spec_append(s, "#define VW_PRIO %d\n", spec_env("VND_WIN_PRIO", 1));
     spec_append(s, "#define VW_LOAD_AUX %d\n", spec_env("VND_SPEC_LOAD_AUX", 2));
     const int waves = (win_workgroups_per_cu(g) * (g.nt / 64) + 3) / 4;
@@ -864,7 +864,7 @@ inline bool win_pick_config(const SpecTable &t, size_t lds_limit, int M, bool sm
                     c.nt = nt; c.win = M; c.win_g = G; c.win_lds = (int)g.lds_bytes(); c.bc = bc ? 1 : 0; c.win_q = g.quad; c.win_s = g.split;
                     c.win_per_cu = win_workgroups_per_cu(g);
                     // reads kept in flight: each holds 4 registers, and 32-frame runs already live at ~240 of the 256 a lane
-                    // has at two waves per SIMD (measured: 3 to 10 reads ahead run the same, tools/win_try.py)
+                    // has at two waves per SIMD (measured: 3 to 10 reads ahead run the same, tools/closed/win_try.py)
                     c.la = spec_env("VND_SPEC_LA", (split && M >= 64) ? (exact ? 3 : 2) : (M >= 32 ? 4 : 6));      // (64-frame runs: 64 / 128 accumulator registers)
                     c.rr = 0; c.pp = 0; c.dd = 0;
                     // the store phase: interleaved frame pairs (one 16-byte read-back per store) unless that build spilled

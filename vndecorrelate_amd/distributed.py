@@ -103,7 +103,7 @@ class ShardedDecorrelator:
         """Build now the per-table kernel this rank's shard launches will use (``vnd_prepare_launch``).  A rank's
         shard of a batch is a SMALL launch (the N = 8 shard of 1024 one-second streams: 6 M frames), and small
         launches never stall for a hipRTC build themselves - call this once after the table broadcast, before the
-        passes: the 128-stream pass then takes 26 us instead of the generic kernel's 30 (tools/shard_try.py)."""
+        passes: the 128-stream pass then takes 26 us instead of the generic kernel's 30 (tools/closed/shard_try.py)."""
         table = getattr(self._convolve, 'table', None)
         if table is not None and streams_local > 0 and frames > 0:
             table.prepare(streams_local, frames, in_channels or table.num_channels, mode)

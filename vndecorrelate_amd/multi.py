@@ -149,15 +149,31 @@ class DevicePool:
             image = first.to_bytes()
             self.last_transport = 'upload'
             return [_GpuWorker(ctxs[0], first)] + [_GpuWorker(c, _native.TapTable.from_bytes(c, image)) for c in ctxs[1:]]
-        # RCCL: one communicator per device in this process; every device's thread enters the broadcast (root = the first device)
-        if self._comms is None:
-            self._rccl = self._rccl or _Rccl()
-            self._comms = self._rccl.init_all(devices)
+        # RCCL: one communicator per device in this process; every device's thread enters the broadcast (root = the first device).
+        # The table image is 8 bytes per tap: if the communicator cannot be made (no librccl, a fabric the single-process
+        # ncclCommInitAll refuses) or the broadcast fails, every device deserialises the image itself - the same bytes, still on
+        # the GPUs, a warning and `last_transport` say which way it went.  A compute failure is never retried this way.
+        def upload(why: str) -> list:
+            import warnings
+            warnings.warn(f'vndecorrelate_amd.multi: table broadcast over RCCL unavailable ({why}); uploading the table to each device instead')
+            image = first.to_bytes()
+            self.last_transport = f'upload (rccl unavailable: {why})'
+            return [_GpuWorker(ctxs[0], first)] + [_GpuWorker(c, _native.TapTable.from_bytes(c, image)) for c in ctxs[1:]]
+        try:
+            if self._comms is None:
+                self._rccl = self._rccl or _Rccl()
+                self._comms = self._rccl.init_all(devices)
+        except (OSError, RuntimeError, AttributeError) as exc:
+            self._comms = None
+            return upload(str(exc)[:160])
         comms = self._comms
 
         def receive(rank):
             return _native.TapTable.broadcast_rccl(ctxs[rank], first if rank == 0 else None, 0, rank, comms[rank])
-        tables = list(self._threads.map(receive, range(len(devices))))
+        try:
+            tables = list(self._threads.map(receive, range(len(devices))))
+        except Exception as exc:
+            return upload(f'broadcast failed: {str(exc)[:140]}')
         self.last_transport = 'rccl'
         return [_GpuWorker(c, t) for c, t in zip(ctxs, tables)]
 
