@@ -404,9 +404,13 @@ def test_mono_fan_out_through_the_specialised_kernels(env, golden, which):
                 launch = table.describe(pool, n, 1, mode)
                 assert launch.startswith('conv_spec'), launch
                 if which == 'function_path':
-                    # round 4: the window forms - fast: the plain form with ONE read stream for both output channels (their taps lie
-                    # almost alike: win_taps_function_merged), 16-byte mono loads; exact: 64-frame runs, a wave per OUTPUT channel,
-                    # the input staged into both plane sets (vw_span_s, VW_BC)
+                    # the window forms - both modes the plain 32-frame form with ONE read stream for both output channels (their taps lie
+                    # almost alike: win_taps_function_merged; exact since round 6: win_taps_function_exact_merged, the products shared
+                    # too), 16-byte mono loads
+                    assert '_window' in launch and 'frames_per_lane=32' in launch and 'split-by-channel' not in launch, launch
+                else:
+                    # class-path tables: fast as above; exact (a pass per segment and sign list) in the split form - 64-frame runs, a
+                    # wave per OUTPUT channel, the input staged into both plane sets (vw_span_s, VW_BC)
                     assert '_window' in launch and ('frames_per_lane=32' in launch if mode == d.MODE_FAST else 'waves=split-by-channel' in launch), launch
                 y = table.convolve_host(x, mode)
                 if mode == d.MODE_EXACT:

@@ -387,8 +387,8 @@ def test_window_form_with_the_waves_split_over_the_channels(env, golden, monkeyp
 def test_stereo_tables_take_the_window_form_by_default_in_both_modes(env, golden):
     """The automatic choice for a stereo table with enough work: the window form, fast and exact, function path and class
     path; tables of 4k channels the window form on channel quads, of 8k channels on octets; a mono input fanned out the plain form
-    with one read stream for both output channels (fast) or 64-frame split runs (exact: function-path tables); tables of 4k + 2
-    channels keep the pair-read form."""
+    with one read stream for both output channels (fast; exact: function-path tables) or 64-frame split runs (exact, class-path
+    tables); tables of 4k + 2 channels ride quads too."""
     d, native, ctx = env
     ctx.set_variant(-1)
     dense, sparse = _table(native, ctx, golden.fir('g48k_k128_u')), _table(native, ctx, golden.fir('g48k_k30'))
@@ -399,8 +399,12 @@ def test_stereo_tables_take_the_window_form_by_default_in_both_modes(env, golden
     for table, shape in ((dense, (24, 2880000, 2)), (sparse, (128, 480000, 2)), (cls, (128, 480000, 2))):
         exact = table.describe(*shape, d.MODE_EXACT)
         assert exact.startswith('conv_spec_exact_window'), exact
-        # (function-path tables: 64-frame runs with the waves split over the channels; the class path's segments: the plain form)
-        assert ('waves=split-by-channel' in exact and 'frames_per_lane=64 ' in exact) == (table is not cls), exact
+        # (64-frame runs with the waves split over the channels - function-path tables, and since round 6 the class path's segments
+        #  too, with the fast mode's late refill; a build that spills would fall back to the plain form)
+        if table is not cls:
+            assert 'waves=split-by-channel' in exact and 'frames_per_lane=64 ' in exact, exact
+        else:
+            assert ('frames_per_lane=64 ' in exact and 'waves=split-by-channel' in exact) or ('frames_per_lane=32 ' in exact and 'split' not in exact), exact
         fast = table.describe(*shape, d.MODE_FAST)
         assert fast.startswith('conv_spec_window'), fast
         # (fast mode: 64-frame runs in the split form - the function-path tables build without spilling; a table whose build
@@ -412,7 +416,10 @@ def test_stereo_tables_take_the_window_form_by_default_in_both_modes(env, golden
     for mode in (d.MODE_FAST, d.MODE_EXACT):
         text = sparse.describe(128, 480000, 1, mode)
         assert text.startswith('conv_spec') and 'window' in text, text
-        assert ('frames_per_lane=32 ' in text and 'split' not in text) if mode == d.MODE_FAST else ('frames_per_lane=64 ' in text and 'waves=split-by-channel' in text), text
+        assert 'frames_per_lane=32 ' in text and 'split' not in text, text          # (one merged read stream, both modes: function-path table)
+        if mode == d.MODE_EXACT:
+            text = cls.describe(128, 480000, 1, mode)                              # (class-path table, exact: the split form, input staged twice)
+            assert text.startswith('conv_spec_exact') and (('frames_per_lane=64 ' in text and 'waves=split-by-channel' in text) or 'window' not in text), text
         text = wide.describe(16, 960000, 8, mode)
         assert text.startswith('conv_spec') and 'window' in text and 'pieces=channel-octets waves=split-by-channel' in text and 'frames_per_lane=32 ' in text, text
         text = four.describe(16, 960000, 4, mode)
@@ -543,3 +550,61 @@ def test_small_one_round_launches_are_cut_into_cu_chunks(env, golden, streams, n
     finally:
         ctx.set_variant(-1)
     table.close()
+
+
+def test_round6_forms_against_the_forms_they_replaced(env, golden, monkeypatch):
+    """Round 6's three default changes, each beside its switch (tuning variables, read live):
+    * VND_MODE_FAST in the reference's class-path association - adds inside a run of equal |w|, the gain ratio once per run
+      (decorrelation.py:402-414) - against one FMA per tap (VND_WIN_ADDS=0): both within 1e-6 of peak of the oracle on every
+      stream, and within 6e-7 of each other (two summation orders of the same products);
+    * VND_MODE_EXACT of a mono input through a function-path table with ONE merged read stream and shared products against a pass
+      per channel in the split form (VND_WIN_EXACT_MERGED=0);
+    * VND_MODE_EXACT of a class-path table in the split 64-frame form against the plain 32-frame form (VND_WIN_SPLIT_CLASS=0):
+    the exact ones bit for bit the oracle either way."""
+    d, native, ctx = env
+    ctx.set_variant(FORCE)
+    try:
+        rng = np.random.default_rng(66)
+        for gname, shape in (('g48k_k30', (6, 70001 * 2, 2)), ('g48k_k128_u', (3, 90000, 2)), ('g96k_k64_c8', (2, 50000, 8))):
+            fir = golden.fir(gname)
+            table = _table(native, ctx, fir)
+            x = rng.uniform(-1, 1, shape).astype(np.float32)
+            want = c_oracle.convolve(x, *O.fir_to_taps(fir), threads=4)
+            got = {}
+            for adds in ('1', '0'):
+                monkeypatch.setenv('VND_WIN_ADDS', adds)
+                text = table.describe(*shape, d.MODE_FAST)
+                assert text.startswith('conv_spec_window') and text.endswith('taps=adds-per-segment') == (adds == '1'), text
+                got[adds] = table.convolve_host(x, d.MODE_FAST)
+                for b in range(shape[0]):
+                    assert _err(got[adds][b], want[b]) <= TOL_PEAK, (gname, adds, b)
+            assert 0.0 < _err(got['1'], got['0'].astype(np.float64)) <= 6e-7, gname
+            monkeypatch.delenv('VND_WIN_ADDS')
+            table.close()
+        # a mono input through the function-path table, exact
+        fir = golden.fir('g48k_k30')
+        table = _table(native, ctx, fir)
+        xm = rng.uniform(-1, 1, (5, 90002, 1)).astype(np.float32)
+        want = c_oracle.convolve(np.ascontiguousarray(np.repeat(xm, 2, axis=2)), *O.fir_to_taps(fir), threads=4)
+        for merged in ('1', '0'):
+            monkeypatch.setenv('VND_WIN_EXACT_MERGED', merged)
+            text = table.describe(5, 90002, 1, d.MODE_EXACT)
+            assert text.startswith('conv_spec_exact_window') and ('split-by-channel' in text) == (merged == '0'), text
+            assert np.array_equal(table.convolve_host(xm, d.MODE_EXACT), want), merged
+        monkeypatch.delenv('VND_WIN_EXACT_MERGED')
+        table.close()
+        # the class path's table, exact: stereo, and a mono input fanned out
+        vn = d.VelvetNoise(sample_rate_hz=48000, seed=1)
+        cls = vn._device_table()
+        taps = O.generate_class_taps(sample_rate_hz=48000, seed=1)
+        xs = rng.uniform(-1, 1, (4, 80000, 2)).astype(np.float32)
+        want = np.stack([O.class_convolve(s, taps, (0.85, 0.55, 0.35, 0.2), 2) for s in xs])
+        want_m = np.stack([O.class_convolve(np.ascontiguousarray(np.repeat(s[:, :1], 2, axis=1)), taps, (0.85, 0.55, 0.35, 0.2), 2) for s in xs])
+        for split in ('1', '0'):
+            monkeypatch.setenv('VND_WIN_SPLIT_CLASS', split)
+            text = cls.describe(4, 80000, 2, d.MODE_EXACT)
+            assert text.startswith('conv_spec_exact_window') and (('frames_per_lane=64 ' in text) == (split == '1') or split == '1'), text
+            assert np.array_equal(cls.convolve_host(xs, d.MODE_EXACT), want), split
+            assert np.array_equal(cls.convolve_host(np.ascontiguousarray(xs[:, :, :1]), d.MODE_EXACT), want_m), split
+    finally:
+        ctx.set_variant(-1)

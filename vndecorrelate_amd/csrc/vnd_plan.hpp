@@ -445,8 +445,10 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     //    constants kept out of the tile loop's registers: cfg3 +3-4.5 % (0.457 -> 0.437 ms), cfg2 +3.8 % (0.195 -> 0.188 ms,
     //    tools/split64_fast_probe.py); a table whose build spills all the same falls back to the plain 32-frame form
     const bool exact_now = mode == VND_MODE_EXACT;
+    //    Class-path tables in the exact mode (a segment sum and an output sum per pair: the fast mode's register count) take it with
+    //    the fast mode's late refill since round 6 (VND_WIN_SPLIT_CLASS=0: the plain 32-frame form)
     if (!picked && win_mode_ok && split_scope && split_env == 1 && vw == 0 &&
-        ((exact_now && !t->spec_table.has_seg) || mode == VND_MODE_FAST))
+        ((exact_now && (!t->spec_table.has_seg || spec_env("VND_WIN_SPLIT_CLASS", 1) != 0)) || mode == VND_MODE_FAST))
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, 64, attempt == 1, bc, &p.cfg, rejected, 0, true, exact_now);
     if (!picked && win_mode_ok && split_scope && split_env == 2)
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, bc, &p.cfg, rejected, 0, true, exact_now);

@@ -767,7 +767,7 @@ inline std::string win_taps_function_exact_merged(const SpecTable &t, const WinG
     return s;
 }
 
-inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
+inline std::string win_prologue(const WinGeom &g, const SpecConfig &c, bool two_sums = false)
 {
     std::string s;
     spec_append(s, "#define VW_NT %d\n#define VW_M %d\n#define VW_R %d\n#define VW_G %d\n#define VW_NB %d\n#define VW_DE %d\n#define VW_PLANE %d\n#define VW_LA %d\n",
@@ -778,7 +778,8 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
     // them) instead of a tile ahead: 64-frame runs keep half of them out of the tap phase's registers
     // (the fast mode's E / P accumulators are twice the exact mode's sums: all but one late there - hipRTC's build of cfg2's table
     //  spills 20-64 bytes with 12-14 of the 16 late and none with 15; 4 to 15 late run the same)
-    spec_append(s, "#define VW_LATE %d\n", g.split ? std::min(std::max(spec_env("VND_WIN_SPLIT_LATE", g.M >= 64 ? (c.exact ? g.M / 8 : g.M / 4 - 1) : 0), 0), g.M / 4 - 1) : 0);
+    // (two_sums: a class-path table in the exact mode carries a segment sum AND an output sum per pair - as many registers as the fast mode)
+    spec_append(s, "#define VW_LATE %d\n", g.split ? std::min(std::max(spec_env("VND_WIN_SPLIT_LATE", g.M >= 64 ? ((c.exact && !two_sums) ? g.M / 8 : g.M / 4 - 1) : 0), 0), g.M / 4 - 1) : 0);
     spec_append(s, "#define VW_NT_STORE_AUX %d\n", spec_env("VND_SPEC_STORE_AUX", 2));
     // the transposition as interleaved frame pairs (one 16-byte read-back per store, planes an odd number of slots apart) or as
     // planar chunks read back in 8-byte halves (VND_WIN_XPOSE_PAIRS=0: then 32-frame runs swizzle their lanes' pair indices)
@@ -799,7 +800,7 @@ inline std::string win_prologue(const WinGeom &g, const SpecConfig &c)
 // the whole translation unit of the window kernel for (table, geometry)
 inline std::string win_source(const SpecTable &t, const WinGeom &g, const SpecConfig &c)
 {
-    std::string src = win_prologue(g, c);
+    std::string src = win_prologue(g, c, c.exact && t.has_seg);
     const std::string fixed = kWinKernelSource;
     const std::string marker = "//@@VW_TAPS@@";
     const size_t at = fixed.find(marker);
