@@ -726,7 +726,7 @@ def cfg4_strong(torch, dist, vnd, _native, ctx, table_image, mode, world, rank, 
         step(i); i += 1
         if i % 8 == 0:
             torch.cuda.synchronize()
-    steps = 200
+    steps = 200 if world == 1 else 200 * min(world, 4)     # (a shard's pass is short - 24 us at N = 8 - and the region ends in a barrier: 5-20 ms of passes per region either way)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
