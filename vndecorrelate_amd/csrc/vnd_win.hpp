@@ -202,7 +202,8 @@ inline std::string win_rd(const WinGeom &g, int ch, int o)
 // VelvetNoise.convolve adds and subtracts x[n + i] per segment and multiplies the segment's sum by its gain once
 // (decorrelation.py:402-414); every generated table has at most len(segment_envelope) distinct |w| (:621-625, :539-542).  Under the
 // board's power cap a launch's time is its energy, and a v_pk_add_f32 costs less of it than a v_pk_fma_f32: the same window reads
-// sustain 12-16 % more packed adds than packed FMAs per second on random data (tools/micro/lds_power.hip, profiles/r06_lds_power.txt).
+// sustain 12-16 % more packed adds than packed FMAs per second on random data in isolation (tools/micro/lds_power.hip,
+// profiles/r06_lds_power.txt) - in the launches themselves +0.5 ... +3.6 % (profiles/r06_adds_ab.txt: never slower, hence the default).
 // So an accumulator holds its partial sum in UNITS of the gain g of the taps it is taking:
 //     same |w| as the last tap:   acc = acc +- x                       v_pk_add_f32, the sign a neg_lo / neg_hi modifier
 //     another |w| = g':           acc = fma(acc, g / g', +-x)          the one multiply per segment, riding in an FMA
@@ -225,6 +226,52 @@ inline bool win_adds_ok(const SpecTable &t)
 
 // the ratio that takes a sum from units of `from` to units of `to`, rounded once
 inline float win_unit_ratio(float from, float to) { return (float)((double)from / (double)to); }
+
+// one tap of one chain in that association: `acc` (a v2f pair or a single float) takes +-x of a tap of weight w; `unit` is the gain
+// whose units the chain is in (0: not open yet) and becomes |w|
+inline void win_emit_adds_op(std::string &s, const std::string &acc, const std::string &x, bool pair, float w, float *unit)
+{
+    const float mag = std::fabs(w);
+    const char sign = std::signbit(w) ? '-' : '+';
+    if (*unit == 0.0f) spec_append(s, "    %s = %s %c %s;\n", acc.c_str(), pair ? "Z2" : "0.0f", sign, x.c_str());
+    else if (*unit == mag) spec_append(s, "    %s = %s %c %s;\n", acc.c_str(), acc.c_str(), sign, x.c_str());
+    else spec_append(s, "    %s = %s(%s, %s, %s%s);\n", acc.c_str(), pair ? "VW_FMA" : "__builtin_fmaf", acc.c_str(), spec_float(win_unit_ratio(*unit, mag)).c_str(),
+                     sign == '-' ? "-" : "", x.c_str());
+    *unit = mag;
+}
+
+// the outputs of one channel from its chains: o[j] = E + O per output, in the chains' common unit with one packed multiply per
+// output pair - or, where the chains of a channel ended in different units (a table whose nearest taps are all of one parity),
+// every chain scaled by its own unit first.  name(kind, k): the chain's C expression (kind 0 E[k], 1 P[k], 2 O0, 3 OL)
+template <class Name>
+inline void win_emit_adds_merge(std::string &s, int ch, int M, const std::vector<float> &e_unit, const std::vector<float> &p_unit, float o0_unit, float ol_unit, Name name)
+{
+    float common = 0.0f;
+    bool uniform = true;
+    auto see = [&](float u) { if (u == 0.0f) return; if (common == 0.0f) common = u; else if (u != common) uniform = false; };
+    for (float u : e_unit) see(u);
+    for (float u : p_unit) see(u);
+    see(o0_unit); see(ol_unit);
+    for (int j = 0; j < M; ++j) {
+        const float eu = e_unit[j / 2];
+        const float ou = j == 0 ? o0_unit : (j == M - 1 ? ol_unit : p_unit[(j - 1) / 2]);
+        std::string ev = eu != 0.0f ? (name(0, j / 2) + "." + ((j & 1) ? "y" : "x")) : std::string();
+        std::string ov;
+        if (ou != 0.0f) ov = j == 0 ? name(2, 0) : (j == M - 1 ? name(3, 0) : name(1, (j - 1) / 2) + "." + ((j & 1) ? "x" : "y"));
+        if (!uniform) {
+            if (!ev.empty()) ev = "(" + ev + " * " + spec_float(eu) + ")";
+            if (!ov.empty()) ov = "(" + ov + " * " + spec_float(ou) + ")";
+        }
+        const std::string rhs = ev.empty() ? (ov.empty() ? std::string("0.0f") : ov) : (ov.empty() ? ev : ev + " + " + ov);
+        spec_append(s, "    o%d[%d] = %s;\n", ch, j, rhs.c_str());
+    }
+    if (uniform && common != 0.0f && common != 1.0f) {
+        const std::string u = spec_float(common);
+        for (int k = 0; k < M / 2; ++k)
+            spec_append(s, "    { const v2f t2 = v2f{o%d[%d], o%d[%d]} * v2f{%s, %s}; o%d[%d] = t2.x; o%d[%d] = t2.y; }\n", ch, 2 * k, ch, 2 * k + 1, u.c_str(), u.c_str(),
+                        ch, 2 * k, ch, 2 * k + 1);
+    }
+}
 
 inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int la, int pg = 0, int only_ch = -1, bool adds = false)
 {
@@ -268,35 +315,6 @@ inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int l
             spec_append(s, "    o%d[%d] = %s;\n", ch, j, rhs.c_str());
         }
     };
-    // adds: the merge in units - pair (2k, 2k+1) of the outputs is fl(E + O) times the chains' last unit, one packed multiply per pair
-    // (chains that end in different units - a table whose nearest taps are all of one parity - are scaled one by one first)
-    auto emit_merge_units = [&](int ch, const std::vector<float> &e_unit, const std::vector<float> &p_unit, float o0_unit, float ol_unit) {
-        float common = 0.0f;
-        bool uniform = true;
-        auto see = [&](float u) { if (u == 0.0f) return; if (common == 0.0f) common = u; else if (u != common) uniform = false; };
-        for (float u : e_unit) see(u);
-        for (float u : p_unit) see(u);
-        see(o0_unit); see(ol_unit);
-        for (int j = 0; j < M; ++j) {
-            const float eu = e_unit[j / 2];
-            const float ou = j == 0 ? o0_unit : (j == M - 1 ? ol_unit : p_unit[(j - 1) / 2]);
-            std::string ev = eu != 0.0f ? ("E[" + std::to_string(j / 2) + "]." + ((j & 1) ? "y" : "x")) : std::string();
-            std::string ov;
-            if (ou != 0.0f) ov = j == 0 ? std::string("O0") : (j == M - 1 ? std::string("OL") : "P[" + std::to_string((j - 1) / 2) + "]." + ((j & 1) ? "x" : "y"));
-            if (!uniform) {
-                if (!ev.empty()) ev = "(" + ev + " * " + spec_float(eu) + ")";
-                if (!ov.empty()) ov = "(" + ov + " * " + spec_float(ou) + ")";
-            }
-            const std::string rhs = ev.empty() ? (ov.empty() ? std::string("0.0f") : ov) : (ov.empty() ? ev : ev + " + " + ov);
-            spec_append(s, "    o%d[%d] = %s;\n", ch, j, rhs.c_str());
-        }
-        if (uniform && common != 0.0f && common != 1.0f) {
-            const std::string u = spec_float(common);
-            for (int k = 0; k < M / 2; ++k)
-                spec_append(s, "    { const v2f t2 = v2f{o%d[%d], o%d[%d]} * v2f{%s, %s}; o%d[%d] = t2.x; o%d[%d] = t2.y; }\n", ch, 2 * k, ch, 2 * k + 1, u.c_str(), u.c_str(),
-                            ch, 2 * k, ch, 2 * k + 1);
-        }
-    };
     for (size_t k = 0; k < std::min(reads.size(), (size_t)la); ++k) emit_read(k);
     for (int ch = 0; ch < 2; ++ch) {
         if (only_ch >= 0 && ch != only_ch) continue;
@@ -313,14 +331,7 @@ inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int l
                     const bool pair = op.kind <= 1, is0 = op.kind == 2;
                     const std::string acc = pair ? std::string(op.kind == 0 ? "E[" : "P[") + std::to_string(op.acc) + "]" : std::string(is0 ? "O0" : "OL");
                     const std::string x = pair ? qk + (op.half ? ".zw" : ".xy") : qk + (is0 ? (op.half ? ".w" : ".y") : (op.half ? ".z" : ".x"));
-                    float &unit = pair ? (op.kind == 0 ? e_unit[op.acc] : p_unit[op.acc]) : (is0 ? o0_unit : ol_unit);
-                    const float mag = std::fabs(op.w);
-                    const char sign = std::signbit(op.w) ? '-' : '+';
-                    if (unit == 0.0f) spec_append(s, "    %s = %s %c %s;\n", acc.c_str(), pair ? "Z2" : "0.0f", sign, x.c_str());
-                    else if (unit == mag) spec_append(s, "    %s = %s %c %s;\n", acc.c_str(), acc.c_str(), sign, x.c_str());
-                    else if (pair) spec_append(s, "    %s = VW_FMA(%s, %s, %s%s);\n", acc.c_str(), acc.c_str(), spec_float(win_unit_ratio(unit, mag)).c_str(), sign == '-' ? "-" : "", x.c_str());
-                    else spec_append(s, "    %s = __builtin_fmaf(%s, %s, %s%s);\n", acc.c_str(), acc.c_str(), spec_float(win_unit_ratio(unit, mag)).c_str(), sign == '-' ? "-" : "", x.c_str());
-                    unit = mag;
+                    win_emit_adds_op(s, acc, x, pair, op.w, pair ? (op.kind == 0 ? &e_unit[op.acc] : &p_unit[op.acc]) : (is0 ? &o0_unit : &ol_unit));
                     continue;
                 }
                 if (op.kind <= 1) {
@@ -342,7 +353,10 @@ inline std::string win_taps_function(const SpecTable &t, const WinGeom &g, int l
             }
             s += "    VW_SB;\n";
         }
-        if (adds) emit_merge_units(ch, e_unit, p_unit, o0_unit, ol_unit);
+        if (adds)
+            win_emit_adds_merge(s, ch, M, e_unit, p_unit, o0_unit, ol_unit, [](int kind, int k) {
+                return kind == 0 ? "E[" + std::to_string(k) + "]" : (kind == 1 ? "P[" + std::to_string(k) + "]" : std::string(kind == 2 ? "O0" : "OL"));
+            });
         else emit_merge(ch, e_used, p_used, o0_used, ol_used);
     }
     s += "}\n";
@@ -496,14 +510,7 @@ inline std::string win_taps_function_merged(const SpecTable &t, const WinGeom &g
                 const bool pair = op.kind <= 1, is0 = op.kind == 2;
                 const std::string acc = pair ? std::string(op.kind == 0 ? "E" : "P") + c + "[" + std::to_string(op.acc) + "]" : std::string(is0 ? "O0" : "OL") + c;
                 const std::string x = pair ? qk + (op.half ? ".zw" : ".xy") : qk + (is0 ? (op.half ? ".w" : ".y") : (op.half ? ".z" : ".x"));
-                float &unit = pair ? (op.kind == 0 ? e_unit[ch][op.acc] : p_unit[ch][op.acc]) : (is0 ? o0_unit[ch] : ol_unit[ch]);
-                const float mag = std::fabs(op.w);
-                const char sign = std::signbit(op.w) ? '-' : '+';
-                if (unit == 0.0f) spec_append(s, "    %s = %s %c %s;\n", acc.c_str(), pair ? "Z2" : "0.0f", sign, x.c_str());
-                else if (unit == mag) spec_append(s, "    %s = %s %c %s;\n", acc.c_str(), acc.c_str(), sign, x.c_str());
-                else if (pair) spec_append(s, "    %s = VW_FMA(%s, %s, %s%s);\n", acc.c_str(), acc.c_str(), spec_float(win_unit_ratio(unit, mag)).c_str(), sign == '-' ? "-" : "", x.c_str());
-                else spec_append(s, "    %s = __builtin_fmaf(%s, %s, %s%s);\n", acc.c_str(), acc.c_str(), spec_float(win_unit_ratio(unit, mag)).c_str(), sign == '-' ? "-" : "", x.c_str());
-                unit = mag;
+                win_emit_adds_op(s, acc, x, pair, op.w, pair ? (op.kind == 0 ? &e_unit[ch][op.acc] : &p_unit[ch][op.acc]) : (is0 ? &o0_unit[ch] : &ol_unit[ch]));
                 continue;
             }
             if (op.kind <= 1) {
@@ -527,28 +534,20 @@ inline std::string win_taps_function_merged(const SpecTable &t, const WinGeom &g
     }
     for (int ch = 0; ch < 2; ++ch) {
         const std::string c = std::to_string(ch);
-        float common = 0.0f;
-        bool uniform = true;
-        auto see = [&](float u) { if (u == 0.0f) return; if (common == 0.0f) common = u; else if (u != common) uniform = false; };
-        if (adds) { for (float u : e_unit[ch]) see(u); for (float u : p_unit[ch]) see(u); see(o0_unit[ch]); see(ol_unit[ch]); }
+        if (adds) {
+            win_emit_adds_merge(s, ch, M, e_unit[ch], p_unit[ch], o0_unit[ch], ol_unit[ch], [&](int kind, int k) {
+                return kind == 0 ? "E" + c + "[" + std::to_string(k) + "]" : (kind == 1 ? "P" + c + "[" + std::to_string(k) + "]" : (kind == 2 ? "O0" : "OL") + c);
+            });
+            continue;
+        }
         for (int j = 0; j < M; ++j) {
-            const bool e_on = adds ? e_unit[ch][j / 2] != 0.0f : e_used[ch][j / 2] != 0;
-            const bool o_on = j == 0 ? (adds ? o0_unit[ch] != 0.0f : o0_used[ch]) : (j == M - 1 ? (adds ? ol_unit[ch] != 0.0f : ol_used[ch]) : (adds ? p_unit[ch][(j - 1) / 2] != 0.0f : p_used[ch][(j - 1) / 2] != 0));
-            std::string ev = e_on ? ("E" + c + "[" + std::to_string(j / 2) + "]." + ((j & 1) ? "y" : "x")) : std::string();
+            std::string ev = e_used[ch][j / 2] ? ("E" + c + "[" + std::to_string(j / 2) + "]." + ((j & 1) ? "y" : "x")) : std::string();
             std::string ov;
-            if (o_on) ov = j == 0 ? "O0" + c : (j == M - 1 ? "OL" + c : "P" + c + "[" + std::to_string((j - 1) / 2) + "]." + ((j & 1) ? "x" : "y"));
-            if (adds && !uniform) {
-                if (!ev.empty()) ev = "(" + ev + " * " + spec_float(e_unit[ch][j / 2]) + ")";
-                if (!ov.empty()) ov = "(" + ov + " * " + spec_float(j == 0 ? o0_unit[ch] : (j == M - 1 ? ol_unit[ch] : p_unit[ch][(j - 1) / 2])) + ")";
-            }
+            if (j == 0) { if (o0_used[ch]) ov = "O0" + c; }
+            else if (j == M - 1) { if (ol_used[ch]) ov = "OL" + c; }
+            else if (p_used[ch][(j - 1) / 2]) ov = "P" + c + "[" + std::to_string((j - 1) / 2) + "]." + ((j & 1) ? "x" : "y");
             const std::string rhs = ev.empty() ? (ov.empty() ? std::string("0.0f") : ov) : (ov.empty() ? ev : ev + " + " + ov);
             spec_append(s, "    o%d[%d] = %s;\n", ch, j, rhs.c_str());
-        }
-        if (adds && uniform && common != 0.0f && common != 1.0f) {
-            const std::string u = spec_float(common);
-            for (int k = 0; k < M / 2; ++k)
-                spec_append(s, "    { const v2f t2 = v2f{o%d[%d], o%d[%d]} * v2f{%s, %s}; o%d[%d] = t2.x; o%d[%d] = t2.y; }\n", ch, 2 * k, ch, 2 * k + 1, u.c_str(), u.c_str(),
-                            ch, 2 * k, ch, 2 * k + 1);
         }
     }
     s += "}\n";
