@@ -529,6 +529,56 @@ def next_rows(torch, vnd, _native, power=None) -> dict:
         out['f1_pool'] = rec
     except Exception as exc:
         out['f1_pool'] = {'error': repr(exc)}
+    # f1 on MONO signals - the reference's canonical use (decorrelation.py:428-442: mono_to_stereo, convolve, side-channel encode, normalise):
+    # the stage over a resident pool of 128 x 10 s mono signals, stereo out.  Bytes per FRAME the stage must move: convolution 4 in + 8 out,
+    # NumPy-order sums 4 + 8 (exact only), scale pass 8 + 8: 40 exact, 28 fused fast
+    try:
+        from oracle import vnd_oracle as O
+        vn = vnd.VelvetNoise(sample_rate_hz=SAMPLE_RATE, seed=1)
+        table = vn._device_table()
+        st = torch.cuda.current_stream().cuda_stream
+        pool = 128
+        x = torch.empty((pool, n, 1), dtype=torch.float32, device='cuda').uniform_(-1, 1)
+        y = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda')
+        ws_bytes = _native.decorrelate_workspace_bytes(pool, n, 2)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device='cuda')
+        rec = {}
+        for label, mode, bytes_per_frame in (('exact', vnd.MODE_EXACT, 40), ('fast_fused', vnd.MODE_FAST, 28)):
+            table.prepare(pool, n, 1, mode)
+
+            def run():
+                table.decorrelate_device(x.data_ptr(), y.data_ptr(), pool, n, 1, mode=mode, ms_encode=True, width=None,
+                                         normalize=1, workspace_ptr=ws.data_ptr(), workspace_bytes=ws_bytes, stream=st)
+            for _ in range(5):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(20):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            board = board_under(torch, power, lambda k: run())
+            worst = 0.0
+            for b in (0, pool - 1):
+                want = O.decorrelate(x[b, :, 0].cpu().numpy(), sample_rate_hz=SAMPLE_RATE, seed=1)
+                got = y[b].cpu().numpy()
+                if mode == vnd.MODE_EXACT:
+                    assert np.array_equal(got, want), f'f1_mono: exact stage differs from the oracle (stream {b})'
+                else:
+                    worst = max(worst, float(np.max(np.abs(got.astype(np.float64) - want)) / np.max(np.abs(want))))
+            assert worst <= 5e-4, f'f1_mono: fused fast stage off by {worst:.2e} of peak'
+            rec[label] = {'ms_per_call': round(ms, 4), 'bytes_per_frame_moved': bytes_per_frame, 'achieved_GBs': round(bytes_per_frame * pool * n / (ms * 1e-3) / 1e9, 1),
+                          'frac_of_8TBs': round(bytes_per_frame * pool * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'Gframes_s': round(pool * n / (ms * 1e-3) / 1e9, 1),
+                          'parity_vs_oracle_stage_of_peak': worst, 'board': board}
+        rec['what'] = ('vnd_decorrelate_fanout_f32_dev over 128 x 10 s MONO signals, stereo out, one call: exact - bit-identical to the reference\'s whole stage on the '
+                       'checked streams (asserted) - and fused fast; the exact stage\'s convolution in the plain window form with the block sums in its store phase')
+        out['f1_mono'] = rec
+        del x, y, ws
+        torch.cuda.empty_cache()
+    except Exception as exc:
+        out['f1_mono'] = {'error': repr(exc)}
     # f1 on cfg5's shape: VelvetNoise(num_outs=8, mode='LR', filtered_channels=0..7).decorrelate - how BASELINE's 8-channel config maps onto
     # the class API (decorrelation.py:417-442 with :433-440 reduced to the per-channel RMS normaliser) - over a resident pool
     try:
@@ -785,6 +835,7 @@ COMPACT_KEYS = {
     'worst_parity_over_pools': 'the largest of them',
     'audio_frac / audio_exact_frac': 'the headline pool\'s bytes as 10 s streams of the reference\'s viola recording (44.1 kHz stereo, its 20 ms table) instead of random floats',
     'f1_P_exact_frac / f1_P_fast_frac': 'the whole decorrelate stage over a pool of P 10 s stereo signals, by its own 24 / 16 B per sample',
+    'f1_mono_exact_frac / f1_mono_fast_frac / f1_mono_exact_ms': 'VelvetNoise.decorrelate of 128 x 10 s MONO signals (stereo out), by 40 / 28 B per frame',
     'f1_c8_frac': 'VelvetNoise.decorrelate of 8-channel 96 kHz signals (LR mode, RMS normaliser), fused fast stage, by 16 B per sample',
     'm2s_frac / m2s_exact_frac': 'mono in, stereo out, 12 B per frame',
     'scan_ms / chain_ms': 'f3 grid scan of 400 candidates, f4 resident chain: host to host',
@@ -850,12 +901,15 @@ def compact(d: dict) -> dict:
             if v is not None:
                 c[f'f1_{pool}_{short}_frac'] = v
                 board(f'f1_{pool}_{short}', dig(nxt, 'f1_pool', f'pool{pool}_{label}', 'board'))
-    for key, path in (('f1_c8_frac', ('f1_c8', 'fast_fused', 'frac_of_8TBs')), ('f1_c8_exact_frac', ('f1_c8', 'exact', 'frac_of_8TBs')),
+    for key, path in (('f1_mono_exact_frac', ('f1_mono', 'exact', 'frac_of_8TBs')), ('f1_mono_fast_frac', ('f1_mono', 'fast_fused', 'frac_of_8TBs')),
+                      ('f1_mono_exact_ms', ('f1_mono', 'exact', 'ms_per_call')),
+                      ('f1_c8_frac', ('f1_c8', 'fast_fused', 'frac_of_8TBs')), ('f1_c8_exact_frac', ('f1_c8', 'exact', 'frac_of_8TBs')),
                       ('m2s_frac', ('mono_to_stereo_fast', 'frac_of_8TBs')), ('m2s_exact_frac', ('mono_to_stereo_fast', 'exact_mode', 'frac_of_8TBs')),
                       ('scan_ms', ('f3_grid_scan', 'ms_host_to_host')), ('chain_ms', ('f4_resident_chain', 'ms_host_to_host'))):
         v = dig(nxt, *path)
         if v is not None:
             c[key] = v
+    board('f1_mono_exact', dig(nxt, 'f1_mono', 'exact', 'board'))
     board('f1_c8', dig(nxt, 'f1_c8', 'fast_fused', 'board'))
     board('f1_c8_exact', dig(nxt, 'f1_c8', 'exact', 'board'))
     board('m2s', dig(nxt, 'mono_to_stereo_fast', 'board'))

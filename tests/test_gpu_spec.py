@@ -437,19 +437,26 @@ def test_mono_decorrelate_stage_through_the_specialised_kernel(env, golden, tmp_
     x = torch.empty((pool, n, 1), dtype=torch.float32, device='cuda').uniform_(-1, 1)
     s = torch.cuda.current_stream().cuda_stream
     ws_bytes = native.decorrelate_workspace_bytes(pool, n, 2)
-    outs = {}
-    for label, variant in (('spec', FORCE | EXACT_TOO | span_bits(1, 2)), ('generic', GENERIC)):
+    outs, sources = {}, {}
+    # window: the plain 32-frame window form (VW_BC + VW_EPI: both channels' passes read the one plane set, the store phase encodes with the
+    # mono frame and leaves the block sums of the exact RMS - the default since round 6); pair_read: the form it replaced (VND_WIN_FANOUT_EPI=0)
+    for label, variant, fan in (('window', FORCE | EXACT_TOO | span_bits(1, 2), '1'), ('pair_read', FORCE | EXACT_TOO | span_bits(1, 2), '0'), ('generic', GENERIC, '1')):
         ctx.set_variant(variant)
+        monkeypatch.setenv('VND_WIN_FANOUT_EPI', fan)
         y = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda')
         ws = torch.zeros(ws_bytes // 8 + 1, dtype=torch.float64, device='cuda')
         table.decorrelate_device(x.data_ptr(), y.data_ptr(), pool, n, 1, mode=d.MODE_EXACT, ms_encode=True, width=0.4,
                                  normalize=True, workspace_ptr=ws.data_ptr(), workspace_bytes=ws_bytes, stream=s)
         torch.cuda.synchronize()
         outs[label] = y
+        if label != 'generic':
+            sources[label] = (tmp_path / 'kernel.hip').read_text()
     ctx.set_variant(-1)
-    source = (tmp_path / 'kernel.hip').read_text()
-    assert '#define VS_EPI 1' in source and '#define VS_BC 1' in source and len(list((tmp_path / 'cache').glob('*.co'))) == 1
-    assert torch.equal(outs['spec'], outs['generic'])
+    assert '#define VW_EPI 1' in sources['window'] and '#define VW_BC 1' in sources['window'] and '#define VW_EXACT 1' in sources['window']
+    assert '#define VS_EPI 1' in sources['pair_read'] and '#define VS_BC 1' in sources['pair_read']
+    assert len(list((tmp_path / 'cache').glob('*.co'))) == 2
+    assert torch.equal(outs['window'], outs['generic']) and torch.equal(outs['pair_read'], outs['generic'])
+    outs['spec'] = outs['window']
     want = O.decorrelate(x[5, :, 0].cpu().numpy().copy(), sample_rate_hz=48000, seed=2024, width=0.4, mode='MS')
     assert np.array_equal(outs['spec'][5].cpu().numpy(), want)
 
