@@ -626,22 +626,25 @@ class VelvetNoise(Decorrelator):
         then the epilogue - side-channel encode (MS mode), width, normaliser - on the device
         where that is faithful to the reference (see ``set_device_epilogue``), else in NumPy."""
         input_signal = to_float32(input_signal)
-        mono = None
+        if input_signal.ndim == 1 and self.num_outs == 2 and input_signal.shape[0] > 0:
+            # a mono signal (mono_to_stereo, decorrelation.py:428-431): the device reads the one channel for both outputs (fan-out);
+            # the (n, 2) copy the reference makes is materialised only where the host epilogue needs it - it costs more than the
+            # whole device stage of a 10 s signal
+            mono = np.ascontiguousarray(input_signal, dtype=np.float32)[:, None]
+            if _use_device_epilogue(2, self.normalizer is not None, mono.shape[0], True) and \
+                    (self.normalizer is None or self.normalizer is rms_normalize):
+                return self._decorrelate_on_device(mono)
+            output_signal = self._device_table().convolve_host(mono, _default_mode)
+            return self._host_epilogue(mono_to_stereo(input_signal), output_signal)
         if input_signal.ndim == 1:
-            # the device reads the one channel for both outputs (fan-out) instead of a copy
-            if self.num_outs == 2 and input_signal.shape[0] > 0:
-                mono = np.ascontiguousarray(input_signal, dtype=np.float32)[:, None]
             input_signal = mono_to_stereo(input_signal)
         # NumPy's sum order follows the memory layout (a Fortran-ordered signal is summed pairwise,
         # column by column): the device repeats the C-contiguous order only, so by default other
         # layouts keep the host epilogue, which sees the caller's array as the reference does
         if _use_device_epilogue(self.num_outs, self.normalizer is not None, input_signal.shape[0],
                                 input_signal.flags.c_contiguous) and self._device_epilogue_applies(input_signal):
-            return self._decorrelate_on_device(input_signal if mono is None else mono)
-        if mono is not None:
-            output_signal = self._device_table().convolve_host(mono, _default_mode)
-        else:
-            output_signal = self.convolve(input_signal)
+            return self._decorrelate_on_device(input_signal)
+        output_signal = self.convolve(input_signal)
         return self._host_epilogue(input_signal, output_signal)
 
     def _host_epilogue(self, input_signal: NDArray, output_signal: NDArray) -> NDArray:
