@@ -292,6 +292,46 @@ def test_one_lane_of_the_merged_exact_fanout_function_is_bit_identical(native, g
         assert got.tobytes() == want.tobytes(), f'own={own}: {np.abs(got - want).max():.3e}'
 
 
+@pytest.mark.parametrize('mags,order', [(3, 'runs'), (8, 'runs'), (3, 'scrambled'), (9, 'runs'), (20, 'scrambled')])
+def test_adds_per_segment_only_for_tables_of_few_gains_in_runs(native, tmp_path, mags, order):
+    """The fast mode's adds-per-segment association (decorrelation.py:402-414 as a summation order) is taken for tables with at most 8
+    distinct |w| that come in RUNS along the offsets (a segmented envelope: at most 8 changes per channel) - a chain changes its unit
+    with one FMA per change; a table of more gains, or of few gains in scrambled order, keeps one FMA per tap.  Either way one lane's
+    generated function equals the plain tap sum."""
+    rng = np.random.default_rng(900 + mags)
+    M, nt = 32, 128
+    gains = np.round(rng.uniform(0.05, 1.5, mags), 3).astype(np.float32)
+    offs, idx, w = [0], [], []
+    for c in range(2):
+        k = 40
+        ii = np.sort(rng.choice(700, size=k, replace=False))
+        idx += list(ii)
+        g = rng.choice(gains, size=k) if order == 'scrambled' else gains[(np.arange(k) * min(mags, 9)) // k]
+        w += list(g * rng.choice([-1.0, 1.0], size=k))
+        offs.append(len(idx))
+    offs, idx, w = np.array(offs, np.int32), np.array(idx, np.int32), np.array(w, np.float32)
+    src = native.window_kernel_source(offs, idx, w, 2, M, nt)
+    body = src[src.index('void vw_taps('):src.index('#if VW_EPI')]
+    adds = 'Z2 +' in body or 'Z2 -' in body
+    distinct = len(set(np.abs(w).tolist()))
+    assert adds == (distinct <= 8 and order == 'runs'), (mags, distinct, order)
+    if adds:
+        changes = sum(int((np.abs(w[offs[c]:offs[c + 1]])[1:] != np.abs(w[offs[c]:offs[c + 1]])[:-1]).sum()) for c in range(2))
+        assert body.count('VW_FMA(') <= changes * M                    # a unit change per run and chain (M / 2 E and P chains each), nothing else multiplies
+    else:
+        assert body.count('VW_FMA(') >= len(idx) * (M // 2) - len(idx) - 2 * M        # one FMA per (tap, output pair)
+    R, G, plane = _macro(src, 'VW_R'), _macro(src, 'VW_G'), _macro(src, 'VW_PLANE')
+    lib = _host_lane(src, tmp_path, f'mags{mags}{order}')
+    x = rng.uniform(-1, 1, (R * M, 2)).astype(np.float32)
+    want = _want(x.astype(np.float64), offs, idx, w, M)
+    peak = np.abs(want).max()
+    for own in (0, R - 1, 7):
+        img = _lds_image(x, own, M, R, G, plane)
+        o0, o1 = np.zeros(M, np.float32), np.zeros(M, np.float32)
+        lib.run_lane(img.ctypes.data, own, o0.ctypes.data, o1.ctypes.data)
+        assert np.abs(np.stack([o0, o1], 1) - want).max() <= 1e-6 * peak
+
+
 def test_window_reads_fewer_lds_bytes_than_a_read_per_tap(native, golden):
     """The point of the form: bytes read from LDS per (tap, output) product; the pair-read kernel pays 4."""
     per = {}
