@@ -653,29 +653,31 @@ def test_compiled_kernels_are_cached_on_disk(env, golden, tmp_path, monkeypatch)
 
 
 @pytest.mark.parametrize('kind', ['uniform', 'int16', 'sparse'])
+@pytest.mark.parametrize('cx', [1, 2])
 @pytest.mark.parametrize('ms_encode,width,normalize', [(True, None, True), (False, 0.3, True), (True, 0.7, False), (False, None, True)])
-def test_mono_exact_stage_in_the_window_form_equals_the_generic_kernels(env, golden, tmp_path, monkeypatch, kind, ms_encode, width, normalize):
-    """Round 6: the exact `decorrelate` stage of MONO signals rides the plain window form (VW_BC + VW_EPI: the store phase encodes with
-    the mono frame and leaves the block sums of the NumPy-order RMS).  Every combination of the stage's steps, ragged lengths across
-    tile and block seams, signals with ties and zero runs in the sums: the same bytes as the generic kernels' stage, and the oracle's
-    on one stream."""
+def test_exact_stage_in_the_window_form_equals_the_generic_kernels(env, golden, tmp_path, monkeypatch, kind, cx, ms_encode, width, normalize):
+    """The exact `decorrelate` stage in the plain window form with VW_EPI - the store phase applies the pointwise steps and leaves the
+    block sums of the NumPy-order RMS - for stereo input and (round 6) for MONO input (VW_BC: the mono frame feeds the side-channel
+    encode) and for the normaliser alone (LR mode: no pointwise step, the launch is taken for its block sums).  Every combination of
+    the stage's steps, ragged lengths across tile and block seams, signals with ties and zero runs in the sums: the same bytes as the
+    generic kernels' stage, and the oracle's on one stream."""
     import torch
     d, native, ctx = env
     kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in golden.manifest['class_taps']['v48k']['kwargs'].items()}
     kw['seed'] = 77
     table = d.VelvetNoise(**kw)._device_table()
     import zlib
-    rng = np.random.default_rng(zlib.crc32(repr((kind, ms_encode, width, normalize)).encode()))
+    rng = np.random.default_rng(zlib.crc32(repr((kind, cx, ms_encode, width, normalize)).encode()))
     monkeypatch.setenv('VND_SPEC_CACHE_DIR', str(tmp_path / 'cache'))
     monkeypatch.setenv('VND_SPEC_DUMP', str(tmp_path / 'kernel.hip'))
     s = torch.cuda.current_stream().cuda_stream
     for pool, n in ((6, 3 * 8192 + 2048 + 78), (3, 2 * 8192)):          # (even lengths: odd mono streams are not 8-byte aligned - generic kernels)
         if kind == 'uniform':
-            xh = rng.uniform(-1, 1, (pool, n, 1))
+            xh = rng.uniform(-1, 1, (pool, n, cx))
         elif kind == 'int16':
-            xh = rng.integers(-32768, 32767, (pool, n, 1)) / 32768.0
+            xh = rng.integers(-32768, 32767, (pool, n, cx)) / 32768.0
         else:
-            xh = rng.integers(-3, 4, (pool, n, 1)) * (rng.random((pool, n, 1)) < 0.2)
+            xh = rng.integers(-3, 4, (pool, n, cx)) * (rng.random((pool, n, cx)) < 0.2)
         x = torch.from_numpy(np.ascontiguousarray(xh, np.float32)).cuda()
         ws_bytes = native.decorrelate_workspace_bytes(pool, n, 2)
         outs = {}
@@ -683,15 +685,16 @@ def test_mono_exact_stage_in_the_window_form_equals_the_generic_kernels(env, gol
             ctx.set_variant(variant)
             y = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda')
             ws = torch.zeros(ws_bytes // 8 + 1, dtype=torch.float64, device='cuda')
-            table.decorrelate_device(x.data_ptr(), y.data_ptr(), pool, n, 1, mode=d.MODE_EXACT, ms_encode=ms_encode, width=width,
+            table.decorrelate_device(x.data_ptr(), y.data_ptr(), pool, n, cx, mode=d.MODE_EXACT, ms_encode=ms_encode, width=width,
                                      normalize=normalize, workspace_ptr=ws.data_ptr(), workspace_bytes=ws_bytes, stream=s)
             torch.cuda.synchronize()
             outs[label] = y
         ctx.set_variant(-1)
         source = (tmp_path / 'kernel.hip').read_text()
-        if normalize and (ms_encode or width is not None):      # (pointwise steps + block sums: the window form; no pointwise step: a plain convolution launch; no normaliser: the pair-read form keeps it)
-            assert '#define VW_EPI 1' in source and '#define VW_BC 1' in source and '#define VW_EXACT 1' in source
+        if normalize:          # (the block sums bring a mono launch to the window form - with or without pointwise steps; without a normaliser the pair-read form keeps it)
+            assert '#define VW_EPI 1' in source and f'#define VW_BC {2 - cx}' in source and '#define VW_EXACT 1' in source
         assert torch.equal(outs['window'], outs['generic']), (pool, n)
         if ms_encode and normalize:
-            want = O.decorrelate(x[pool - 1, :, 0].cpu().numpy().copy(), sample_rate_hz=48000, seed=77, width=width, mode='MS')
+            xs = x[pool - 1].cpu().numpy().copy()
+            want = O.decorrelate(xs[:, 0] if cx == 1 else xs, sample_rate_hz=48000, seed=77, width=width, mode='MS')
             assert np.array_equal(outs['window'][pool - 1].cpu().numpy(), want, equal_nan=True)

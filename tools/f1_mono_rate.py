@@ -13,8 +13,9 @@ from vndecorrelate_amd import _native
 from oracle import vnd_oracle as O
 
 pool = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+lr = 'lr' in sys.argv[2:]            # LR mode: the normaliser alone, no side-channel encode
 n = 480000
-vn = vnd.VelvetNoise(sample_rate_hz=48000, seed=1)
+vn = vnd.VelvetNoise(sample_rate_hz=48000, seed=1, **(dict(mode='LR') if 'lr' in sys.argv[2:] else {}))
 table = vn._device_table()
 st = torch.cuda.current_stream().cuda_stream
 torch.manual_seed(3)
@@ -24,11 +25,12 @@ for cx in (1, 2):
     ws_bytes = _native.decorrelate_workspace_bytes(pool, n, 2)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device='cuda')
     for label, mode, fan in (('exact', vnd.MODE_EXACT, '1'), ('exact', vnd.MODE_EXACT, '0'), ('exact', vnd.MODE_EXACT, '1'), ('fast', vnd.MODE_FAST, '1')):
-        if cx == 2 and fan == '0':
+        if cx == 2 and fan == '0' and not lr:
             continue
+        os.environ['VND_EPI_SUMS_ONLY'] = fan
         os.environ['VND_WIN_FANOUT_EPI'] = fan          # (0: a mono input's exact stage through the pair-read form + a pass for the block sums, as until round 6)
         table.prepare(pool, n, cx, mode)
-        run = lambda: table.decorrelate_device(x.data_ptr(), y.data_ptr(), pool, n, cx, mode=mode, ms_encode=True, width=None, normalize=1,
+        run = lambda: table.decorrelate_device(x.data_ptr(), y.data_ptr(), pool, n, cx, mode=mode, ms_encode=not lr, width=None, normalize=1,
                                                workspace_ptr=ws.data_ptr(), workspace_bytes=ws_bytes, stream=st)
         for _ in range(5):
             run()
@@ -41,7 +43,7 @@ for cx in (1, 2):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 20
         xs = x[pool - 1].cpu().numpy()
-        want = O.decorrelate(xs[:, 0] if cx == 1 else xs, sample_rate_hz=48000, seed=1)
+        want = O.decorrelate(xs[:, 0] if cx == 1 else xs, sample_rate_hz=48000, seed=1, **(dict(mode='LR') if lr else {}))
         got = y[pool - 1].cpu().numpy()
         ok = 'bit-identical' if np.array_equal(got, want) else f'{np.max(np.abs(got.astype(np.float64) - want)) / np.max(np.abs(want)):.1e} of peak'
         d = table.describe(pool, n, cx, mode)

@@ -138,7 +138,10 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
         // table-order modes: the pointwise steps ride in the ordered kernel's store phase when the
         // plan has both channels in one workgroup; the sums of squares follow as their own pass
         const bool pointwise = ms_encode || use_width;
-        const bool in_kernel = pointwise && mode != VND_MODE_FAST && ctx->variant_nofuse == 0 &&
+        // (LR mode with the normaliser alone - no pointwise step - takes the same launch for the block sums its store phase leaves: the
+        //  sums' own pass over x and y is a fifth of the stage at 128 streams)
+        const bool sums_only = !pointwise && want_blk && normalize && spec_env("VND_EPI_SUMS_ONLY", 1) != 0;
+        const bool in_kernel = (pointwise || sums_only) && mode != VND_MODE_FAST && ctx->variant_nofuse == 0 &&
                                ordered_epi_kernel(p, arithmetic_of(t, mode)) != nullptr;
         if (in_kernel) {
             EpiFuse f{nullptr, e.ms_encode, e.use_width, 0, e.w_mid, e.w_side};
