@@ -631,6 +631,41 @@ __device__ __forceinline__ void par_stage(const RArgs &a, int64_t b, int blk, fl
     const v4i ry = make_rsrc(ys, (a.n - f0) * 8);
     // 8 bytes per access where a stream's first sample is only 8-byte aligned (n odd, or a misaligned base): a.wide says when whole
     // 16-byte accesses are safe - they move the same bytes at 1.4-1.8x the rate (MI355X_MICROARCH.md: 8-byte accesses 0.54-0.70x)
+    if (a.wide) {
+        // whole 16-byte accesses, a wave's 64 lanes on 1 KB of CONSECUTIVE bytes (8 cache lines per access; a lane taking 32 consecutive
+        // bytes as two accesses made each of them 16 half-used lines - round 6): a lane holds frame pairs 2*tid + 512*k of y (and of a
+        // stereo x), frames 4*tid + 1024*u .. + 3 of a mono x
+        v4f yq[4], xq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) yq[k] = buf_load4(ry, tid * 16 + 4096 * k, 0, 0);
+        if constexpr (MONO) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) xq[u] = buf_load4(rx, tid * 16 + 4096 * u, 0, 0);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xq[k] = buf_load4(rx, tid * 16 + 4096 * k, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float2 *dst = (float2 *)(sq + 2 * tid + 512 * k);
+            dst[2 * kParFrames / 2] = make_float2(yq[k].x * yq[k].x, yq[k].z * yq[k].z);
+            dst[3 * kParFrames / 2] = make_float2(yq[k].y * yq[k].y, yq[k].w * yq[k].w);
+            if constexpr (!MONO) {
+                dst[0 * kParFrames / 2] = make_float2(xq[k].x * xq[k].x, xq[k].z * xq[k].z);
+                dst[1 * kParFrames / 2] = make_float2(xq[k].y * xq[k].y, xq[k].w * xq[k].w);
+            }
+        }
+        if constexpr (MONO) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float4 m2 = make_float4(xq[u].x * xq[u].x, xq[u].y * xq[u].y, xq[u].z * xq[u].z, xq[u].w * xq[u].w);
+                float4 *dst = (float4 *)(sq + 4 * tid + 1024 * u);
+                dst[0 * kParFrames / 4] = m2;
+                dst[1 * kParFrames / 4] = m2;
+            }
+        }
+        return;
+    }
     v4f yv[2][2], xv[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {                         // frames 4*tid + 1024*u + {0..3}
@@ -690,19 +725,21 @@ __device__ __forceinline__ void par_stage_quad(const RArgs &a, int64_t b0, int b
     int64_t xb, yb;
     const float *xs = par_pair_base(a, a.x, b0, f0, 0, &xb), *ys = par_pair_base(a, a.y, b0, f0, 0, &yb);
     const v4i rx = make_rsrc(xs, xb), ry = make_rsrc(ys, yb);
-    const int fb = a.C * 4, fr = 4 * tid;
+    // (a lane takes frames tid, tid + 512, ...: a wave's access is 64 CONSECUTIVE frames - 16 cache lines for a signal of 8 channels.
+    //  Four consecutive frames per lane - one 128-byte line each, 16 bytes of it per access - made every access 64 lines: the tally
+    //  of cfg5's pool ran 441 us for 0.98 GB, all of it from HBM once - profiles/r06_f1_c8_kernels.txt)
+    const int fb = a.C * 4;
     v4f xq[4], yq[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { xq[k] = buf_load4(rx, (fr + k) * fb, 0, 0); yq[k] = buf_load4(ry, (fr + k) * fb, 0, 0); }
-    float4 *dst = (float4 *)(sq + fr);
-    dst[0 * kParFrames / 4] = make_float4(xq[0].x * xq[0].x, xq[1].x * xq[1].x, xq[2].x * xq[2].x, xq[3].x * xq[3].x);
-    dst[1 * kParFrames / 4] = make_float4(xq[0].y * xq[0].y, xq[1].y * xq[1].y, xq[2].y * xq[2].y, xq[3].y * xq[3].y);
-    dst[2 * kParFrames / 4] = make_float4(yq[0].x * yq[0].x, yq[1].x * yq[1].x, yq[2].x * yq[2].x, yq[3].x * yq[3].x);
-    dst[3 * kParFrames / 4] = make_float4(yq[0].y * yq[0].y, yq[1].y * yq[1].y, yq[2].y * yq[2].y, yq[3].y * yq[3].y);
-    dst[4 * kParFrames / 4] = make_float4(xq[0].z * xq[0].z, xq[1].z * xq[1].z, xq[2].z * xq[2].z, xq[3].z * xq[3].z);
-    dst[5 * kParFrames / 4] = make_float4(xq[0].w * xq[0].w, xq[1].w * xq[1].w, xq[2].w * xq[2].w, xq[3].w * xq[3].w);
-    dst[6 * kParFrames / 4] = make_float4(yq[0].z * yq[0].z, yq[1].z * yq[1].z, yq[2].z * yq[2].z, yq[3].z * yq[3].z);
-    dst[7 * kParFrames / 4] = make_float4(yq[0].w * yq[0].w, yq[1].w * yq[1].w, yq[2].w * yq[2].w, yq[3].w * yq[3].w);
+    for (int k = 0; k < 4; ++k) { xq[k] = buf_load4(rx, (tid + 512 * k) * fb, 0, 0); yq[k] = buf_load4(ry, (tid + 512 * k) * fb, 0, 0); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float *dst = sq + tid + 512 * k;
+        dst[0 * kParFrames] = xq[k].x * xq[k].x; dst[1 * kParFrames] = xq[k].y * xq[k].y;
+        dst[2 * kParFrames] = yq[k].x * yq[k].x; dst[3 * kParFrames] = yq[k].y * yq[k].y;
+        dst[4 * kParFrames] = xq[k].z * xq[k].z; dst[5 * kParFrames] = xq[k].w * xq[k].w;
+        dst[6 * kParFrames] = yq[k].z * yq[k].z; dst[7 * kParFrames] = yq[k].w * yq[k].w;
+    }
 }
 
 __device__ __forceinline__ double wave_sum_f64(double v)
@@ -1245,6 +1282,22 @@ __global__ __launch_bounds__(kEpiThreads) void epilogue_scale_kernel(const EArgs
                 v.x = v.x * s0;
                 v.y = v.y * s1;
                 *(float2 *)(ys + e) = v;
+            }
+        }
+    } else if (C % 4 == 0 && (((uintptr_t)ys) & 15) == 0) {
+        // 4k channels: 16 bytes per lane - a channel quad of a frame (the scalar form below ran cfg5's shape at 4.0 TB/s where the
+        // stereo form runs 6.6: a 4-byte access and a 64-bit modulo per element).  A chunk starts on a frame, so a lane's quad is
+        // (4 * lane + k * 4 * threads) mod C: constant over the loop whenever 4 * threads is a multiple of C (4, 8, 16, 32 ... channels)
+        int at = (int)((4 * threadIdx.x) % (unsigned)C);
+        const int step = (int)((4 * kEpiThreads) % (unsigned)C);
+        float4 sc = make_float4(scale[at], scale[at + 1], scale[at + 2], scale[at + 3]);
+        for (int64_t e = e0 + 4 * threadIdx.x; e < e1; e += 4 * kEpiThreads) {
+            float4 v = *(float4 *)(ys + e);
+            v.x = v.x * sc.x; v.y = v.y * sc.y; v.z = v.z * sc.z; v.w = v.w * sc.w;
+            *(float4 *)(ys + e) = v;
+            if (step != 0) {
+                at += step; if (at >= C) at -= C;
+                sc = make_float4(scale[at], scale[at + 1], scale[at + 2], scale[at + 3]);
             }
         }
     } else {
