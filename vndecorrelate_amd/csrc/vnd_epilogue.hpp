@@ -449,10 +449,10 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
             const v4i ry = make_rsrc(ys + f0 * 2, (n - f0) * 8);
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
-                if (a.wide) {                                  // streams start 16-byte aligned: two frames per access
-#pragma unroll
+                if (a.wide) {                                  // streams start 16-byte aligned: two frames per access,
+#pragma unroll                                                 // a wave's 64 lanes on 1 KB of consecutive bytes (frames 2*tid + 512*(k/2), + 1)
                     for (int k = 0; k < 4; k += 2) {
-                        const int fr = u * (BF / PER) + 4 * tid + k;
+                        const int fr = u * (BF / PER) + (a.wide == 2 ? 2 * tid + 256 * k : 4 * tid + k);
                         if (!split || arr == 1) {
                             const v4f ty = buf_load4(ry, fr * 8, 0, 0);
                             yr[u][k] = v2f{ty.x, ty.y}; yr[u][k + 1] = v2f{ty.z, ty.w};
@@ -487,6 +487,23 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
         if constexpr (STEREO) {
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
+                if (a.wide == 2) {                             // (the coalesced mapping of fetch: frame pairs 2*tid + 512*h)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        float2 *dst = (float2 *)(sq + u * (BF / PER) + 2 * tid + 512 * h);
+                        if (split) {
+                            const v2f (&vr)[4] = arr ? yr[u] : xr[u];
+                            dst[0 * BF / 2] = make_float2(vr[2 * h].x * vr[2 * h].x, vr[2 * h + 1].x * vr[2 * h + 1].x);
+                            dst[1 * BF / 2] = make_float2(vr[2 * h].y * vr[2 * h].y, vr[2 * h + 1].y * vr[2 * h + 1].y);
+                            continue;
+                        }
+                        dst[0 * BF / 2] = make_float2(xr[u][2 * h].x * xr[u][2 * h].x, xr[u][2 * h + 1].x * xr[u][2 * h + 1].x);
+                        dst[1 * BF / 2] = make_float2(xr[u][2 * h].y * xr[u][2 * h].y, xr[u][2 * h + 1].y * xr[u][2 * h + 1].y);
+                        dst[2 * BF / 2] = make_float2(yr[u][2 * h].x * yr[u][2 * h].x, yr[u][2 * h + 1].x * yr[u][2 * h + 1].x);
+                        dst[3 * BF / 2] = make_float2(yr[u][2 * h].y * yr[u][2 * h].y, yr[u][2 * h + 1].y * yr[u][2 * h + 1].y);
+                    }
+                    continue;
+                }
                 float4 *dst = (float4 *)(sq + u * (BF / PER) + 4 * tid);
                 if (split) {                                   // this workgroup's array only: its two chains are rows 0 and 1
                     const v2f (&vr)[4] = arr ? yr[u] : xr[u];
@@ -631,7 +648,7 @@ __device__ __forceinline__ void par_stage(const RArgs &a, int64_t b, int blk, fl
     const v4i ry = make_rsrc(ys, (a.n - f0) * 8);
     // 8 bytes per access where a stream's first sample is only 8-byte aligned (n odd, or a misaligned base): a.wide says when whole
     // 16-byte accesses are safe - they move the same bytes at 1.4-1.8x the rate (MI355X_MICROARCH.md: 8-byte accesses 0.54-0.70x)
-    if (a.wide) {
+    if (a.wide == 2) {
         // whole 16-byte accesses, a wave's 64 lanes on 1 KB of CONSECUTIVE bytes (8 cache lines per access; a lane taking 32 consecutive
         // bytes as two accesses made each of them 16 half-used lines - round 6): a lane holds frame pairs 2*tid + 512*k of y (and of a
         // stereo x), frames 4*tid + 1024*u .. + 3 of a mono x
