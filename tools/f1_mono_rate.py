@@ -28,7 +28,6 @@ for cx in (1, 2):
         if cx == 2 and fan == '0' and not lr and pool < 256:
             continue
         os.environ['VND_EPI_SUMS_ONLY'] = fan
-        os.environ['VND_EPI_SEQ_COALESCED'] = fan       # (pools of 256 streams and more: the per-stream sums kernel's load mapping)
         os.environ['VND_WIN_FANOUT_EPI'] = fan          # (0: a mono input's exact stage through the pair-read form + a pass for the block sums, as until round 6)
         table.prepare(pool, n, cx, mode)
         run = lambda: table.decorrelate_device(x.data_ptr(), y.data_ptr(), pool, n, cx, mode=mode, ms_encode=not lr, width=None, normalize=1,

@@ -425,6 +425,9 @@ __device__ __forceinline__ float seq_sum_block(const float *row, float acc, int 
 // blockDim.x = 64 * W, W = min(2C, 16) waves; wave w owns chains w, w + W, ...
 // STEREO: C == 2, branch-free vector staging (range-checked buffer loads: frames past the end
 // read 0 and add +0, exact); MONO: x has one channel, fanned out.
+// (Round 6 tried this kernel's loads on consecutive bytes per wave access, as the block-parallel staging now has them: 256 mono streams
+//  1.350 -> 1.463 ms, stereo 1.401 -> 1.419 - and the mere presence of both mappings behind a uniform branch cost 19 % (569 -> 677 us):
+//  the kernel is as it was.)
 template <bool STEREO, bool MONO, int BF = (STEREO ? kSeqFramesStereo : kSeqFrames)>
 __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(const EArgs a)
 {
@@ -449,10 +452,10 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
             const v4i ry = make_rsrc(ys + f0 * 2, (n - f0) * 8);
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
-                if (a.wide) {                                  // streams start 16-byte aligned: two frames per access,
-#pragma unroll                                                 // a wave's 64 lanes on 1 KB of consecutive bytes (frames 2*tid + 512*(k/2), + 1)
+                if (a.wide) {                                  // streams start 16-byte aligned: two frames per access
+#pragma unroll
                     for (int k = 0; k < 4; k += 2) {
-                        const int fr = u * (BF / PER) + (a.wide == 2 ? 2 * tid + 256 * k : 4 * tid + k);
+                        const int fr = u * (BF / PER) + 4 * tid + k;
                         if (!split || arr == 1) {
                             const v4f ty = buf_load4(ry, fr * 8, 0, 0);
                             yr[u][k] = v2f{ty.x, ty.y}; yr[u][k + 1] = v2f{ty.z, ty.w};
@@ -487,23 +490,6 @@ __global__ __launch_bounds__(64 * kSeqMaxWaves) void epilogue_rms_seq_kernel(con
         if constexpr (STEREO) {
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
-                if (a.wide == 2) {                             // (the coalesced mapping of fetch: frame pairs 2*tid + 512*h)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        float2 *dst = (float2 *)(sq + u * (BF / PER) + 2 * tid + 512 * h);
-                        if (split) {
-                            const v2f (&vr)[4] = arr ? yr[u] : xr[u];
-                            dst[0 * BF / 2] = make_float2(vr[2 * h].x * vr[2 * h].x, vr[2 * h + 1].x * vr[2 * h + 1].x);
-                            dst[1 * BF / 2] = make_float2(vr[2 * h].y * vr[2 * h].y, vr[2 * h + 1].y * vr[2 * h + 1].y);
-                            continue;
-                        }
-                        dst[0 * BF / 2] = make_float2(xr[u][2 * h].x * xr[u][2 * h].x, xr[u][2 * h + 1].x * xr[u][2 * h + 1].x);
-                        dst[1 * BF / 2] = make_float2(xr[u][2 * h].y * xr[u][2 * h].y, xr[u][2 * h + 1].y * xr[u][2 * h + 1].y);
-                        dst[2 * BF / 2] = make_float2(yr[u][2 * h].x * yr[u][2 * h].x, yr[u][2 * h + 1].x * yr[u][2 * h + 1].x);
-                        dst[3 * BF / 2] = make_float2(yr[u][2 * h].y * yr[u][2 * h].y, yr[u][2 * h + 1].y * yr[u][2 * h + 1].y);
-                    }
-                    continue;
-                }
                 float4 *dst = (float4 *)(sq + u * (BF / PER) + 4 * tid);
                 if (split) {                                   // this workgroup's array only: its two chains are rows 0 and 1
                     const v2f (&vr)[4] = arr ? yr[u] : xr[u];

@@ -91,7 +91,7 @@ static const char *const kTuningNames[] = {
     "VND_WIN_SPLIT_LATE", "VND_WIN_SPLIT_SMALL_NT", "VND_WIN_TAIL",
     // which form runs
     "VND_WIN_EXACT", "VND_WIN_SPLIT_CLASS", "VND_WIN_QUAD", "VND_WIN_OCTET", "VND_WIN_WIDE", "VND_WIN_SPLIT", "VND_WIN_SPLIT_FANOUT", "VND_WIN_FANOUT_EPI", "VND_WIN_XPOSE_PAIRS", "VND_WIN_FAR_FIRST", "VND_WIN_ADDS", "VND_WIN_EXACT_MERGED",
-    "VND_WIN_SOURCE_FANOUT", "VND_WIN_SOURCE_EPI", "VND_EPI_BLOCK_SUMS", "VND_EPI_SUMS_ONLY", "VND_EPI_WIDE", "VND_EPI_SEQ_SPLIT", "VND_EPI_SEQ_COALESCED", "VND_EPI_PAR_COALESCED",
+    "VND_WIN_SOURCE_FANOUT", "VND_WIN_SOURCE_EPI", "VND_EPI_BLOCK_SUMS", "VND_EPI_SUMS_ONLY", "VND_EPI_WIDE", "VND_EPI_SEQ_SPLIT", "VND_EPI_PAR_COALESCED",
     // one-round launches, pacing, priorities, cache policies
     "VND_WIN_CHUNKS", "VND_WIN_CHUNK_LEN0", "VND_WIN_STAGGER_TICKS", "VND_WIN_PACE", "VND_WIN_PACE_MIN_TILES", "VND_WIN_PRIO", "VND_SPEC_LOAD_AUX",
     "VND_SPEC_STORE_AUX", "VND_NT_MIN_MB", "VND_NO_NT", "VND_FORCE_NT",

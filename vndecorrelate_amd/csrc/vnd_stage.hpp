@@ -53,12 +53,11 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
     e.w_mid = (float)(1.0 - width); e.w_side = (float)width;   // float32(python float), as NumPy's in-place multiply
     e.normalize = normalize ? 1 : 0; e.eps = eps;
     e.wide = (((uintptr_t)y & 15) == 0 && ((uintptr_t)x & (Cx == 1 ? 7 : 15)) == 0 && (batch == 1 || n % 2 == 0) && spec_env("VND_EPI_WIDE", 1) != 0) ? 1 : 0;
-    // (wide == 2: a wave's 16-byte accesses on consecutive bytes instead of 32 consecutive bytes per lane as two accesses.  The block-parallel
-    //  sums' staging takes it - interleaved A/B at 128 / 64 / 32 streams: stereo +1 ... 3 %, mono +3 ... 10 %, the quads of a wider signal
-    //  441 -> 348 us - the per-stream kernel of pools of 256 streams and more does NOT: 256 mono streams 1.350 -> 1.463 ms with it, stereo
-    //  1.401 -> 1.419 (tools/stage_coalesced_ab.py, profiles/r06_f1_mono.txt); VND_EPI_SEQ_COALESCED=1 is that experiment)
+    // (wide == 2, the block-parallel sums' staging: a wave's 16-byte accesses on consecutive bytes instead of 32 consecutive bytes per
+    //  lane as two accesses - interleaved A/B at 128 / 64 / 32 streams: stereo +1 ... 3 %, mono +3 ... 10 %, the quads of a wider signal
+    //  441 -> 348 us (tools/stage_coalesced_ab.py).  The per-stream kernel of pools of 256 streams and more keeps its own mapping:
+    //  it measured slower with this one - see epilogue_rms_seq_kernel)
     const int wide_par = e.wide ? (spec_env("VND_EPI_PAR_COALESCED", 1) != 0 ? 2 : 1) : 0;
-    if (e.wide && spec_env("VND_EPI_SEQ_COALESCED", 0) != 0) e.wide = 2;
     const dim3 grid((unsigned)epi_chunks(n), (unsigned)batch);
 
     // Fused form: the fast kernel applies the pointwise steps and writes one row of sums per tile.
