@@ -551,7 +551,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
         if (len0_env > 0 && len0_env < w) { best_len0 = len0_env; best = -1.0; }
         if (w >= 2 && best < uniform - 1e-9 && best_len0 < w && w * (cps - 1) < tiles_total) {
             p.chunk_tiles = (int)w; p.chunk_len0 = (int)best_len0; p.chunks_per_stream = (int)cps; p.cus_per_xcd = cus / 8;
-            p.stagger_ticks = std::max(0, spec_env("VND_WIN_STAGGER_TICKS", 300));      // 3 us: about the first workgroup's ring fill - the later one loads while that one computes (tools/ablate/run_r4b.sh, run_r4c.sh)
+            p.stagger_ticks = std::max(0, spec_env("VND_WIN_STAGGER_TICKS", 300));      // 3 us: about the first workgroup's ring fill - the later one loads while that one computes (tools/ablate/RUNS.md: run_r4b, run_r4c.sh)
             p.units = (uint32_t)(2 * cus);
             p.nblocks = p.units;
         }

@@ -38,7 +38,7 @@ struct WinGeom {
     // octets: the 4-byte staging writes and read-backs of a wave touch, per channel plane, one dword of 32 frames x 2 quads.  The frames
     // fall into banks 8a + b (a = 0..7 chunk planes an odd number of slots apart, b = 0..3 frames of a chunk): half the banks.  The second
     // quad's plane sets are shifted by 16 bytes so that it takes the other half (8a + 4 + b) instead of meeting the first in the same ones:
-    // SQ_LDS_BANK_CONFLICT 22.1 M -> 14.1 M cycles per cfg5 launch (tools/ablate/run_r4j.sh) - and the launch takes the same time: the
+    // SQ_LDS_BANK_CONFLICT 22.1 M -> 14.1 M cycles per cfg5 launch (tools/ablate/RUNS.md: run_r4j) - and the launch takes the same time: the
     // staging phase is not what the LDS array limits.
     int quad_pad() const { return quad == 2 ? 16 : 0; }
     size_t lds_bytes() const { return (size_t)(quad ? 2 * quad : 1) * (size_t)npl * (size_t)(M / 4) * (size_t)plane + (size_t)quad_pad(); }
@@ -72,7 +72,7 @@ inline bool win_geometry(const SpecTable &t, int M, int nt, int G, bool bc, size
         // the 8-byte accesses of the staging and of the transposition: 16 lanes at a time write (read) 32 dwords into 32 banks -
         // 8 planes x 2 halves of ONE entry with 32-frame runs (4 planes of two entries with 16, 8 of the 16 planes with 64) - so the
         // planes must lie an ODD multiple of 8/QC slots apart (QC = 8: an odd number of slots; QC = 4: 2 mod 4; QC = 16: odd).
-        // Counted, not guessed (SQ_LDS_BANK_CONFLICT per launch of 512 cfg2 streams, tools/ablate/run_r3f.sh): odd 7.7 M,
+        // Counted, not guessed (SQ_LDS_BANK_CONFLICT per launch of 512 cfg2 streams, tools/ablate/RUNS.md: run_r3f): odd 7.7 M,
         // 2 mod 4 - the rule until late round 3 - 16.2 M, 4 mod 8 56 M, 0 mod 8 137 M.
         // 32-frame runs: with the lanes' pair indices swizzled (VW_LANE_SWIZZLE, the kernel) planes 2 mod 4 slots apart make
         // BOTH the 16-lane writes and the 32-lane read-backs conflict-free
