@@ -455,7 +455,7 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
     // (a mono input under the decorrelate stage's pointwise steps, exact mode - VelvetNoise.decorrelate of mono signals,
     //  decorrelation.py:428-440 - rides the plain form too since round 6: both channels' passes read the one plane set, the store
     //  phase has the mono frame for the side-channel encode and leaves the block sums of the exact RMS; until then the pair-read form
-    //  plus a pass of its own for those sums: 128 x 10 s 0.916 -> 0.655 ms, bit-identical; pools of 256 streams and more, whose sums
+    //  plus a pass of its own for those sums: 128 x 10 s 0.916 -> 0.655 ms, bit-identical; pools of more than 320 streams, whose sums
     //  run per stream and take no block sums, stay 2 % ahead in the pair-read form and keep it: profiles/r06_f1_mono.txt)
     if (!picked && win_mode_ok && win_c && (!bc || vw >= 2 || (pointwise2 && epi->blk_sum != nullptr && mode == VND_MODE_EXACT && spec_env("VND_WIN_FANOUT_EPI", 1) != 0)))
         picked = win_pick_config(t->spec_table, (size_t)ctx->lds_limit, win_m, attempt == 1, bc, &p.cfg, rejected);

@@ -80,7 +80,7 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
     // arrays for them otherwise.  Which form, by batch (tools/rms_batch_rate.py, 10 s signals, ms per stage: per-stream / block-parallel):
     //   up to 64 streams the one-workgroup-per-stream kernel leaves most CUs dark (16: 0.49 / 0.17);
     //   65 .. 255: it still fills less than every CU once (128: 0.80 / 0.82, and 0.66 once the block sums come from the convolution);
-    //   256 and more: it fills the chip by itself and reads the data once instead of twice (1024: 4.36 / 6.76).
+    //   more than 320: it fills the chip by itself and reads the data once instead of twice (1024: 4.43 / 5.0; the switch was at 256 until round 6).
     // variant bit 19 keeps the per-stream kernel, bit 17 forces the block-parallel form (A/B runs).
     // Wider signals (round 5): the same kernels channel pair by channel pair - a "stream" of theirs is one pair of a stream (RArgs::pairs),
     // 8 bytes of every frame.  The per-stream kernel takes 16 workgroups for cfg5's pool of 16 signals (8.7 ms for the stage); the
@@ -102,7 +102,9 @@ static vnd_status decorrelate_dev(vnd_ctx *ctx, const vnd_taps *t, const float *
         r.prefixed = r.nblocks > kParPrefixBlocks ? 1 : 0;
         r.wide = wide_par;
     }
-    const bool want_blk = par_ok && C == 2 && (batch < 256 || par_forced) && spec_env("VND_EPI_BLOCK_SUMS", 1) != 0;
+    // (round 6, with the tally's staging on consecutive bytes: 256 streams 1.27-1.37 -> 1.22-1.25 ms block-parallel; from 384 on the per-stream
+    //  kernel leads, 1.70 against 1.80-1.84 - tools/f1_threshold_try.py, profiles/r06_f1_threshold.txt)
+    const bool want_blk = par_ok && C == 2 && (batch <= 320 || par_forced) && spec_env("VND_EPI_BLOCK_SUMS", 1) != 0;
     bool sums_pending = false;                             // the sequential sums still have to run
     // 4k channels, fast mode, the normaliser alone (LR mode - cfg5 through the class API, decorrelation.py:433-440): the quad / octet
     // kernel's store phase leaves the sums of squares on its way (x still in the ring, y in registers), one streaming pass scales:
