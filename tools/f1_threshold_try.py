@@ -14,7 +14,7 @@ vn = vnd.VelvetNoise(sample_rate_hz=48000, seed=1)
 table = vn._device_table()
 ctx = _native.default_context()
 st = torch.cuda.current_stream().cuda_stream
-for pool in (192, 256, 384, 512, 1024):
+for pool in ([int(a) for a in sys.argv[1:]] or [192, 256, 320, 384, 512, 1024]):
     torch.manual_seed(pool)
     x = torch.empty((pool, n, 2), dtype=torch.float32, device='cuda').uniform_(-1, 1)
     y = torch.empty_like(x)
