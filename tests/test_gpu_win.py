@@ -608,3 +608,41 @@ def test_round6_forms_against_the_forms_they_replaced(env, golden, monkeypatch):
             assert np.array_equal(cls.convolve_host(np.ascontiguousarray(xs[:, :, :1]), d.MODE_EXACT), want_m), split
     finally:
         ctx.set_variant(-1)
+
+
+@pytest.mark.parametrize('pool,n', [(7, 3 * 8192 + 50), (13, 8192 * 2), (5, 70000), (3, 200002)])
+def test_balanced_cut_equals_the_spans(env, golden, monkeypatch, pool, n):
+    """Round 6: pools whose spans would fill the one round of workgroups unevenly are cut into equal contiguous ranges of the pool's
+    tiles (vnd_win_kernel.inc: bal_total) - a workgroup's range may end inside a stream and go on in the next one.  Forced here
+    (VND_WIN_BALANCE=2) on small ragged pools - ranges of a tile or two, ranges over three streams, tails inside a tile: exact mode
+    bit for bit the oracle on every stream, fast mode the very bits of the uniform spans (an output depends on table and position
+    alone), function- and class-path tables, a mono input."""
+    d, native, ctx = env
+    ctx.set_variant(FORCE)
+    rng = np.random.default_rng(pool * 1000 + n % 997)
+    try:
+        fir = golden.fir('g48k_k30')
+        table = _table(native, ctx, fir)
+        x = rng.uniform(-1, 1, (pool, n, 2)).astype(np.float32)
+        want = c_oracle.convolve(x, *O.fir_to_taps(fir), threads=4)
+        outs = {}
+        for bal in ('2', '0'):
+            monkeypatch.setenv('VND_WIN_BALANCE', bal)
+            text = table.describe(pool, n, 2, d.MODE_FAST)
+            assert ('balanced ranges' in text) == (bal == '2'), text
+            outs[bal] = table.convolve_host(x, d.MODE_FAST)
+            assert np.array_equal(table.convolve_host(x, d.MODE_EXACT), want), bal
+        assert np.array_equal(outs['2'], outs['0']) and _err(outs['2'], want) <= TOL_PEAK
+        monkeypatch.setenv('VND_WIN_BALANCE', '2')
+        xm = np.ascontiguousarray(x[:, :, :1])
+        want_m = c_oracle.convolve(np.ascontiguousarray(np.repeat(xm, 2, axis=2)), *O.fir_to_taps(fir), threads=4)
+        assert 'balanced ranges' in table.describe(pool, n, 1, d.MODE_EXACT)
+        assert np.array_equal(table.convolve_host(xm, d.MODE_EXACT), want_m)
+        table.close()
+        cls = d.VelvetNoise(sample_rate_hz=48000, seed=1)._device_table()
+        taps = O.generate_class_taps(sample_rate_hz=48000, seed=1)
+        want_c = np.stack([O.class_convolve(s, taps, (0.85, 0.55, 0.35, 0.2), 2) for s in x])
+        assert 'balanced ranges' in cls.describe(pool, n, 2, d.MODE_EXACT)
+        assert np.array_equal(cls.convolve_host(x, d.MODE_EXACT), want_c)
+    finally:
+        ctx.set_variant(-1)

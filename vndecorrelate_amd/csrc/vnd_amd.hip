@@ -340,6 +340,7 @@ static vnd_status describe(vnd_ctx *ctx, const vnd_taps *t, int64_t batch, int64
             if (sp.cfg.win) {
                 char split[96];
                 if (sp.chunk_tiles > 0) snprintf(split, sizeof split, "a chunk of %d tiles per CU as %d + %d, %d chunks", sp.chunk_tiles, sp.chunk_len0, sp.chunk_tiles - sp.chunk_len0, sp.chunks_per_stream);
+                else if (sp.bal_total > 0) snprintf(split, sizeof split, "balanced ranges of %d tiles, %d in the pool", sp.tiles_per_span, sp.bal_total);
                 else snprintf(split, sizeof split, "%d spans x %d tiles", sp.spans, sp.tiles_per_span);
                 snprintf(text, (size_t)len,
                          "conv_spec%s_window (hipRTC, per table) frames_per_lane=%d tile=%d reads_ahead=%d "

@@ -296,6 +296,7 @@ struct SpecPlan {
     // a small launch's CU chunks (window form, stereo): chunk_tiles consecutive tiles per CU, its first-dispatched workgroup takes
     // chunk_len0 of them, the second the rest (0: uniform spans)
     int chunk_tiles = 0, chunk_len0 = 0, chunks_per_stream = 0, cus_per_xcd = 0, stagger_ticks = 0;
+    int bal_total = 0;              // > 0: the BALANCED cut - every workgroup a contiguous range of the pool's streams x tiles_total tiles
     const char *why = "";           // when !use: the reason, for vnd_describe_launch
 };
 
@@ -556,6 +557,27 @@ static SpecPlan make_spec_plan(const vnd_ctx *ctx, const vnd_taps *t, const floa
             p.nblocks = p.units;
         }
     }
+    // ---- spans that fill the one round unevenly: the BALANCED cut ------------------------------------------------------
+    // 192 ten-second streams are 960 spans of 12 tiles on 512 resident workgroups: most walk two, the launch takes 24 tile periods for
+    // 22.1 tiles of work per workgroup (0.608 of 8 TB/s where 128 and 256 streams run 0.66-0.67, profiles/r06_pool_sweep.txt).  Instead
+    // every workgroup takes a contiguous range of the pool's tiles, the same number (+- 1); a range that crosses into the next stream
+    // starts a new ring there.  Taken when a two-line cost model (a ring fill = 0.55 tile periods) puts it 3 % ahead of the spans.
+    p.bal_total = 0;
+    if (p.cfg.win && C == 2 && p.chunk_tiles == 0 && !(v >= 0 && ((v >> 28) & 7)) && !(v >= 0 && ((v >> 20) & 7)) && spec_env("VND_WIN_BALANCE", 1) != 0) {
+        const int64_t total = batch * tiles_total;
+        const int64_t wgs = std::min<int64_t>(resident, total / 4);                      // (at least 4 tiles per workgroup)
+        if (wgs >= 1 && total < 0x7fffffffLL) {
+            const int64_t per_wg = (total + wgs - 1) / wgs;
+            const int64_t uni_units = (units * spans + p.nblocks - 1) / p.nblocks;         // units the busiest workgroup walks
+            const double cost_spans = (double)uni_units * ((double)per_span + 0.55);
+            const double cost_bal = (double)per_wg + 0.55 * (1.0 + (double)per_wg / (double)tiles_total);
+            if (per_wg <= max_tiles && (spec_env("VND_WIN_BALANCE", 1) == 2 || cost_bal < 0.97 * cost_spans)) {      // (a range stays under 2 GiB of descriptor offsets)
+                p.bal_total = (int)total;
+                p.nblocks = (uint32_t)wgs; p.units = (uint32_t)wgs;
+                p.tiles_per_span = (int)per_wg; p.spans = 0;                           // (what the description and the pacing rule read)
+            }
+        }
+    }
     p.use = true;
     // (window form: 8192-frame tiles down to 3 per span - 256 one-second streams 42.6 us with them, 45.7 with 4096-frame
     //  tiles; at 2 per span - 128 such streams - the smaller tiles win, 26.3 against 28.1 us: tools/closed/shard_try.py)
@@ -643,7 +665,7 @@ static vnd_status launch_spec(vnd_ctx *ctx, const vnd_taps *t, const SpecPlan &p
         (int64_t)p.units * p.tiles_per_span >= (int64_t)p.nblocks * spec_env("VND_WIN_PACE_MIN_TILES", 16)) {
         a.pace = ctx->pace;                                  // made and zeroed by vnd_ctx_create: a *_dev launch only enqueues (null: no pacing)
     }
-    a.stagger_ticks = p.stagger_ticks; a.chunk_prio = 1;
+    a.stagger_ticks = p.stagger_ticks; a.chunk_prio = 1; a.bal_total = p.bal_total;
     if (epi != nullptr && p.cfg.epi) {
         a.epi_ms_encode = epi->ms_encode; a.epi_use_width = epi->use_width; a.epi_w_mid = epi->w_mid; a.epi_w_side = epi->w_side;
         // a wave of the plain 32-frame form owns one 2048-frame block of the sums (kParFrames)

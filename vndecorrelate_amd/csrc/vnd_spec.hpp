@@ -93,7 +93,7 @@ static const char *const kTuningNames[] = {
     "VND_WIN_EXACT", "VND_WIN_SPLIT_CLASS", "VND_WIN_QUAD", "VND_WIN_OCTET", "VND_WIN_WIDE", "VND_WIN_SPLIT", "VND_WIN_SPLIT_FANOUT", "VND_WIN_FANOUT_EPI", "VND_WIN_XPOSE_PAIRS", "VND_WIN_FAR_FIRST", "VND_WIN_ADDS", "VND_WIN_EXACT_MERGED",
     "VND_WIN_SOURCE_FANOUT", "VND_WIN_SOURCE_EPI", "VND_EPI_BLOCK_SUMS", "VND_EPI_SUMS_ONLY", "VND_EPI_WIDE", "VND_EPI_SEQ_SPLIT", "VND_EPI_PAR_COALESCED",
     // one-round launches, pacing, priorities, cache policies
-    "VND_WIN_CHUNKS", "VND_WIN_CHUNK_LEN0", "VND_WIN_STAGGER_TICKS", "VND_WIN_PACE", "VND_WIN_PACE_MIN_TILES", "VND_WIN_PRIO", "VND_SPEC_LOAD_AUX",
+    "VND_WIN_CHUNKS", "VND_WIN_BALANCE", "VND_WIN_CHUNK_LEN0", "VND_WIN_STAGGER_TICKS", "VND_WIN_PACE", "VND_WIN_PACE_MIN_TILES", "VND_WIN_PRIO", "VND_SPEC_LOAD_AUX",
     "VND_SPEC_STORE_AUX", "VND_NT_MIN_MB", "VND_NO_NT", "VND_FORCE_NT",
     // diagnosis builds
     "VND_WIN_STAMPS", "VND_WIN_STAMP_PHASES", "VND_WIN_STAMP_WAVE",
@@ -399,7 +399,7 @@ struct SpecArgs {
     float epi_w_mid, epi_w_side;
     // window form only (VWArgs): a small launch's CU chunks - see vnd_win_kernel.inc
     int chunk_tiles, chunk_len0, chunks_per_stream, cus_per_xcd;
-    int stagger_ticks, chunk_prio, reserved0;
+    int stagger_ticks, chunk_prio, bal_total;      // (bal_total: the balanced cut of the window form - vnd_win_kernel.inc)
     double *epi_blk_sum;          // VW_EPI with 32-frame runs: per-block sums of squares for the block-parallel exact RMS sums
     int epi_nblocks, epi_rows_major;
     unsigned *pace;               // [2048 CU indices][2] tile counters of co-resident workgroups (window form: pacing)
