@@ -644,5 +644,20 @@ def test_balanced_cut_equals_the_spans(env, golden, monkeypatch, pool, n):
         want_c = np.stack([O.class_convolve(s, taps, (0.85, 0.55, 0.35, 0.2), 2) for s in x])
         assert 'balanced ranges' in cls.describe(pool, n, 2, d.MODE_EXACT)
         assert np.array_equal(cls.convolve_host(x, d.MODE_EXACT), want_c)
+        # ... and under the decorrelate stage (pointwise steps and the RMS block sums in the store phase: a block's index comes from the
+        # range's first tile): the generic kernels' bytes
+        import torch
+        xd = torch.from_numpy(x).cuda()
+        ws_bytes = native.decorrelate_workspace_bytes(pool, n, 2)
+        outs = {}
+        for label, variant in (('balanced', FORCE | (1 << 15)), ('generic', GENERIC)):
+            ctx.set_variant(variant)
+            yd = torch.empty_like(xd)
+            ws = torch.zeros(ws_bytes // 8 + 1, dtype=torch.float64, device='cuda')
+            cls.decorrelate_device(xd.data_ptr(), yd.data_ptr(), pool, n, 2, mode=d.MODE_EXACT, ms_encode=True, width=0.3, normalize=True,
+                                   workspace_ptr=ws.data_ptr(), workspace_bytes=ws_bytes, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            outs[label] = yd
+        assert torch.equal(outs['balanced'], outs['generic'])
     finally:
         ctx.set_variant(-1)
